@@ -1,0 +1,146 @@
+"""Autograd wiring shared by the Needleman-Wunsch and Smith-Waterman operators.
+
+Mirrors the reference's Function pair (deepblast/nw_cuda.py:168-262, nw.py:315-386):
+
+    Function.forward(theta, A, operator)            -> Vt            saves (theta, A, state)
+    Function.backward(Et)                           -> (E, A, None)  via FunctionBackward.apply
+    FunctionBackward.forward(theta, A, Et, Q, op)   -> (E, A)        saves (state, E)
+    FunctionBackward.backward(Ztheta, ZA)           -> (Ed, None, Vtd, None, None)
+
+and keeps its gradient-flow quirks: the first-order "gradient" returned
+for A is A itself (nw.py:337-339,355); the second-order gradient w.r.t. A is None
+(nw.py:386); Et may be non-uniform.
+
+Differences that are part of the design, not of the maths: `Q` is an opaque state tensor
+(flat fp32, library-private layout) instead of (B,N+2,M+2,3), and E is produced directly
+as (B,N,M) -- the reference's E[:,1:-1,1:-1] -- without materialising the zero border.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _engine
+
+
+def _validate(theta, A, operator, allow_none_operator):
+    # error behaviour of the reference GPU variant (nw_cuda.py:171-175)
+    if operator != 'softmax' and not (allow_none_operator and operator is None):
+        raise NotImplementedError("HIP variant only supports 'softmax' operator")
+    if theta.dtype != torch.float32:
+        raise TypeError("HIP variant only supports torch.float32 type")
+    if theta.dim() != 3 or A.shape != theta.shape:
+        raise ValueError(f"theta and A must both be (B, N, M); got {tuple(theta.shape)} and {tuple(A.shape)}")
+
+
+def make_functions(variant, prefix, allow_none_operator=False):
+    """Build the (Function, FunctionBackward) pair for one variant."""
+
+    class FunctionBackward(torch.autograd.Function):
+
+        @staticmethod
+        def forward(ctx, theta, A, Et, Q, operator, lens=None):
+            eng = _engine.get_engine()
+            E = eng.backward(Et.detach(), Q, tuple(theta.shape), variant, lens)
+            ctx.save_for_backward(Q, E)
+            ctx.others = (operator, lens)
+            return E, A
+
+        @staticmethod
+        def backward(ctx, Ztheta, ZA):
+            Q, E = ctx.saved_tensors
+            _, lens = ctx.others
+            eng = _engine.get_engine()
+            Vtd, Qd = eng.adjoint_forward(Q, Ztheta, ZA, variant, lens)
+            Ed = eng.adjoint_backward(E, Q, Qd, variant, lens)
+            return Ed, None, Vtd, None, None, None
+
+    class Function(torch.autograd.Function):
+
+        @staticmethod
+        def forward(ctx, theta, A, operator, lens=None):
+            _validate(theta, A, operator, allow_none_operator)
+            eng = _engine.get_engine()
+            Vt, Q = eng.forward(theta.detach(), A.detach(), variant, lens)
+            ctx.save_for_backward(theta, A, Q)
+            ctx.others = (operator, lens)
+            return Vt
+
+        @staticmethod
+        def backward(ctx, Et):
+            theta, A, Q = ctx.saved_tensors
+            operator, lens = ctx.others
+            E, A = FunctionBackward.apply(theta, A, Et, Q, operator, lens)
+            return E, A, None, None
+
+    Function.__name__ = Function.__qualname__ = prefix + "Function"
+    FunctionBackward.__name__ = FunctionBackward.__qualname__ = prefix + "FunctionBackward"
+    return Function, FunctionBackward
+
+
+def traceback(grad):
+    """Greedy arg-max walk over one (N, M) expected-alignment matrix -> [(i, j, state)].
+
+    Same rule as the reference's CPU decoder (deepblast/nw.py:401-444, sw.py:328-371):
+    start at the bottom-right match, repeatedly step to the largest of
+    left=(i-1,j) [state x=0], diag=(i-1,j-1) [m=1], upper=(i,j-1) [y=2] (first wins ties),
+    stop when all three are off the matrix, then pad the remaining gaps.  The reference
+    reads grad[i-1, j-1] with Python's negative-index wrap when exactly one of i, j is 0
+    and can walk off the matrix (IndexError) on inputs that are not alignment matrices;
+    both behaviours are preserved.
+    """
+    x, m, y = 0, 1, 2
+    g = grad.detach().cpu().numpy() if isinstance(grad, torch.Tensor) else np.asarray(grad)
+    N, M = g.shape
+    floor = -100000
+    i, j = N - 1, M - 1
+    states = [(i, j, m)]
+    while True:
+        left = floor if i <= 0 else g[i - 1, j]
+        diag = floor if (i <= 0 and j <= 0) else g[i - 1, j - 1]
+        upper = floor if j <= 0 else g[i, j - 1]
+        if left == floor and diag == floor and upper == floor:
+            break
+        cands = (left, diag, upper)
+        best = 0
+        for k in (1, 2):
+            if cands[k] > cands[best]:
+                best = k
+        i, j = ((i - 1, j), (i - 1, j - 1), (i, j - 1))[best]
+        states.append((i, j, (x, m, y)[best]))
+    while i > 0:
+        i -= 1
+        states.append((i, j, x))
+    while j > 0:
+        j -= 1
+        states.append((i, j, y))
+    return states[::-1]
+
+
+class _Decoder(nn.Module):
+    """Common body of NeedlemanWunschDecoder / SmithWatermanDecoder (nw_cuda.py:265-325)."""
+
+    _function = None
+
+    def __init__(self, operator):
+        super().__init__()
+        self.operator = operator
+
+    def forward(self, theta, A, lengths=None):
+        """theta, A: (B, N, M) fp32 on a ROCm device -> Vt (B,) on the same device.
+
+        `lengths` (optional, (B,2) int) is an extension: per-pair true sizes of a padded
+        batch; None reproduces the reference (DP over the full padded matrix)."""
+        if lengths is None:
+            return self._function.apply(theta, A, self.operator)
+        return self._function.apply(theta, A, self.operator, lengths)
+
+    def traceback(self, grad):
+        return traceback(grad)
+
+    def decode(self, theta, A, lengths=None):
+        """Expected alignment matrix dVt/dtheta, differentiable (nw_cuda.py:319-325)."""
+        with torch.enable_grad():
+            nll = self.forward(theta, A, lengths)
+            v = torch.sum(nll)
+            v_grad, _ = torch.autograd.grad(v, (theta, A), create_graph=True)
+        return v_grad

@@ -1,0 +1,125 @@
+"""Host-side engine: turns PyTorch-ROCm tensors into raw pointers for the C ABI.
+
+One instance per process.  It owns no device memory: every buffer (state, E, Vt, ...)
+is a torch tensor allocated by the caller's caching allocator on the caller's current
+stream, which is also the stream the kernels are enqueued on -- so ordering with the
+surrounding PyTorch ops needs no extra synchronisation.
+"""
+import torch
+
+from . import _lib
+
+NW, SW = _lib.SDP_NW, _lib.SDP_SW
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class HipEngine:
+    """Thin veneer over libsdp_hip.so.  All tensors must be fp32, contiguous, on one ROCm device."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    # ---- helpers -------------------------------------------------------------------
+    @staticmethod
+    def _dev(t):
+        if not t.is_cuda:
+            raise RuntimeError(
+                "deepblast_amd runs on a ROCm device only (got a CPU tensor); there is no CPU fallback. "
+                "Move theta/A to 'cuda'.")
+        return t.device.index if t.device.index is not None else torch.cuda.current_device()
+
+    @staticmethod
+    def _stream(dev):
+        return torch.cuda.current_stream(dev).cuda_stream
+
+    def max_cols(self):
+        return self.lib.sdp_max_cols()
+
+    def new_state(self, B, N, M, device):
+        nbytes = self.lib.sdp_state_bytes(B, N, M)
+        return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+
+    @staticmethod
+    def _lens(lens, B, device):
+        if lens is None:
+            return None
+        lens = torch.as_tensor(lens, dtype=torch.int32, device=device).contiguous()
+        if lens.shape != (B, 2):
+            raise ValueError(f"lengths must have shape ({B}, 2), got {tuple(lens.shape)}")
+        return lens
+
+    # ---- the four passes -----------------------------------------------------------
+    def forward(self, theta, A, variant, lens=None):
+        """-> (Vt (B,), state).  Replaces _forward_pass_kernel (nw_cuda.py:74-79)."""
+        dev = self._dev(theta)
+        theta, A = theta.contiguous(), A.contiguous()
+        B, N, M = theta.shape
+        lens = self._lens(lens, B, theta.device)
+        state = self.new_state(B, N, M, theta.device)
+        Vt = torch.empty(B, dtype=torch.float32, device=theta.device)
+        with torch.cuda.device(dev):
+            rc = self.lib.sdp_forward_f32(_ptr(theta), _ptr(A), _ptr(state), _ptr(Vt), B, N, M, _ptr(lens),
+                                          variant, dev, self._stream(dev))
+        _lib.check(rc, "sdp_forward_f32")
+        return Vt, state
+
+    def backward(self, Et, state, shape, variant, lens=None):
+        """-> E (B,N,M).  Replaces _backward_pass_kernel (nw_cuda.py:98-102)."""
+        dev = self._dev(state)
+        B, N, M = shape
+        Et = Et.to(torch.float32).expand(B).contiguous()
+        lens = self._lens(lens, B, state.device)
+        E = torch.empty((B, N, M), dtype=torch.float32, device=state.device)
+        with torch.cuda.device(dev):
+            rc = self.lib.sdp_backward_f32(_ptr(Et), _ptr(state), _ptr(E), B, N, M, _ptr(lens), variant, dev,
+                                           self._stream(dev))
+        _lib.check(rc, "sdp_backward_f32")
+        return E
+
+    def adjoint_forward(self, state, Ztheta, ZA, variant, lens=None):
+        """-> (Vtd (B,), state_d).  Replaces _adjoint_forward_pass_kernel (nw_cuda.py:134-139)."""
+        dev = self._dev(state)
+        Ztheta = Ztheta.to(torch.float32).contiguous()
+        B, N, M = Ztheta.shape
+        if ZA is not None:
+            ZA = ZA.to(torch.float32).contiguous()
+        lens = self._lens(lens, B, state.device)
+        state_d = self.new_state(B, N, M, state.device)
+        Vtd = torch.empty(B, dtype=torch.float32, device=state.device)
+        with torch.cuda.device(dev):
+            rc = self.lib.sdp_adjoint_forward_f32(_ptr(state), _ptr(Ztheta), _ptr(ZA), _ptr(Vtd), _ptr(state_d),
+                                                  B, N, M, _ptr(lens), variant, dev, self._stream(dev))
+        _lib.check(rc, "sdp_adjoint_forward_f32")
+        return Vtd, state_d
+
+    def adjoint_backward(self, E, state, state_d, variant, lens=None):
+        """-> Ed (B,N,M).  Replaces _adjoint_backward_pass_kernel (nw_cuda.py:160-165)."""
+        dev = self._dev(state)
+        E = E.contiguous()
+        B, N, M = E.shape
+        lens = self._lens(lens, B, state.device)
+        Ed = torch.empty((B, N, M), dtype=torch.float32, device=state.device)
+        with torch.cuda.device(dev):
+            rc = self.lib.sdp_adjoint_backward_f32(_ptr(E), _ptr(state), _ptr(state_d), _ptr(Ed), B, N, M,
+                                                   _ptr(lens), variant, dev, self._stream(dev))
+        _lib.check(rc, "sdp_adjoint_backward_f32")
+        return Ed
+
+    def selftest(self, device=0):
+        _lib.check(self.lib.sdp_selftest(device), "sdp_selftest")
+
+
+_ENGINE = None
+
+
+def get_engine():
+    """The process-wide engine.  Raises (ImportError) if the HIP library is not built."""
+    global _ENGINE
+    if _ENGINE is None:
+        _ENGINE = HipEngine()
+    return _ENGINE

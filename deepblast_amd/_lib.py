@@ -1,0 +1,71 @@
+"""ctypes binding of libsdp_hip.so (the C ABI in include/sdp.h).
+
+This is the whole FFI: raw device pointers, ints and a stream handle.  There is no
+CPU fallback -- if the shared library is missing the import fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdp_hip.so")
+
+SDP_NW, SDP_SW = 0, 1
+
+_c_f32p = ctypes.c_void_p
+_c_i32p = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/sdp.h declares
+SIGNATURES = {
+    "sdp_version": (ctypes.c_int, []),
+    "sdp_last_error_string": (ctypes.c_char_p, []),
+    "sdp_max_cols": (ctypes.c_int, []),
+    "sdp_state_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "sdp_forward_f32": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_int, _c_i32p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "sdp_backward_f32": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        _c_i32p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "sdp_adjoint_forward_f32": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_int, _c_i32p, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_void_p]),
+    "sdp_adjoint_backward_f32": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int, _c_i32p, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_void_p]),
+    "sdp_selftest": (ctypes.c_int, [ctypes.c_int]),
+    "sdp_set_waves": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+}
+
+_LIB = None
+
+
+class SdpLibraryMissing(ImportError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raise if the HIP library was not built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise SdpLibraryMissing(
+                f"{LIB_PATH} not found: the HIP engine is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or deepblast_amd/build.py). "
+                "deepblast_amd has no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def check(rc, what):
+    """Map the ABI's status codes onto Python exceptions."""
+    if rc == 0:
+        return
+    msg = load().sdp_last_error_string().decode("utf-8", "replace")
+    if rc == -3:
+        raise ValueError(f"{what}: {msg}")
+    if rc in (-1, -2, -4, -5):
+        raise ValueError(f"{what}: {msg}")
+    raise RuntimeError(f"{what}: {msg} (status {rc})")

@@ -1,0 +1,32 @@
+"""Build libsdp_hip.so for gfx950 with hipcc (in-tree, next to this file)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = [os.path.join(HERE, "csrc", "sdp_kernels.hip"), os.path.join(HERE, "csrc", "sdp_api.hip")]
+HDR = [os.path.join(HERE, "csrc", "sdp_kernels.h"), os.path.join(ROOT, "include", "sdp.h")]
+OUT = os.path.join(HERE, "libsdp_hip.so")
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.sep not in c or os.path.exists(c)):
+            return c
+    return "hipcc"
+
+
+def build(force=False, extra=()):
+    newest = max(os.path.getmtime(f) for f in SRC + HDR)
+    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest:
+        return OUT
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
+           *extra, *SRC, "-o", OUT]
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,198 @@
+// sdp_api.hip -- host side of the C ABI declared in include/sdp.h.
+// Validates arguments, sizes the launch and enqueues one kernel per call on the
+// caller's stream.  No allocation, no synchronisation, no global mutable state
+// besides the experiment knob sdp_set_waves().
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "sdp_kernels.h"
+
+namespace {
+
+thread_local char g_err[256] = "";
+int g_waves[4] = {0, 0, 0, 0};
+
+int fail(int code, const char *msg)
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+int fail_hip(hipError_t e, const char *what)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+
+struct PassInfo {
+    const void *kernel;
+    int K, nstage;
+};
+
+PassInfo pass_info(int pass)
+{
+    switch (pass) {
+    case sdp::PASS_FWD: return {(const void *)sdp_fwd_kernel, SDP_K_FWD, 2};
+    case sdp::PASS_BWD: return {(const void *)sdp_bwd_kernel, SDP_K_BWD, 1};
+    case sdp::PASS_AFWD: return {(const void *)sdp_adj_fwd_kernel, SDP_K_AFWD, 2};
+    default: return {(const void *)sdp_adj_bwd_kernel, SDP_K_ABWD, 2};
+    }
+}
+
+int check_shape(int B, int N, int M, int variant)
+{
+    if (B <= 0 || N <= 0 || M <= 0) return fail(SDP_E_SHAPE, "B, N and M must be positive");
+    if (M > sdp::MAX_COLS) return fail(SDP_E_MAXCOLS, "M exceeds sdp_max_cols()");
+    if (variant != SDP_NW && variant != SDP_SW) return fail(SDP_E_VARIANT, "variant must be SDP_NW or SDP_SW");
+    if ((size_t)N * (size_t)M > ((size_t)1 << 28)) return fail(SDP_E_TOOBIG, "N*M exceeds 2^28 cells per pair");
+    return 0;
+}
+
+int launch(int pass, sdp::Params &p, int device, void *stream)
+{
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    const PassInfo pi = pass_info(pass);
+    const int nstrips = sdp::state_nstrips(p.N);
+    int W = g_waves[pass] > 0 ? g_waves[pass] : 4;
+    if (W > 4) W = 4;
+    if (W > nstrips) W = nstrips;
+    const int nslot = W > 1 ? W : 2;
+    p.nstrips_max = nstrips;
+    p.tpad = sdp::state_tpad(p.M);
+    p.mcap = (p.M + 63) / 64 * 64;
+    size_t off = (size_t)nslot * p.mcap * sizeof(double) + 64;  // boundary rows + progress words
+    off = (off + 15) & ~(size_t)15;
+    p.stage_off = (int)off;
+    const size_t lds = off + (size_t)W * pi.nstage * 64 * (pi.K + 1) * sizeof(float);
+    e = hipFuncSetAttribute(pi.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    void *args[] = {&p};
+    e = hipLaunchKernel(pi.kernel, dim3(p.B), dim3(64 * W), args, lds, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "hipLaunchKernel");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sdp_version(void) { return SDP_VERSION; }
+
+const char *sdp_last_error_string(void) { return g_err; }
+
+int sdp_max_cols(void) { return sdp::MAX_COLS; }
+
+size_t sdp_state_bytes(int B, int N, int M)
+{
+    if (B <= 0 || N <= 0 || M <= 0) return 0;
+    return (size_t)B * sdp::state_nstrips(N) * sdp::state_tpad(M) * 64 * sizeof(float2);
+}
+
+int sdp_set_waves(int pass, int waves)
+{
+    if (pass < 0 || pass > 3) return -1;
+    const int old = g_waves[pass];
+    g_waves[pass] = waves;
+    return old;
+}
+
+int sdp_forward_f32(const float *theta, const float *A, float *state, float *Vt, int B, int N, int M,
+                    const int32_t *lens, int variant, int device, void *stream)
+{
+    if (!theta || !A || !state || !Vt) return fail(SDP_E_NULLPTR, "sdp_forward_f32: null pointer");
+    if (int rc = check_shape(B, N, M, variant)) return rc;
+    sdp::Params p = {};
+    p.sin0 = theta;
+    p.sin1 = A;
+    p.dout = reinterpret_cast<float2 *>(state);
+    p.vout = Vt;
+    p.lens = lens;
+    p.B = B, p.N = N, p.M = M, p.variant = variant;
+    return launch(sdp::PASS_FWD, p, device, stream);
+}
+
+int sdp_backward_f32(const float *Et, const float *state, float *E, int B, int N, int M, const int32_t *lens,
+                     int variant, int device, void *stream)
+{
+    if (!Et || !state || !E) return fail(SDP_E_NULLPTR, "sdp_backward_f32: null pointer");
+    if (int rc = check_shape(B, N, M, variant)) return rc;
+    if (lens) {
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipMemsetAsync(E, 0, (size_t)B * N * M * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(E)");
+    }
+    sdp::Params p = {};
+    p.vin = Et;
+    p.din0 = reinterpret_cast<const float2 *>(state);
+    p.sout = E;
+    p.lens = lens;
+    p.B = B, p.N = N, p.M = M, p.variant = variant;
+    return launch(sdp::PASS_BWD, p, device, stream);
+}
+
+int sdp_adjoint_forward_f32(const float *state, const float *Ztheta, const float *ZA, float *Vtd, float *state_d,
+                            int B, int N, int M, const int32_t *lens, int variant, int device, void *stream)
+{
+    if (!state || !Ztheta || !Vtd || !state_d) return fail(SDP_E_NULLPTR, "sdp_adjoint_forward_f32: null pointer");
+    if (int rc = check_shape(B, N, M, variant)) return rc;
+    sdp::Params p = {};
+    p.din0 = reinterpret_cast<const float2 *>(state);
+    p.sin0 = Ztheta;
+    p.sin1 = ZA;
+    p.dout = reinterpret_cast<float2 *>(state_d);
+    p.vout = Vtd;
+    p.lens = lens;
+    p.B = B, p.N = N, p.M = M, p.variant = variant;
+    return launch(sdp::PASS_AFWD, p, device, stream);
+}
+
+int sdp_adjoint_backward_f32(const float *E, const float *state, const float *state_d, float *Ed, int B, int N,
+                             int M, const int32_t *lens, int variant, int device, void *stream)
+{
+    if (!E || !state || !state_d || !Ed) return fail(SDP_E_NULLPTR, "sdp_adjoint_backward_f32: null pointer");
+    if (int rc = check_shape(B, N, M, variant)) return rc;
+    if (lens) {
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipMemsetAsync(Ed, 0, (size_t)B * N * M * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(Ed)");
+    }
+    sdp::Params p = {};
+    p.sin0 = E;
+    p.din0 = reinterpret_cast<const float2 *>(state);
+    p.din1 = reinterpret_cast<const float2 *>(state_d);
+    p.sout = Ed;
+    p.lens = lens;
+    p.B = B, p.N = N, p.M = M, p.variant = variant;
+    return launch(sdp::PASS_ABWD, p, device, stream);
+}
+
+int sdp_selftest(int device)
+{
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    int *d = nullptr;
+    e = hipMalloc(&d, 192 * sizeof(int));
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc");
+    int h[192];
+    for (int i = 0; i < 192; ++i) h[i] = 7777;
+    (void)hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(sdp_selftest_kernel, dim3(1), dim3(64), 0, 0, d);
+    e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail_hip(e, "sdp_selftest_kernel");
+    int bad = 0;
+    for (int i = 0; i < 64; ++i) bad |= h[i];
+    for (int i = 0; i < 64; ++i)
+        if (h[64 + i] != 1000 + i) bad |= 128;   // in-range stores must land
+    for (int i = 128; i < 192; ++i)
+        if (h[i] != 7777) bad |= 256;            // out-of-range stores must be dropped
+    if (bad) {
+        snprintf(g_err, sizeof(g_err), "sdp_selftest: hardware semantics mismatch, mask 0x%x", bad);
+        return SDP_E_SELFTEST;
+    }
+    return 0;
+}
+
+}  // extern "C"

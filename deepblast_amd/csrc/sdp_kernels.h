@@ -1,0 +1,74 @@
+// sdp_kernels.h -- shared between the kernels (sdp_kernels.hip) and the C-ABI host
+// side (sdp_api.hip).  Not part of the public interface (that is include/sdp.h).
+#ifndef SDP_KERNELS_H_
+#define SDP_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sdp.h"
+
+// chunk length K (steps per staged chunk; must divide 64) and direct-state prefetch
+// depth PFD (chunks in flight ahead of the one being consumed) per pass
+#ifndef SDP_K_FWD
+#define SDP_K_FWD 16
+#endif
+#ifndef SDP_K_BWD
+#define SDP_K_BWD 32
+#endif
+#ifndef SDP_PFD_BWD
+#define SDP_PFD_BWD 2
+#endif
+#ifndef SDP_K_AFWD
+#define SDP_K_AFWD 16
+#endif
+#ifndef SDP_PFD_AFWD
+#define SDP_PFD_AFWD 2
+#endif
+#ifndef SDP_K_ABWD
+#define SDP_K_ABWD 16
+#endif
+#ifndef SDP_PFD_ABWD
+#define SDP_PFD_ABWD 2
+#endif
+
+namespace sdp {
+
+enum { PASS_FWD = 0, PASS_BWD = 1, PASS_AFWD = 2, PASS_ABWD = 3 };
+
+constexpr int MAX_COLS = 2048;     // boundary rows live in LDS (4 x MAX_COLS x 8 B = 64 KiB)
+constexpr int PROG_STRIDE = 4096;  // > MAX_COLS: progress words are (use index)*PROG_STRIDE + columns
+
+struct Params {
+    const float *sin0;   // staged (row-major) input plane 0: theta | Ztheta | E
+    const float *sin1;   // staged input plane 1: A | ZA (may be null = zeros)
+    float *sout;         // staged (row-major) output: E | Ed
+    const float2 *din0;  // skewed state in: Q
+    const float2 *din1;  // skewed state in: Qd
+    float2 *dout;        // skewed state out: Q | Qd
+    const float *vin;    // Et
+    float *vout;         // Vt | Vtd
+    const int32_t *lens; // (B,2) or null
+    int B, N, M;
+    int nstrips_max;     // ceil(N/64): strips per pair in the state layout
+    int tpad;            // state rows (steps) per strip: roundup(M+63, 64)
+    int mcap;            // doubles per boundary row in LDS
+    int stage_off;       // byte offset of the per-wave staging area in LDS
+    int variant;
+};
+
+// state geometry (shared by host and device)
+__host__ __device__ inline int state_nstrips(int N) { return (N + 63) / 64; }
+__host__ __device__ inline int state_tpad(int M) { return (M + 63 + 63) / 64 * 64; }
+
+}  // namespace sdp
+
+extern "C" {
+__global__ void sdp_fwd_kernel(const sdp::Params p);
+__global__ void sdp_bwd_kernel(const sdp::Params p);
+__global__ void sdp_adj_fwd_kernel(const sdp::Params p);
+__global__ void sdp_adj_bwd_kernel(const sdp::Params p);
+__global__ void sdp_selftest_kernel(int *out);
+}
+
+#endif  // SDP_KERNELS_H_

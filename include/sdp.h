@@ -1,0 +1,104 @@
+/*
+ * sdp.h -- C ABI of the MI355X soft-DP alignment engine (libsdp_hip.so).
+ *
+ * This is the drop-in boundary for DeepBLAST's differentiable alignment operator.
+ * Each entry point replaces one Numba-CUDA kernel launch of the reference; the
+ * Python side (deepblast_amd/nw.py, sw.py) binds them with ctypes exactly where
+ * the reference launches its kernels:
+ *
+ *   sdp_forward_f32           <- _forward_pass_kernel[tpb,bpg](theta, A, Q, Vt)
+ *                                deepblast/nw_cuda.py:74-79,184-187  (sw_cuda.py:74-79)
+ *   sdp_backward_f32          <- _backward_pass_kernel[tpb,bpg](Et, Q, E)
+ *                                deepblast/nw_cuda.py:98-102,222-226 (sw_cuda.py:98-102)
+ *   sdp_adjoint_forward_f32   <- _adjoint_forward_pass_kernel[tpb,bpg](Q, Ztheta, ZA, Vtd, Qd)
+ *                                deepblast/nw_cuda.py:134-139,258
+ *   sdp_adjoint_backward_f32  <- _adjoint_backward_pass_kernel[tpb,bpg](E, Q, Qd, Ed)
+ *                                deepblast/nw_cuda.py:160-165,259
+ *   sdp_state_bytes           <- torch.zeros((B, N+2, M+2, 3)) for Q / Qd
+ *                                deepblast/nw_cuda.py:180-182,250-252
+ *
+ * Conventions
+ *   - Every tensor pointer is a DEVICE pointer to a contiguous row-major fp32 array
+ *     owned by the caller (PyTorch's caching allocator).  The library never
+ *     allocates, frees or retains device memory.
+ *   - theta, A, ZA, Ztheta, E, Ed are (B, N, M).  E/Ed are written in full
+ *     (the reference's (B,N+2,M+2) zero border is not materialised; its interior
+ *     [:,1:-1,1:-1] is exactly this array).
+ *   - `state` / `state_d` are opaque buffers of sdp_state_bytes(B,N,M) bytes that
+ *     stand in for the reference's Q / Qd tensors.  Their layout is private
+ *     (wavefront-skewed); only this library reads them.
+ *   - `lens` is NULL (reference semantics: every pair uses the full padded N x M)
+ *     or a DEVICE pointer to B x 2 int32 (n_b, m_b): pair b is aligned over its
+ *     top-left n_b x m_b block, terminal cell (n_b, m_b); E/Ed outside the block
+ *     are written as zero.
+ *   - variant: SDP_NW (deepblast/nw.py) or SDP_SW (deepblast/sw.py: the same
+ *     recurrence with padded row 1 / column 1 skipped in forward and backward).
+ *   - `device` is the HIP device ordinal, `stream` a hipStream_t (NULL = default
+ *     stream).  Calls only enqueue work; they never synchronise.
+ *   - Return: 0 ok; negative = SDP_E_* below; positive = hipError_t.  Nothing is
+ *     thrown across the boundary.  sdp_last_error_string() is thread-local.
+ *   - Re-entrant: no global mutable state besides a per-thread error string.
+ */
+#ifndef SDP_H_
+#define SDP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDP_VERSION 100 /* 0.1.0 */
+
+#define SDP_NW 0
+#define SDP_SW 1
+
+#define SDP_E_NULLPTR (-1)  /* a required pointer is NULL */
+#define SDP_E_SHAPE (-2)    /* B, N or M non-positive */
+#define SDP_E_MAXCOLS (-3)  /* M exceeds sdp_max_cols() (reference: max_cols, nw_cuda.py:11) */
+#define SDP_E_VARIANT (-4)  /* variant is neither SDP_NW nor SDP_SW */
+#define SDP_E_TOOBIG (-5)   /* a tensor exceeds the 4 GiB-per-plane addressing limit */
+#define SDP_E_SELFTEST (-6) /* sdp_selftest found a hardware-semantics mismatch */
+
+int sdp_version(void);
+
+/* Human-readable description of the last non-zero return on this thread. */
+const char *sdp_last_error_string(void);
+
+/* Largest M accepted (the reference's GPU path stops at 2047 columns). */
+int sdp_max_cols(void);
+
+/* Bytes of one opaque state buffer (Q or Qd) for a (B,N,M) problem; 0 on bad shape. */
+size_t sdp_state_bytes(int B, int N, int M);
+
+/* Vt[b] = V[n_b, m_b]; state <- softmax weights of every cell. */
+int sdp_forward_f32(const float *theta, const float *A, float *state, float *Vt, int B, int N,
+                    int M, const int32_t *lens, int variant, int device, void *stream);
+
+/* E = dVt/dtheta * Et  (expected alignment matrix), from the saved state. */
+int sdp_backward_f32(const float *Et, const float *state, float *E, int B, int N, int M,
+                     const int32_t *lens, int variant, int device, void *stream);
+
+/* Directional derivative through the DP: Vtd (B,), state_d <- Qd.  ZA may be NULL (= zeros). */
+int sdp_adjoint_forward_f32(const float *state, const float *Ztheta, const float *ZA, float *Vtd,
+                            float *state_d, int B, int N, int M, const int32_t *lens, int variant,
+                            int device, void *stream);
+
+/* Ed = reverse sweep of the derivative (Hessian-vector product w.r.t. theta). */
+int sdp_adjoint_backward_f32(const float *E, const float *state, const float *state_d, float *Ed,
+                             int B, int N, int M, const int32_t *lens, int variant, int device,
+                             void *stream);
+
+/* Runs a few-microsecond device check of the cross-lane (DPP) and buffer-addressing
+ * behaviour the kernels rely on.  Synchronises the device.  0 = ok. */
+int sdp_selftest(int device);
+
+/* Tuning knob for experiments: waves per workgroup (0 = automatic). Returns previous value.
+ * Process-wide, not part of the drop-in surface. */
+int sdp_set_waves(int pass /*0 fwd,1 bwd,2 adj-fwd,3 adj-bwd*/, int waves);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDP_H_ */

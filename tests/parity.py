@@ -1,0 +1,95 @@
+"""Shared parity helpers: run the HIP engine and the CPU oracle on the same inputs.
+
+Tolerances (BASELINE.json north_star "<= 1e-4 fp32"):
+  E, Ed : max-abs <= 1e-4 (E in [0,1]); Ed scaled by max(1, max|Ed_ref|)
+  Vt,Vtd: |d| <= 1e-4 * max(1, |ref|)   (fp32 cannot hold Vt ~ 1000 to 1e-4 absolute)
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import oracle  # noqa: E402  (test infrastructure)
+
+TOL = 1e-4
+
+
+def rel_err(got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref)))) if ref.size else 0.0
+
+
+def abs_err(got, ref, scale=False):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    if not ref.size:
+        return 0.0
+    d = float(np.max(np.abs(got - ref)))
+    if scale:
+        d /= max(1.0, float(np.max(np.abs(ref))))
+    return d
+
+
+def oracle_all(theta, A, Et, Z, variant, ZA=None, omp=True):
+    """Reference-semantics results for one padded batch (no lengths)."""
+    Vt, E, Q, Efull = oracle.fwd_bwd(theta, A, Et, variant, omp=omp)
+    out = {"Vt": Vt, "E": E}
+    if Z is not None:
+        Ed, Vtd, _ = oracle.double_backward(Q, Efull, Z, ZA, omp=omp)
+        out["Ed"], out["Vtd"] = Ed, Vtd
+    return out
+
+
+def oracle_lens(theta, A, Et, Z, variant, lens):
+    """Lengths-aware semantics = per-item sliced calls (deepblast/alignment.py:165-170)."""
+    B, N, M = theta.shape
+    out = {"Vt": np.zeros(B, np.float32), "E": np.zeros((B, N, M), np.float32)}
+    if Z is not None:
+        out["Ed"] = np.zeros((B, N, M), np.float32)
+        out["Vtd"] = np.zeros(B, np.float32)
+    for b in range(B):
+        n, m = int(lens[b, 0]), int(lens[b, 1])
+        r = oracle_all(np.ascontiguousarray(theta[b:b + 1, :n, :m]), np.ascontiguousarray(A[b:b + 1, :n, :m]),
+                       None if Et is None else Et[b:b + 1],
+                       None if Z is None else np.ascontiguousarray(Z[b:b + 1, :n, :m]), variant, omp=False)
+        out["Vt"][b] = r["Vt"][0]
+        out["E"][b, :n, :m] = r["E"][0]
+        if Z is not None:
+            out["Ed"][b, :n, :m] = r["Ed"][0]
+            out["Vtd"][b] = r["Vtd"][0]
+    return out
+
+
+def engine_all(theta, A, Et, Z, variant, lens=None, ZA=None, device="cuda"):
+    """The four HIP passes through the C ABI (no autograd), numpy in / numpy out."""
+    import torch
+    from deepblast_amd._engine import get_engine
+    eng = get_engine()
+    t = torch.from_numpy(np.ascontiguousarray(theta)).to(device)
+    a = torch.from_numpy(np.ascontiguousarray(A)).to(device)
+    B = t.shape[0]
+    et = torch.ones(B, device=device) if Et is None else torch.from_numpy(Et).to(device)
+    ln = None if lens is None else torch.from_numpy(np.ascontiguousarray(lens, dtype=np.int32)).to(device)
+    Vt, Q = eng.forward(t, a, variant, ln)
+    E = eng.backward(et, Q, tuple(t.shape), variant, ln)
+    out = {"Vt": Vt.cpu().numpy(), "E": E.cpu().numpy()}
+    if Z is not None:
+        z = torch.from_numpy(np.ascontiguousarray(Z)).to(device)
+        za = None if ZA is None else torch.from_numpy(np.ascontiguousarray(ZA)).to(device)
+        Vtd, Qd = eng.adjoint_forward(Q, z, za, variant, ln)
+        Ed = eng.adjoint_backward(E, Q, Qd, variant, ln)
+        out["Ed"], out["Vtd"] = Ed.cpu().numpy(), Vtd.cpu().numpy()
+    torch.cuda.synchronize()
+    return out
+
+
+def compare(got, ref):
+    """-> dict of errors, already normalised so that each must be <= TOL."""
+    errs = {"Vt": rel_err(got["Vt"], ref["Vt"]), "E": abs_err(got["E"], ref["E"])}
+    if "Ed" in ref:
+        errs["Ed"] = abs_err(got["Ed"], ref["Ed"], scale=True)
+        errs["Vtd"] = rel_err(got["Vtd"], ref["Vtd"])
+    return errs
