@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark: NW soft-DP forward+backward, B=256 N=M=512 per GPU.
+
+Metric (BASELINE.json): DP cell-updates/s, one cell-update = one recurrence evaluation at one
+(b,i,j); a step `Vt = dec(theta, A); Vt.sum().backward()` on (B,N,M) is 2*B*N*M cell-updates.
+Inputs are synthetic (theta ~ U[0,1), A = -U[0,1), fp32, tests/datagen.py) and resident in HBM
+before the timed region.  N>1: one process per GPU (torch.distributed.run), every rank aligns its
+own B pairs (weak scaling, no data-path collective) and the step ends with the RCCL all-gather
+that collects the terminal scores Vt from all ranks (--gather e also gathers E).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (sdp_fwd_kernel): algorithmic
+bytes (12 B per cell-update) over its mean launch duration measured with HIP events
+on the launch stream inside the timed region.  `cpu_baseline` is the CPU oracle (a port of
+deepblast/nw.py, oracle/sdp_oracle.c) timed on this box's host cores, rank 0 at N=1 only.
+"""
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ALGO_BYTES_PER_CELL_UPDATE = 12  # theta 4 + A 4 + state 4 | state 4 + A 4 + E 4
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--B", type=int, default=256, help="pairs per GPU")
+    ap.add_argument("--N", type=int, default=512)
+    ap.add_argument("--M", type=int, default=512)
+    ap.add_argument("--variant", choices=["nw", "sw"], default="nw")
+    ap.add_argument("--mode", choices=["fwdbwd", "train"], default="fwdbwd",
+                    help="fwdbwd: headline; train: decode -> loss -> backward (adds the adjoint pair)")
+    ap.add_argument("--gather", choices=["vt", "e", "none"], default="vt")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs in the CPU-baseline sample")
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """Brackets every engine launch with a pair of events on the current stream."""
+
+    def __init__(self):
+        self.spans = []
+        self.enabled = False
+
+    @contextlib.contextmanager
+    def __call__(self, name):
+        if not self.enabled:
+            yield
+            return
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        try:
+            yield
+        finally:
+            e.record()
+            self.spans.append((name, s, e))
+
+    def means_ms(self):
+        acc = {}
+        for name, s, e in self.spans:
+            acc.setdefault(name, []).append(s.elapsed_time(e))
+        return {k: float(np.mean(v)) for k, v in acc.items()}
+
+
+def cpu_baseline(args):
+    """Time the CPU oracle (port of deepblast/nw.py) on a bounded sample of the same workload."""
+    import datagen
+    from oracle import oracle
+    oracle.build()
+    variant = 0 if args.variant == "nw" else 1
+    Bc = min(args.cpu_pairs, args.B)
+    theta, A = datagen.theta_A(1, Bc, args.N, args.M)
+    et = np.ones(Bc, np.float32)
+    reps = 0
+    t0 = time.perf_counter()
+    while True:  # faithful: the reference loops `for b in range(B)` serially around single-threaded code
+        _, Q = oracle.forward(theta, A, variant, omp=False)
+        oracle.backward(et, Q, variant, omp=False)
+        reps += 1
+        if time.perf_counter() - t0 > 10.0 or reps >= 3:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    out = {"value": 2.0 * Bc * args.N * args.M / dt, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+           "sample": f"oracle/sdp_oracle.c (port of deepblast/nw.py, -O2, f64 internals) fwd+bwd on {Bc} of the "
+                     f"{args.B} pairs ({args.N}x{args.M}), {reps} rep(s), 1 thread"}
+    ncpu = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    _, Q = oracle.forward(theta, A, variant, omp=True)
+    oracle.backward(et, Q, variant, omp=True)
+    dt = time.perf_counter() - t0
+    out["all_cores_value"] = 2.0 * Bc * args.N * args.M / dt
+    out["all_cores"] = ncpu
+    try:
+        with open("/proc/cpuinfo") as f:
+            models = [ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")]
+        out["cpu_model"] = models[0] if models else "unknown"
+    except OSError:
+        out["cpu_model"] = "unknown"
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import datagen
+    from deepblast_amd import NeedlemanWunschDecoder, SmithWatermanDecoder
+    from deepblast_amd._engine import get_engine
+    from deepblast_amd.distributed import ShardedAligner
+
+    B, N, M = args.B, args.N, args.M
+    theta_np, A_np = datagen.theta_A(1 + rank, B, N, M)  # BASELINE.md config C2 (seed 1) per rank
+    theta = torch.from_numpy(theta_np).to(dev)
+    A = torch.from_numpy(A_np).to(dev)
+    Zl = torch.from_numpy(datagen.normal(7, (B, N, M))).to(dev) if args.mode == "train" else None
+    dec = (NeedlemanWunschDecoder if args.variant == "nw" else SmithWatermanDecoder)("softmax")
+    aligner = ShardedAligner(dec, gather=args.gather if world > 1 else "none")
+    eng = get_engine()
+    timer = KernelTimer()
+    eng.launch_hook = timer
+
+    def step():
+        if args.mode == "fwdbwd":
+            out = aligner.align(theta, A)      # Vt = dec(theta, A); dVt.sum()/dtheta; all-gather Vt
+            return out["E_local"]
+        t = theta.detach().requires_grad_(True)
+        aln = dec.decode(t, A)                 # forward + backward kernels (create_graph)
+        (aln * Zl).sum().backward()            # adjoint forward + adjoint backward kernels
+        return t.grad
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    cells = B * N * M if args.variant == "nw" else B * (N - 1) * (M - 1)
+    per_step_updates = (2 if args.mode == "fwdbwd" else 4) * cells
+    value = world * per_step_updates * args.steps / elapsed
+    ms = timer.means_ms()
+
+    if rank == 0:
+        dom = "sdp_fwd_kernel"
+        dom_ms = ms.get(dom, float("nan"))
+        achieved = cells * ALGO_BYTES_PER_CELL_UPDATE / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf) and (B, N, M, args.variant) == (256, 512, 512, "nw"):
+            try:
+                traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
+            except (OSError, ValueError):
+                traffic = None
+        line = {
+            "metric": "DP cell-updates/sec (fwd+bwd)" if args.mode == "fwdbwd" else "DP cell-updates/sec (train: fwd+bwd+adjoint pair)",
+            "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.variant.upper()} soft-DP {'fwd+bwd' if args.mode == 'fwdbwd' else 'decode+loss.backward'}"
+                                   f", B={B} per GPU, N={N}, M={M}, random theta/A (BASELINE.json configs[1])",
+                       "global_batch": B * world, "N": N, "M": M, "variant": args.variant,
+                       "parallelism": f"batch-sharded x{world}", "gather": args.gather if world > 1 else "none",
+                       "arith": "f64 carries, f32 exp/log, f32 storage"},
+            "kernel_ms": ms,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": cells * ALGO_BYTES_PER_CELL_UPDATE,
+                         "launch_ms": dom_ms,
+                         "whole_step_frac": (per_step_updates * ALGO_BYTES_PER_CELL_UPDATE * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+            line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

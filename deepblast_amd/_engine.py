@@ -12,6 +12,17 @@ from . import _lib
 NW, SW = _lib.SDP_NW, _lib.SDP_SW
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_CTX = _NullCtx()
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -23,6 +34,12 @@ class HipEngine:
 
     def __init__(self):
         self.lib = _lib.load()
+        # optional profiling hook (bench.py): callable(name) -> context manager that brackets one
+        # kernel launch on the current stream, e.g. with a pair of events.  None = no overhead.
+        self.launch_hook = None
+
+    def _bracket(self, name):
+        return self.launch_hook(name) if self.launch_hook is not None else _NULL_CTX
 
     # ---- helpers -------------------------------------------------------------------
     @staticmethod
@@ -62,7 +79,7 @@ class HipEngine:
         lens = self._lens(lens, B, theta.device)
         state = self.new_state(B, N, M, theta.device)
         Vt = torch.empty(B, dtype=torch.float32, device=theta.device)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), self._bracket("sdp_fwd_kernel"):
             rc = self.lib.sdp_forward_f32(_ptr(theta), _ptr(A), _ptr(state), _ptr(Vt), B, N, M, _ptr(lens),
                                           variant, dev, self._stream(dev))
         _lib.check(rc, "sdp_forward_f32")
@@ -75,7 +92,7 @@ class HipEngine:
         Et = Et.to(torch.float32).expand(B).contiguous()
         lens = self._lens(lens, B, state.device)
         E = torch.empty((B, N, M), dtype=torch.float32, device=state.device)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), self._bracket("sdp_bwd_kernel"):
             rc = self.lib.sdp_backward_f32(_ptr(Et), _ptr(state), _ptr(E), B, N, M, _ptr(lens), variant, dev,
                                            self._stream(dev))
         _lib.check(rc, "sdp_backward_f32")
@@ -91,7 +108,7 @@ class HipEngine:
         lens = self._lens(lens, B, state.device)
         state_d = self.new_state(B, N, M, state.device)
         Vtd = torch.empty(B, dtype=torch.float32, device=state.device)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), self._bracket("sdp_adj_fwd_kernel"):
             rc = self.lib.sdp_adjoint_forward_f32(_ptr(state), _ptr(Ztheta), _ptr(ZA), _ptr(Vtd), _ptr(state_d),
                                                   B, N, M, _ptr(lens), variant, dev, self._stream(dev))
         _lib.check(rc, "sdp_adjoint_forward_f32")
@@ -104,7 +121,7 @@ class HipEngine:
         B, N, M = E.shape
         lens = self._lens(lens, B, state.device)
         Ed = torch.empty((B, N, M), dtype=torch.float32, device=state.device)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), self._bracket("sdp_adj_bwd_kernel"):
             rc = self.lib.sdp_adjoint_backward_f32(_ptr(E), _ptr(state), _ptr(state_d), _ptr(Ed), B, N, M,
                                                    _ptr(lens), variant, dev, self._stream(dev))
         _lib.check(rc, "sdp_adjoint_backward_f32")

@@ -17,7 +17,15 @@ def hipcc():
     return "hipcc"
 
 
-def build(force=False, extra=()):
+def build(force=False, extra=(), out=None):
+    """Compile the engine.  `extra`/`out` build experiment variants (e.g. -DSDP_K_FWD=32) next to it."""
+    global OUT
+    if out is not None:
+        saved, OUT = OUT, out
+        try:
+            return build(True, extra)
+        finally:
+            OUT = saved
     newest = max(os.path.getmtime(f) for f in SRC + HDR)
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest:
         return OUT

@@ -75,7 +75,36 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, un
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
 }
 
-constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every buffer we build
+constexpr unsigned OOB = 0x80000000u;
+
+// Ablation switches for timing experiments (tools/gpu_tune.py builds variants with -DSDP_ABL=mask);
+// results are wrong when any bit is set.  bit0: no global stores, bit1: no global loads,
+// bit2: no strip hand-off waits.
+#ifndef SDP_ABL
+#define SDP_ABL 0
+#endif
+constexpr bool ABL_NOSTORE = (SDP_ABL & 1) != 0;
+constexpr bool ABL_NOLOAD = (SDP_ABL & 2) != 0;
+constexpr bool ABL_NOSYNC = (SDP_ABL & 4) != 0;
+// Progress words live in LDS and are polled by other waves.  They are accessed with explicit DS
+// instructions: a volatile access through a generic pointer compiles to flat_load + vmcnt(0),
+// which drains every outstanding prefetch at each poll.
+__device__ __forceinline__ int lds_load_i32(unsigned addr)
+{
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_store_i32(unsigned addr, int v)
+{
+    asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(v) : "memory");
+}
+
+template <class X>
+__device__ __forceinline__ void keep(X &x)
+{
+    asm volatile("" : "+v"(x));
+}  // voffset that is out of range for every buffer we build
 
 // ----------------------------------------------------------------------------------
 // pass descriptions
@@ -148,12 +177,12 @@ __device__ __forceinline__ void sweep(const Params &p)
     // ---- LDS carve: boundary rows (f64), progress words, per-wave staging ----
     const int nslot = W > 1 ? W : 2;
     double *bnd = reinterpret_cast<double *>(smem);
-    volatile int *prog = reinterpret_cast<volatile int *>(bnd + (size_t)nslot * p.mcap);
+    const unsigned prog = (unsigned)(uintptr_t)(bnd + (size_t)nslot * p.mcap);  // LDS byte address of word 0
     float *stage = reinterpret_cast<float *>(smem + p.stage_off) + (size_t)wave * (NSTAGE > 0 ? NSTAGE : 1) * PLANE;
     float *lds_in = stage;
     float *lds_out = stage + T::SIN * PLANE;
 
-    if (threadIdx.x < (unsigned)nslot) prog[threadIdx.x] = 0;
+    if (threadIdx.x < (unsigned)nslot) lds_store_i32(prog + 4 * threadIdx.x, 0);
     __syncthreads();
     if (wave >= nstrips) return;
 
@@ -208,6 +237,7 @@ __device__ __forceinline__ void sweep(const Params &p)
         cy.c = 0.0;
         double bc = 0.0;    // boundary values for the edge lane, rotated one lane per step
         double coll = 0.0;  // shift register collecting the edge lane's outputs
+        double vt_keep = 0.0;  // fwd passes: value of the terminal cell, captured when this lane reaches it
 
         float rs[NS][K];       // staged inputs of the NEXT chunk (registers)
         float2 rd[ND][PFD + 1][K];  // direct state rows: ring of chunks, [0] = current
@@ -219,8 +249,13 @@ __device__ __forceinline__ void sweep(const Params &p)
                 for (int k = 0; k < K; ++k) {
                     const unsigned off = (unsigned)(lane_off + ubase + (k * RPI) * (ld - 1) * 4);
 #pragma unroll
-                    for (int q = 0; q < T::SIN; ++q)
-                        rs[q][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in[q], off, 0, 0));
+                    for (int q = 0; q < T::SIN; ++q) {
+                        if constexpr (ABL_NOLOAD) {
+                            rs[q][k] = __builtin_bit_cast(float, off & 0x3fffffu) * 1e30f;
+                        } else {
+                            rs[q][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in[q], off, 0, 0));
+                        }
+                    }
                 }
             }
         };
@@ -239,8 +274,13 @@ __device__ __forceinline__ void sweep(const Params &p)
 #pragma unroll
                     for (int k = 0; k < K; ++k)
 #pragma unroll
-                        for (int q = 0; q < T::DIN; ++q)
-                            rd[q][slot][k] = din[q][(size_t)(c * K + k) * 64];
+                        for (int q = 0; q < T::DIN; ++q) {
+                            if constexpr (ABL_NOLOAD) {
+                                rd[q][slot][k] = make_float2(0.25f + 1e-3f * k, 0.5f - 1e-3f * lane);
+                            } else {
+                                rd[q][slot][k] = din[q][(size_t)(c * K + k) * 64];
+                            }
+                        }
                 }
             }
         };
@@ -279,15 +319,26 @@ __device__ __forceinline__ void sweep(const Params &p)
                 if (need > 0) {
                     // bounded spin: a missed hand-off must never hang the device (results would be wrong,
                     // which the parity tests catch); ~0.2 s at the cap
-                    for (int spin = 0; prog[pslot] < pbase + need && spin < (1 << 21); ++spin)
-                        __builtin_amdgcn_s_sleep(2);
-                    asm volatile("" ::: "memory");
+                    for (int spin = 0; !ABL_NOSYNC && spin < (1 << 21); ++spin) {
+                        if (__builtin_amdgcn_readfirstlane(lds_load_i32(prog + 4 * pslot)) >= pbase + need) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
                     // fwd: lane l <- col c_lo + l (l < K) ; rev: lane 63-j <- col c_lo + K-1-j
                     const int col = REV ? c_lo + K - 1 - (63 - lane) : c_lo + lane;
                     const bool mine = REV ? (lane >= 64 - K) : (lane < K);
                     bc = (mine && col >= 0 && col < m) ? bnd_in[col] : 0.0;
                 } else {
                     bc = 0.0;
+                }
+            }
+
+            // ---- staged inputs of this chunk: one burst of LDS reads, off the dependency chain ----
+            float in0[K], in1[K];
+            if constexpr (T::SIN > 0) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    in0[k] = lds_in[lds_own + k];
+                    if constexpr (T::SIN > 1) in1[k] = lds_in[PLANE + lds_own + k];
                 }
             }
 
@@ -301,8 +352,8 @@ __device__ __forceinline__ void sweep(const Params &p)
                 const bool dead = sw && (col == 0 || (i0 + lane) == 0);  // SW: padded row 1 / col 1
 
                 if constexpr (PASS == PASS_FWD) {
-                    const float th = lds_in[lds_own + k];
-                    const float ga = lds_in[PLANE + lds_own + k];
+                    const float th = in0[k];
+                    const float ga = in1[k];
                     const double up = dpp_f64<DPP_WAVE_SHR1>(bc, cy.a);
                     bc = dpp_f64<DPP_WAVE_ROL1>(bc, bc);
                     const double diag = cy.b, left = cy.a;
@@ -315,14 +366,17 @@ __device__ __forceinline__ void sweep(const Params &p)
                     const float ssum = (ex + em) + ey;
                     const float inv = __builtin_amdgcn_rcpf(ssum);
                     const double v = ((double)th + mx) + (double)fast_log(ssum);
-                    dout[(size_t)t * 64] = make_float2(ex * inv, ey * inv);
+                    {
+                        float2 qq = make_float2(ex * inv, ey * inv);
+                        if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else dout[(size_t)t * 64] = qq;
+                    }
                     cy.b = up;
                     cy.a = (col >= 0 && !dead) ? v : 0.0;
                     coll = dpp_f64<DPP_WAVE_SHL1>(cy.a, coll);
-                    if (t == t_final) p.vout[b] = (float)cy.a;
+                    vt_keep = (t == t_final) ? cy.a : vt_keep;
                 } else if constexpr (PASS == PASS_AFWD) {
-                    const float zt = lds_in[lds_own + k];
-                    const float za = lds_in[PLANE + lds_own + k];
+                    const float zt = in0[k];
+                    const float za = in1[k];
                     float2 q = rd[0][0][k];
                     const double up = dpp_f64<DPP_WAVE_SHR1>(bc, cy.a);
                     bc = dpp_f64<DPP_WAVE_ROL1>(bc, bc);
@@ -334,11 +388,14 @@ __device__ __forceinline__ void sweep(const Params &p)
                     const double a0 = zad + up, a1 = diag, a2 = zad + left;
                     const double tot = (qx * a0 + qm * a1) + qy * a2;
                     const double vd = (double)zt + tot;
-                    dout[(size_t)t * 64] = make_float2((float)(qx * (a0 - tot)), (float)(qy * (a2 - tot)));
+                    {
+                        float2 qq = make_float2((float)(qx * (a0 - tot)), (float)(qy * (a2 - tot)));
+                        if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else dout[(size_t)t * 64] = qq;
+                    }
                     cy.b = up;
                     cy.a = inside ? vd : 0.0;
                     coll = dpp_f64<DPP_WAVE_SHL1>(cy.a, coll);
-                    if (t == t_final) p.vout[b] = (float)cy.a;
+                    vt_keep = (t == t_final) ? cy.a : vt_keep;
                 } else if constexpr (PASS == PASS_BWD) {
                     float2 q = rd[0][0][k];
                     const double in = dpp_f64<DPP_WAVE_SHL1>(bc, cy.a);
@@ -358,7 +415,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                 } else {  // PASS_ABWD
                     float2 q = rd[0][0][k];
                     float2 qd = rd[1][0][k];
-                    const float ef = lds_in[lds_own + k];
+                    const float ef = in0[k];
                     const double in = dpp_f64<DPP_WAVE_SHL1>(bc, cy.a);
                     bc = dpp_f64<DPP_WAVE_ROR1>(bc, bc);
                     const bool cell = inside && lane < rows;
@@ -385,7 +442,6 @@ __device__ __forceinline__ void sweep(const Params &p)
                 const int col = REV ? t0 + lane : t0 + K - 1 - 63 - (63 - lane);
                 const bool mine = REV ? (lane < K) : (lane >= 64 - K);
                 if (mine && col >= 0 && col < m) bnd_out[col] = coll;
-                asm volatile("" ::: "memory");
                 int done;  // columns published so far (fwd: from the left; rev: from the right)
                 if (REV) {
                     done = t0 < m ? m - t0 : 0;
@@ -393,7 +449,9 @@ __device__ __forceinline__ void sweep(const Params &p)
                     const int hi = t0 + K - 63;
                     done = hi < 0 ? 0 : (hi > m ? m : hi);
                 }
-                if (lane == 0) prog[oslot] = obase + done;
+                // LDS executes a wave's DS instructions in order, so the data written above is visible to
+                // any wave that observes this word (the asm statements also stop compiler reordering)
+                if (lane == 0) lds_store_i32(prog + 4 * oslot, obase + done);
             }
 
             // ---- flush the staged output chunk (row-major, coalesced row segments) ----
@@ -406,7 +464,12 @@ __device__ __forceinline__ void sweep(const Params &p)
                     const float val = lds_out[lds_rw + k * RPI * PITCH];
                     const bool ok = (unsigned)col < (unsigned)m && (i0 + row) < n;
                     const unsigned off = ok ? (unsigned)(lane_off + (ubase + k * RPI * (ld - 1)) * 4) : OOB;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rs_out, off, 0, 0);
+                    if constexpr (ABL_NOSTORE) {
+                        unsigned vv = __builtin_bit_cast(unsigned, val) ^ off;
+                        keep(vv);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rs_out, off, 0, 0);
+                    }
                 }
             }
 
@@ -420,6 +483,9 @@ __device__ __forceinline__ void sweep(const Params &p)
 #pragma unroll
                         for (int q = 0; q < T::DIN; ++q) rd[q][d][k] = rd[q][d + 1][k];
             }
+        }
+        if constexpr (!REV) {
+            if (t_final >= 0) p.vout[b] = (float)vt_keep;
         }
     }
 }

@@ -1,0 +1,139 @@
+"""GPU: the drop-in Python surface end to end (Decoder -> autograd.Function -> C ABI -> HIP),
+written after the reference's own tests (deepblast/tests/test_nw.py, test_nw_cuda.py, test_sw.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import datagen
+import parity
+from deepblast_amd import NeedlemanWunschDecoder, SmithWatermanDecoder
+
+pytestmark = pytest.mark.gpu
+DEC = {"nw": NeedlemanWunschDecoder, "sw": SmithWatermanDecoder}
+
+
+@pytest.mark.parametrize("kind", ["nw", "sw"])
+def test_decoding_known_answer(golden_dir, kind):
+    """test_nw_cuda.py:64-76 / test_sw_cuda.py:58-70 on the 5x4 fixture."""
+    d = np.load(os.path.join(golden_dir, f"g2_known_{kind}_f32.npz"))
+    theta = torch.from_numpy(d["theta"]).cuda().requires_grad_()
+    A = torch.from_numpy(d["A"]).cuda().requires_grad_()
+    dec = DEC[kind]("softmax")
+    v = dec(theta, A)
+    assert v.is_cuda and v.shape == (1,)
+    v.backward()
+    assert parity.rel_err(v.detach().cpu().numpy(), d["Vt"]) <= parity.TOL
+    assert parity.abs_err(theta.grad.cpu().numpy(), d["E"]) <= parity.TOL
+    assert dec.traceback(theta.grad.squeeze()) == [tuple(r) for r in d["traceback"].tolist()]
+
+
+@pytest.mark.parametrize("kind", ["nw", "sw"])
+def test_quirks_and_double_backward(golden_dir, kind):
+    d = np.load(os.path.join(golden_dir, f"g1_{kind}_b4_64.npz"))
+    dec = DEC[kind]("softmax")
+    theta = torch.from_numpy(d["theta"]).cuda().requires_grad_()
+    A = torch.from_numpy(d["A"]).cuda().requires_grad_()
+    Z = torch.from_numpy(d["Z"]).cuda()
+    Vt = dec(theta, A)
+    Vt.backward(torch.from_numpy(d["Et"]).cuda())
+    assert parity.abs_err(theta.grad.cpu().numpy(), d["E_et"]) <= parity.TOL
+    assert torch.equal(A.grad, A.detach())                    # nw.py:337-339,355
+    theta.grad = None
+    A.grad = None
+    aln = dec.decode(theta, A)                                 # alignment.py:124
+    assert aln.is_cuda and aln.requires_grad and aln.shape == theta.shape
+    (aln * Z).sum().backward()
+    assert parity.abs_err(theta.grad.cpu().numpy(), d["Ed"], scale=True) <= parity.TOL
+    assert A.grad is None                                      # nw.py:386
+    et = torch.from_numpy(d["Et"]).cuda().requires_grad_()
+    g, _ = torch.autograd.grad(dec(theta, A), (theta, A), et, create_graph=True)
+    (vtd,) = torch.autograd.grad((g * Z).sum(), et)
+    assert parity.rel_err(vtd.cpu().numpy(), d["Vtd_et"]) <= parity.TOL
+
+
+@pytest.mark.parametrize("kind", ["nw", "sw"])
+def test_gradcheck_style_finite_differences(kind):
+    """test_nw_cuda.py:51-61 uses gradcheck with eps=atol=rtol=1e-1 in fp32; here the directional
+    derivative of sum(Vt) along a random direction is compared with <E, d> at matching tolerance,
+    and the directional derivative of <E, Z> with <Ed, d> (gradgradcheck analogue)."""
+    B, N, M = 3, 5, 5
+    theta, A = datagen.theta_A(77, B, N, M)
+    theta = torch.from_numpy(theta).cuda()
+    A = torch.from_numpy(A).cuda().requires_grad_()  # decode() differentiates w.r.t. (theta, A) like the reference
+    dirn = torch.from_numpy(datagen.normal(78, (B, N, M))).cuda()
+    Z = torch.from_numpy(datagen.normal(79, (B, N, M))).cuda()
+    dec = DEC[kind]("softmax")
+    eps = 1e-2
+
+    def f(t):
+        return dec(t, A).sum()
+
+    def g(t):
+        t = t.detach().requires_grad_()
+        return (dec.decode(t, A) * Z).sum()
+
+    t = theta.clone().requires_grad_()
+    (E,) = torch.autograd.grad(f(t), t)
+    fd = (f(theta + eps * dirn) - f(theta - eps * dirn)) / (2 * eps)
+    assert abs(float(fd.detach()) - float((E * dirn).sum())) < 2e-2
+    if kind == "sw":
+        # The reference has no gradgradcheck for SW (test_sw.py) and its SW double-backward is not the
+        # true Hessian-vector product: the adjoint loops keep padded row/col 1 that forward/backward
+        # skip (sw.py:150-151,199-202 vs 54-55,107-110; the CPU oracle gives -3.95 vs -3.23 here).
+        # We match the reference (tests/test_parity_gpu.py), not the finite difference.
+        return
+    t = theta.clone().requires_grad_()
+    (Ed,) = torch.autograd.grad((dec.decode(t, A) * Z).sum(), t)
+    fd2 = (g(theta + eps * dirn) - g(theta - eps * dirn)) / (2 * eps)
+    assert abs(float(fd2.detach()) - float((Ed * dirn).sum())) < 2e-2
+
+
+def test_outputs_stay_on_input_device_and_no_grad_path():
+    """nw_cuda.py:270-271 keeps results on the GPU; score() runs forward under no_grad (alignment.py:136)."""
+    theta, A = datagen.theta_A(5, 2, 30, 20)
+    theta, A = torch.from_numpy(theta).cuda(), torch.from_numpy(A).cuda()
+    dec = NeedlemanWunschDecoder("softmax")
+    with torch.no_grad():
+        v = dec(theta, A)
+    assert v.is_cuda and not v.requires_grad
+    ref = parity.oracle_all(theta.cpu().numpy(), A.cpu().numpy(), None, None, 0)
+    assert parity.rel_err(v.cpu().numpy(), ref["Vt"]) <= parity.TOL
+
+
+def test_side_stream_ordering():
+    """Kernels are enqueued on torch's current stream: results on a side stream are ordered with
+    the producing ops without extra synchronisation."""
+    theta, A = datagen.theta_A(6, 8, 200, 180)
+    ref = parity.oracle_all(theta, A, None, None, 0)
+    s = torch.cuda.Stream()
+    dec = NeedlemanWunschDecoder("softmax")
+    with torch.cuda.stream(s):
+        t = torch.from_numpy(theta).cuda().requires_grad_()
+        a = torch.from_numpy(A).cuda() * 1.0
+        v = dec(t, a)
+        v.sum().backward()
+        E = t.grad.clone()
+    s.synchronize()
+    assert parity.abs_err(E.cpu().numpy(), ref["E"]) <= parity.TOL
+
+
+def test_padded_batch_reference_semantics_and_lengths_extension():
+    """BASELINE.json configs[2]: the reference runs the DP over the full padded matrix (no lengths
+    argument, alignment.py:117-124); lengths-aware mode is an extension checked per item."""
+    B, N, M = 5, 96, 130
+    theta, A = datagen.theta_A(8, B, N, M)
+    lens = datagen.lengths(9, B, 10, 96)
+    dec = NeedlemanWunschDecoder("softmax")
+    t = torch.from_numpy(theta).cuda().requires_grad_()
+    a = torch.from_numpy(A).cuda()
+    dec(t, a).sum().backward()
+    ref = parity.oracle_all(theta, A, None, None, 0)
+    assert parity.abs_err(t.grad.cpu().numpy(), ref["E"]) <= parity.TOL
+    t.grad = None
+    v = dec(t, a, torch.from_numpy(lens).cuda())
+    v.sum().backward()
+    refl = parity.oracle_lens(theta, A, None, None, 0, lens)
+    assert parity.rel_err(v.detach().cpu().numpy(), refl["Vt"]) <= parity.TOL
+    assert parity.abs_err(t.grad.cpu().numpy(), refl["E"]) <= parity.TOL

@@ -1,0 +1,126 @@
+"""GPU: the HIP kernels, called through the C ABI, against the CPU oracle and the committed
+golden fixtures (generated from the real reference).  Tolerance: <= 1e-4 (parity.TOL), absolute
+on E/Ed, relative on Vt/Vtd -- BASELINE.json north_star, SURVEY.md 8c."""
+import os
+
+import numpy as np
+import pytest
+
+import datagen
+import parity
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(1, 1, 1), (2, 1, 7), (2, 7, 1), (2, 2, 2), (3, 5, 4), (2, 16, 16), (2, 17, 33), (2, 37, 101),
+          (2, 64, 64), (2, 63, 65), (2, 65, 63), (2, 65, 64), (2, 101, 37), (2, 128, 128), (2, 129, 70),
+          (2, 200, 300), (3, 257, 255), (2, 320, 90), (3, 512, 512), (1, 300, 1024), (1, 1024, 1024),
+          (1, 70, 2048)]
+
+
+def _assert(errs, what=""):
+    for k, v in errs.items():
+        assert np.isfinite(v) and v <= parity.TOL, f"{what} {k}: {v:.3e} > {parity.TOL}"
+
+
+def test_selftest():
+    from deepblast_amd._engine import get_engine
+    get_engine().selftest(0)
+
+
+@pytest.mark.parametrize("variant", [0, 1], ids=["nw", "sw"])
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_all_four_passes_vs_oracle(shape, variant):
+    B, N, M = shape
+    idx = SHAPES.index(shape)
+    theta, A = datagen.theta_A(1000 + idx, B, N, M)
+    if idx % 3 == 1:
+        A = (-A).astype(np.float32)  # positive gap scores too (test_nw.py:67-72)
+    Z = datagen.normal(2000 + idx, (B, N, M))
+    Et = (0.5 + datagen.uniform(3000 + idx, (B,))).astype(np.float32)
+    ref = parity.oracle_all(theta, A, Et, Z, variant)
+    got = parity.engine_all(theta, A, Et, Z, variant)
+    _assert(parity.compare(got, ref), f"{shape} v{variant}")
+
+
+@pytest.mark.parametrize("variant", [0, 1], ids=["nw", "sw"])
+def test_nonzero_ZA_enters_the_adjoint(variant):
+    """quirk 3: the ZA buffer is part of the adjoint recurrences (nw.py:190-192)."""
+    B, N, M = 2, 70, 45
+    theta, A = datagen.theta_A(50, B, N, M)
+    Z = datagen.normal(51, (B, N, M))
+    ZA = datagen.normal(52, (B, N, M))
+    ref = parity.oracle_all(theta, A, None, Z, variant, ZA=ZA)
+    got = parity.engine_all(theta, A, None, Z, variant, ZA=ZA)
+    _assert(parity.compare(got, ref))
+
+
+@pytest.mark.parametrize("variant", [0, 1], ids=["nw", "sw"])
+def test_lengths_aware_mode(variant):
+    """Padded batch with per-pair sizes == per-item sliced reference calls (alignment.py:165-170)."""
+    B, N, M = 9, 150, 170
+    theta, A = datagen.theta_A(4000, B, N, M)
+    Z = datagen.normal(4001, (B, N, M))
+    lens = datagen.lengths(4002, B, 1, 150)
+    lens[0] = (N, M)
+    lens[1] = (1, 1)
+    lens[2] = (64, 65)
+    ref = parity.oracle_lens(theta, A, None, Z, variant, lens)
+    got = parity.engine_all(theta, A, None, Z, variant, lens=lens)
+    _assert(parity.compare(got, ref))
+    for b in range(B):  # outside the block everything is exactly zero
+        n, m = lens[b]
+        assert not got["E"][b, n:, :].any() and not got["E"][b, :, m:].any()
+        assert not got["Ed"][b, n:, :].any() and not got["Ed"][b, :, m:].any()
+
+
+@pytest.mark.parametrize("kind", ["nw", "sw"])
+def test_golden_config1_and_shapes(golden_dir, kind):
+    """Fixtures produced by the real reference: B=4 N=M=64 (BASELINE configs[0]) + odd shapes."""
+    variant = {"nw": 0, "sw": 1}[kind]
+    d = np.load(os.path.join(golden_dir, f"g1_{kind}_b4_64.npz"))
+    got = parity.engine_all(d["theta"], d["A"], d["Et"], d["Z"], variant)
+    _assert(parity.compare(got, {"Vt": d["Vt_et"], "E": d["E_et"], "Ed": d["Ed_et"], "Vtd": d["Vtd_et"]}))
+    d = np.load(os.path.join(golden_dir, f"g3_{kind}_shapes.npz"))
+    for idx in range(len(d["shapes"])):
+        p = f"s{idx}_"
+        got = parity.engine_all(d[p + "theta"], d[p + "A"], d[p + "Et"], d[p + "Z"], variant)
+        _assert(parity.compare(got, {k: d[p + k] for k in ("Vt", "E", "Ed", "Vtd")}), str(d["shapes"][idx]))
+
+
+@pytest.mark.parametrize("name", ["g5_nw_512", "g5_nw_1024", "g5_sw_512"])
+def test_golden_large(golden_dir, name):
+    """512^2 and 1024^2 outputs of the real reference (samples + checksums)."""
+    d = np.load(os.path.join(golden_dir, name + ".npz"))
+    B, N = int(d["B"]), int(d["N"])
+    theta, A = datagen.theta_A(int(d["seed"]), B, N, N)
+    got = parity.engine_all(theta, A, None, None, {"nw": 0, "sw": 1}[name.split("_")[1]])
+    assert parity.rel_err(got["Vt"], d["Vt"]) <= parity.TOL
+    assert parity.abs_err(got["E"][:, ::61, :], d["E_rows"]) <= parity.TOL
+    assert parity.abs_err(np.stack([np.diagonal(e) for e in got["E"]]), d["E_diag"]) <= parity.TOL
+    assert np.allclose(got["E"].astype(np.float64).sum(axis=(1, 2)), d["E_sum"], rtol=1e-5)
+
+
+def test_headline_config_full_batch():
+    """BASELINE.json configs[1]: B=256, N=M=512, whole batch against the oracle, plus
+    size-independent properties: batch independence (bit-exact) and linearity in Et."""
+    B, N, M = 256, 512, 512
+    theta, A = datagen.theta_A(1, B, N, M)
+    ref = parity.oracle_all(theta, A, None, None, 0, omp=True)
+    got = parity.engine_all(theta, A, None, None, 0)
+    _assert(parity.compare(got, ref))
+    sel = [0, 100, 255]
+    alone = parity.engine_all(theta[sel], A[sel], None, None, 0)
+    assert np.array_equal(alone["Vt"], got["Vt"][sel]) and np.array_equal(alone["E"], got["E"][sel])
+    Et = np.full(3, 3.0, np.float32)
+    scaled = parity.engine_all(theta[sel], A[sel], Et, None, 0)
+    assert np.allclose(scaled["E"], 3.0 * alone["E"], rtol=1e-6, atol=1e-7)
+    assert abs(float(got["E"][0, -1, -1]) - 1.0) < 1e-6  # E[N,M] == Et (quirk 4)
+
+
+def test_max_cols_is_enforced():
+    import torch
+    from deepblast_amd._engine import get_engine
+    eng = get_engine()
+    t = torch.zeros(1, 2, eng.max_cols() + 1, device="cuda")
+    with pytest.raises(ValueError):
+        eng.forward(t, t, 0)

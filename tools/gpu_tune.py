@@ -1,0 +1,95 @@
+#!/usr/bin/env python
+"""Timing experiments on the GPU box: variant libraries x waves x batch sizes.
+usage: python tools/gpu_tune.py [lib=path ...]  (default: main lib + everything under build_variants/)"""
+import ctypes
+import glob
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import datagen  # noqa: E402
+from deepblast_amd import _lib  # noqa: E402
+
+
+def load(path):
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _lib.SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def timeit(fn, n=8):
+    fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3  # us
+
+
+def run(lib, B, N, M, waves=(0, 0, 0, 0), passes="fb"):
+    th, A = datagen.theta_A(1, min(B, 64), N, M)
+    reps = (B + th.shape[0] - 1) // th.shape[0]
+    t = torch.from_numpy(np.tile(th, (reps, 1, 1))[:B]).cuda()
+    a = torch.from_numpy(np.tile(A, (reps, 1, 1))[:B]).cuda()
+    st = torch.empty(lib.sdp_state_bytes(B, N, M) // 4, device="cuda")
+    std = torch.empty_like(st) if "a" in passes else None
+    vt = torch.empty(B, device="cuda")
+    et = torch.ones(B, device="cuda")
+    E = torch.empty(B, N, M, device="cuda")
+    Ed = torch.empty(B, N, M, device="cuda") if "a" in passes else None
+    z = torch.randn(B, N, M, device="cuda") if "a" in passes else None
+    stream = torch.cuda.current_stream().cuda_stream
+    for p, w in enumerate(waves):
+        lib.sdp_set_waves(p, w)
+    out = {}
+    f = lambda: lib.sdp_forward_f32(t.data_ptr(), a.data_ptr(), st.data_ptr(), vt.data_ptr(), B, N, M, None, 0, 0, stream)
+    b = lambda: lib.sdp_backward_f32(et.data_ptr(), st.data_ptr(), E.data_ptr(), B, N, M, None, 0, 0, stream)
+    assert f() == 0
+    out["fwd"] = timeit(f)
+    out["bwd"] = timeit(b)
+    if "a" in passes:
+        af = lambda: lib.sdp_adjoint_forward_f32(st.data_ptr(), z.data_ptr(), None, vt.data_ptr(), std.data_ptr(), B, N, M, None, 0, 0, stream)
+        ab = lambda: lib.sdp_adjoint_backward_f32(E.data_ptr(), st.data_ptr(), std.data_ptr(), Ed.data_ptr(), B, N, M, None, 0, 0, stream)
+        out["afwd"] = timeit(af)
+        out["abwd"] = timeit(ab)
+    return out
+
+
+def main():
+    libs = {"main": os.path.join(ROOT, "deepblast_amd", "libsdp_hip.so")}
+    for p in sorted(glob.glob(os.path.join(ROOT, "build_variants", "libsdp_*.so"))):
+        libs[os.path.basename(p)[7:-3]] = p
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]
+    print("device:", torch.cuda.get_device_name(0))
+    main_lib = load(libs["main"])
+    print("== waves x batch (main lib), N=M=512, us")
+    for B in (64, 256, 512, 1024):
+        for W in (1, 2, 4):
+            r = run(main_lib, B, 512, 512, (W, W, W, W), "fba" if B == 256 else "fb")
+            print(f"B={B:5d} W={W}: " + "  ".join(f"{k}={v:8.1f}" for k, v in r.items()), flush=True)
+    print("== variants at B=256 W=4, us")
+    for name, path in libs.items():
+        if only and name not in only:
+            continue
+        r = run(load(path), 256, 512, 512, (0, 0, 0, 0), "fb")
+        print(f"{name:10s}: " + "  ".join(f"{k}={v:8.1f}" for k, v in r.items()), flush=True)
+    print("== shapes (main lib, W auto), us and cell-updates/s")
+    for (B, N, M) in ((256, 1024, 1024), (256, 128, 128), (2048, 64, 64), (256, 256, 1024), (256, 1024, 256)):
+        r = run(main_lib, B, N, M)
+        cu = 2.0 * B * N * M / ((r["fwd"] + r["bwd"]) * 1e-6)
+        print(f"B={B} N={N} M={M}: fwd={r['fwd']:.1f} bwd={r['bwd']:.1f}  {cu:.3e} cu/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
