@@ -31,6 +31,7 @@ SIGNATURES = {
                                                 ctypes.c_int, ctypes.c_int, _c_i32p, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_void_p]),
     "sdp_selftest": (ctypes.c_int, [ctypes.c_int]),
+    "sdp_probe": (ctypes.c_int, [ctypes.c_int]),
     "sdp_set_waves": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
 }
 

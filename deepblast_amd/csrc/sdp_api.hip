@@ -12,6 +12,7 @@ namespace {
 
 thread_local char g_err[256] = "";
 int g_waves[4] = {0, 0, 0, 0};
+int g_dbg = 0;
 
 int fail(int code, const char *msg)
 {
@@ -55,13 +56,14 @@ int launch(int pass, sdp::Params &p, int device, void *stream)
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
     const PassInfo pi = pass_info(pass);
     const int nstrips = sdp::state_nstrips(p.N);
-    int W = g_waves[pass] > 0 ? g_waves[pass] : 4;
-    if (W > 4) W = 4;
+    int W = g_waves[pass] > 0 ? g_waves[pass] : SDP_DEFAULT_WAVES;
+    if (W > sdp::max_waves(pass)) W = sdp::max_waves(pass);
     if (W > nstrips) W = nstrips;
     const int nslot = W > 1 ? W : 2;
     p.nstrips_max = nstrips;
     p.tpad = sdp::state_tpad(p.M);
     p.mcap = (p.M + 63) / 64 * 64;
+    p.dbg = g_dbg;
     size_t off = (size_t)nslot * p.mcap * sizeof(double) + 64;  // boundary rows + progress words
     off = (off + 15) & ~(size_t)15;
     p.stage_off = (int)off;
@@ -92,6 +94,11 @@ size_t sdp_state_bytes(int B, int N, int M)
 
 int sdp_set_waves(int pass, int waves)
 {
+    if (pass == 100) {  // experiment switches, see Params::dbg
+        const int old = g_dbg;
+        g_dbg = waves;
+        return old;
+    }
     if (pass < 0 || pass > 3) return -1;
     const int old = g_waves[pass];
     g_waves[pass] = waves;
@@ -168,15 +175,23 @@ int sdp_adjoint_backward_f32(const float *E, const float *state, const float *st
     return launch(sdp::PASS_ABWD, p, device, stream);
 }
 
+static int g_probe = -1;
+
+int sdp_probe(int device)
+{
+    if (g_probe < 0) (void)sdp_selftest(device);
+    return g_probe;
+}
+
 int sdp_selftest(int device)
 {
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
     int *d = nullptr;
-    e = hipMalloc(&d, 192 * sizeof(int));
+    e = hipMalloc(&d, 256 * sizeof(int));
     if (e != hipSuccess) return fail_hip(e, "hipMalloc");
-    int h[192];
-    for (int i = 0; i < 192; ++i) h[i] = 7777;
+    int h[256];
+    for (int i = 0; i < 256; ++i) h[i] = 7777;
     (void)hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice);
     hipLaunchKernelGGL(sdp_selftest_kernel, dim3(1), dim3(64), 0, 0, d);
     e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
@@ -188,6 +203,7 @@ int sdp_selftest(int device)
         if (h[64 + i] != 1000 + i) bad |= 128;   // in-range stores must land
     for (int i = 128; i < 192; ++i)
         if (h[i] != 7777) bad |= 256;            // out-of-range stores must be dropped
+    g_probe = (h[192] == 0) ? 1 : 0;  // bit0: scalar offset takes part in the buffer range check
     if (bad) {
         snprintf(g_err, sizeof(g_err), "sdp_selftest: hardware semantics mismatch, mask 0x%x", bad);
         return SDP_E_SELFTEST;

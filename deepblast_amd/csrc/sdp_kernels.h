@@ -8,33 +8,38 @@
 
 #include "sdp.h"
 
-// chunk length K (steps per staged chunk; must divide 64) and direct-state prefetch
-// depth PFD (chunks in flight ahead of the one being consumed) per pass
+// chunk length K per pass (steps per staged chunk; must divide 64).  K is also the prefetch
+// distance of the skewed state rows, in steps.
 #ifndef SDP_K_FWD
-#define SDP_K_FWD 16
+#define SDP_K_FWD 32
 #endif
 #ifndef SDP_K_BWD
 #define SDP_K_BWD 32
 #endif
-#ifndef SDP_PFD_BWD
-#define SDP_PFD_BWD 2
-#endif
 #ifndef SDP_K_AFWD
 #define SDP_K_AFWD 16
-#endif
-#ifndef SDP_PFD_AFWD
-#define SDP_PFD_AFWD 2
 #endif
 #ifndef SDP_K_ABWD
 #define SDP_K_ABWD 16
 #endif
-#ifndef SDP_PFD_ABWD
-#define SDP_PFD_ABWD 2
+
+// Largest workgroup (in waves) each kernel is compiled for; the VGPR budget per wave is
+// 512 / (waves per SIMD), so 8 waves leave 256 registers, 4 waves the full 512.
+#ifndef SDP_MAXW_FWD
+#define SDP_MAXW_FWD 4
+#endif
+#ifndef SDP_MAXW_REV
+#define SDP_MAXW_REV 4
+#endif
+#ifndef SDP_DEFAULT_WAVES
+#define SDP_DEFAULT_WAVES 4
 #endif
 
 namespace sdp {
 
 enum { PASS_FWD = 0, PASS_BWD = 1, PASS_AFWD = 2, PASS_ABWD = 3 };
+
+constexpr int max_waves(int pass) { return pass == PASS_FWD ? SDP_MAXW_FWD : SDP_MAXW_REV; }
 
 constexpr int MAX_COLS = 2048;     // boundary rows live in LDS (4 x MAX_COLS x 8 B = 64 KiB)
 constexpr int PROG_STRIDE = 4096;  // > MAX_COLS: progress words are (use index)*PROG_STRIDE + columns
@@ -55,6 +60,7 @@ struct Params {
     int mcap;            // doubles per boundary row in LDS
     int stage_off;       // byte offset of the per-wave staging area in LDS
     int variant;
+    int dbg;             // experiment switches (sdp_set_waves pass 100): bit0 inputs, bit1 outputs, bit2 state: all pairs alias pair 0
 };
 
 // state geometry (shared by host and device)

@@ -34,6 +34,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "sdp_kernels.h"
 
 namespace sdp {
@@ -86,6 +88,8 @@ constexpr unsigned OOB = 0x80000000u;
 constexpr bool ABL_NOSTORE = (SDP_ABL & 1) != 0;
 constexpr bool ABL_NOLOAD = (SDP_ABL & 2) != 0;
 constexpr bool ABL_NOSYNC = (SDP_ABL & 4) != 0;
+constexpr bool ABL_NOMATH = (SDP_ABL & 8) != 0;
+constexpr bool ABL_ALIGNED = (SDP_ABL & 16) != 0;  // drop the skew from staged global addresses (wrong cells, full-line aligned)  // keep every load/store, replace the recurrence by a copy
 // Progress words live in LDS and are polled by other waves.  They are accessed with explicit DS
 // instructions: a volatile access through a generic pointer compiles to flat_load + vmcnt(0),
 // which drains every outstanding prefetch at each poll.
@@ -132,27 +136,82 @@ struct Traits<PASS_ABWD> {  // nw.py:251-267
     static constexpr bool REV = true;
 };
 
+// ----------------------------------------------------------------------------------
+// carries
+// ----------------------------------------------------------------------------------
+// How a pass represents the values that flow from cell to cell (and across strips):
+//   CK_F64 : float64, as the reference does internally (nw.py:49-53,125,182-185,256).
+//   CK_F32 : float32.  Used by the backward sweep: E is a sum of non-negative products of weights
+//            in [0,1], so there is no cancellation and fp32 accumulation stays ~1e-6 of the result.
+//   CK_EXP : scaled exp-domain pair (a, e) with V = e*ln2 + ln(a), a in [0.5,1).  The forward
+//            recurrence  V = theta + log(e^(A+up) + e^diag + e^(A+left))  becomes
+//            alpha = c_theta * (c_A*(u + l) + d): one fma chain with no exp/log on the dependency
+//            chain (the HMM "scaled forward algorithm").  theta and A are split into an integer
+//            power of two (added to the exponent) and a factor in [1,2), and the three operands are
+//            aligned to their largest exponent, so no finite input can overflow or cancel; every
+//            rescale is an exact power of two, so the only rounding is the fp32 fma chain itself.
+enum { CK_F64 = 0, CK_F32 = 1, CK_EXP = 2 };
+
+#ifndef SDP_FWD_KIND
+#define SDP_FWD_KIND 2
+#endif
+#ifndef SDP_BWD_KIND
+#define SDP_BWD_KIND 1
+#endif
+
+template <int PASS>
+struct Kind {
+    static constexpr int value = PASS == PASS_FWD ? SDP_FWD_KIND : (PASS == PASS_BWD ? SDP_BWD_KIND : CK_F64);
+};
+
+typedef unsigned long long u64;  // one boundary slot (LDS) / one edge value in registers
+
+__device__ __forceinline__ u64 pack2(unsigned lo, unsigned hi) { return ((u64)hi << 32) | lo; }
+__device__ __forceinline__ unsigned lo32(u64 x) { return (unsigned)x; }
+__device__ __forceinline__ unsigned hi32(u64 x) { return (unsigned)(x >> 32); }
+
+// V = 0 in the exp-domain representation: 0.5 * 2^1
+constexpr float EXP_ONE_A = 0.5f;
+constexpr int EXP_ONE_E = 1;
+
+template <int KIND>
+__device__ __forceinline__ u64 edge_zero()
+{
+    if constexpr (KIND == CK_EXP) return pack2(__float_as_uint(EXP_ONE_A), (unsigned)EXP_ONE_E);
+    else return 0ull;  // +0.0 as f64 and as f32
+}
+
 // per-lane recurrence state carried from step to step
 struct Carry {
-    double a;  // fwd: own V (left predecessor)      | rev: value sent to the lane above (px + pm')
-    double b;  // fwd: previous `up` (diag predecessor) | rev: own py (to the cell on the left)
-    double c;  // rev: pm of the previous step
+    // CK_F64: a = own V / value sent up, b = previous `up` / own py, c = pm of the previous step
+    double a, b, c;
+    // CK_F32 (reverse): same roles in fp32
+    float fa, fb, fc;
+    // CK_EXP (forward): own (alpha, exponent), and the diagonal predecessor's pair
+    float xa;
+    int xe;
+    float da;
+    int de;
 };
 
 // ----------------------------------------------------------------------------------
 // the sweep
 // ----------------------------------------------------------------------------------
-template <int PASS, int K, int PFD>
+template <int PASS, int K>
 __device__ __forceinline__ void sweep(const Params &p)
 {
     using T = Traits<PASS>;
     constexpr bool REV = T::REV;
+    constexpr int KIND = Kind<PASS>::value;
     constexpr int RPI = 64 / K;    // tensor rows covered by one staged load/store instruction
     constexpr int PITCH = K + 1;   // LDS pitch of a staged chunk (floats)
     constexpr int PLANE = 64 * PITCH;
     constexpr int NSTAGE = T::SIN + T::SOUT;
     constexpr int ND = T::DIN > 0 ? T::DIN : 1;
     constexpr int NS = T::SIN > 0 ? T::SIN : 1;
+    constexpr int PUB_LANE = REV ? 0 : 63;    // lane that produces this strip's boundary row
+    constexpr int DPP_IN = REV ? DPP_WAVE_SHL1 : DPP_WAVE_SHR1;  // pull from the lane that owns the previous row
+    static_assert(!(KIND == CK_EXP && PASS != PASS_FWD) && !(KIND == CK_F32 && !REV), "unsupported carry kind");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -174,9 +233,9 @@ __device__ __forceinline__ void sweep(const Params &p)
     const int nchunks = (m + 63 + K - 1) / K;  // steps t in [0, m+63)
     const bool sw = p.variant == SDP_SW;
 
-    // ---- LDS carve: boundary rows (f64), progress words, per-wave staging ----
+    // ---- LDS carve: boundary rows (8-byte slots), progress words, per-wave staging ----
     const int nslot = W > 1 ? W : 2;
-    double *bnd = reinterpret_cast<double *>(smem);
+    u64 *bnd = reinterpret_cast<u64 *>(smem);
     const unsigned prog = (unsigned)(uintptr_t)(bnd + (size_t)nslot * p.mcap);  // LDS byte address of word 0
     float *stage = reinterpret_cast<float *>(smem + p.stage_off) + (size_t)wave * (NSTAGE > 0 ? NSTAGE : 1) * PLANE;
     float *lds_in = stage;
@@ -189,13 +248,14 @@ __device__ __forceinline__ void sweep(const Params &p)
     // ---- per-pair tensor descriptors ----
     const size_t plane_elems = (size_t)p.N * p.M;
     const unsigned plane_bytes = (unsigned)(plane_elems * 4);
+    const size_t b_in = (p.dbg & 1) ? 0 : b, b_out = (p.dbg & 2) ? 0 : b, b_st = (p.dbg & 4) ? 0 : b;
     __amdgpu_buffer_rsrc_t rs_in[NS];
     if constexpr (T::SIN > 0) {
-        rs_in[0] = make_rsrc(p.sin0 + (size_t)b * plane_elems, plane_bytes);
+        rs_in[0] = make_rsrc(p.sin0 + b_in * plane_elems, plane_bytes);
         if constexpr (T::SIN > 1)
-            rs_in[1] = make_rsrc(p.sin1 ? p.sin1 + (size_t)b * plane_elems : p.sin0, p.sin1 ? plane_bytes : 0u);
+            rs_in[1] = make_rsrc(p.sin1 ? p.sin1 + b_in * plane_elems : p.sin0, p.sin1 ? plane_bytes : 0u);
     }
-    __amdgpu_buffer_rsrc_t rs_out = make_rsrc(T::SOUT ? (const void *)(p.sout + (size_t)b * plane_elems) : (const void *)p.vout,
+    __amdgpu_buffer_rsrc_t rs_out = make_rsrc(T::SOUT ? (const void *)(p.sout + b_out * plane_elems) : (const void *)p.vout,
                                               T::SOUT ? plane_bytes : 0u);
 
     // per-lane constants of the staged-chunk geometry: lane -> (row r_l within RPI, step s_l)
@@ -216,44 +276,82 @@ __device__ __forceinline__ void sweep(const Params &p)
         const int pidx = sidx - 1;                                  // producer's position in processing order
         const int pslot = has_pred ? pidx % nslot : 0, pbase = has_pred ? (pidx / nslot) * PROG_STRIDE : 0;
         const int oslot = sidx % nslot, obase = (sidx / nslot) * PROG_STRIDE;
-        double *bnd_in = bnd + (size_t)pslot * p.mcap;
-        double *bnd_out = bnd + (size_t)oslot * p.mcap;
+        const u64 *bnd_in = bnd + (size_t)pslot * p.mcap;
+        u64 *bnd_out = bnd + (size_t)oslot * p.mcap;
+        // chunks in which every lane sits on a real, non-special cell need no masking at all
+        const bool plain_strip = rows == 64 && !(sw && s == 0) && s != nstrips - 1;
 
         // step at which this lane meets the terminal cell (n-1, m-1) of the pair; -1 if never
         const int t_final = (s == nstrips - 1 && lane == rows - 1) ? (m - 1 + lane) : -1;
 
-        // skewed state addressing: float2 index of (strip s, step 0, lane)
-        const size_t st_base = ((size_t)b * p.nstrips_max + s) * p.tpad * 64 + lane;
-        const float2 *din[ND];
+        // skewed state addressing: one buffer descriptor per (pair, strip); a row (one step) is 64 x float2
+        // = 512 B, so step t, lane l lives at byte t*512 + l*8.  Step offsets go through the scalar
+        // offset operand, the lane offset is a per-lane constant.
+        const size_t st_base = (b_st * p.nstrips_max + s) * p.tpad * 64;
+        const unsigned st_bytes = (unsigned)p.tpad * 512u;
+        const unsigned st_lane = lane * 8;
+        __amdgpu_buffer_rsrc_t rs_din[ND];
         if constexpr (T::DIN > 0) {
-            din[0] = p.din0 + st_base;
-            if constexpr (T::DIN > 1) din[1] = p.din1 + st_base;
+            rs_din[0] = make_rsrc(p.din0 + st_base, st_bytes);
+            if constexpr (T::DIN > 1) rs_din[1] = make_rsrc(p.din1 + st_base, st_bytes);
         }
-        float2 *dout = T::DOUT ? p.dout + st_base : nullptr;
+        __amdgpu_buffer_rsrc_t rs_dout = make_rsrc(T::DOUT ? (const void *)(p.dout + st_base) : (const void *)p.vout,
+                                                   T::DOUT ? st_bytes : 0u);
+        auto load_state = [&](int q, int t_base, int k) {  // row t_base + k
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_din[q], st_lane + (k & 7) * 512, (t_base + (k & ~7)) * 512, 0);
+            // NB: copy the elements to scalars first -- __builtin_bit_cast applied directly to a vector
+            // element lvalue (v[1]) reads element 0 with this compiler.
+            const unsigned lo = v[0], hi = v[1];
+            return make_float2(__uint_as_float(lo), __uint_as_float(hi));
+        };
+        auto store_state = [&](int t_base, int k, float2 qq) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 v;
+            v[0] = __float_as_uint(qq.x);
+            v[1] = __float_as_uint(qq.y);
+            __builtin_amdgcn_raw_buffer_store_b64(v, rs_dout, st_lane + (k & 7) * 512, (t_base + (k & ~7)) * 512, 0);
+        };
 
         Carry cy;
-        cy.a = 0.0;
-        cy.b = 0.0;
-        cy.c = 0.0;
-        double bc = 0.0;    // boundary values for the edge lane, rotated one lane per step
-        double coll = 0.0;  // shift register collecting the edge lane's outputs
-        double vt_keep = 0.0;  // fwd passes: value of the terminal cell, captured when this lane reaches it
+        cy.a = cy.b = cy.c = 0.0;
+        cy.fa = cy.fb = cy.fc = 0.f;
+        cy.xa = cy.da = EXP_ONE_A;
+        cy.xe = cy.de = EXP_ONE_E;
+        u64 vt_keep = edge_zero<KIND>();  // fwd passes: terminal cell's value, captured when this lane reaches it
 
-        float rs[NS][K];       // staged inputs of the NEXT chunk (registers)
-        float2 rd[ND][PFD + 1][K];  // direct state rows: ring of chunks, [0] = current
+        float rs[NS][K];   // staged inputs of the NEXT chunk (registers)
+        float2 rd[ND][K];  // skewed state rows: slot k holds step t0+k of the current chunk and is
+                           // refilled with the same slot of the next chunk right after it is consumed
+
+        // byte offset of this lane's element in staged instruction k, relative to (row i0, step 0)
+        unsigned voff[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) voff[k] = (unsigned)(lane_off + (k * RPI) * (ld - 1) * 4) + (ABL_ALIGNED ? (unsigned)(k * RPI + r_l) * 4u : 0u);
+
+        // Chunk c of this strip touches only real cells of a full, unmasked strip: its addresses are all in
+        // range, so the uniform part can ride in the scalar offset (no per-instruction VALU add, and no
+        // reliance on how the hardware range-checks the scalar offset).
+        auto chunk_interior = [&](int c) { return plain_strip && c * K >= 63 && c * K + K < m; };
 
         auto load_staged = [&](int c) {
             if constexpr (T::SIN > 0) {
                 const int ubase = (i0 * ld + c * K) * 4;
+                if (chunk_interior(c)) {
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const unsigned off = (unsigned)(lane_off + ubase + (k * RPI) * (ld - 1) * 4);
+                    for (int k = 0; k < K; ++k)
 #pragma unroll
-                    for (int q = 0; q < T::SIN; ++q) {
-                        if constexpr (ABL_NOLOAD) {
-                            rs[q][k] = __builtin_bit_cast(float, off & 0x3fffffu) * 1e30f;
-                        } else {
-                            rs[q][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in[q], off, 0, 0));
+                        for (int q = 0; q < T::SIN; ++q) {
+                            if constexpr (ABL_NOLOAD) rs[q][k] = __uint_as_float(voff[k] & 0x3fffffu) * 1e30f;
+                            else rs[q][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in[q], voff[k], ubase, 0));
+                        }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const unsigned off = voff[k] + (unsigned)ubase;
+#pragma unroll
+                        for (int q = 0; q < T::SIN; ++q) {
+                            if constexpr (ABL_NOLOAD) rs[q][k] = __uint_as_float(off & 0x3fffffu) * 1e30f;
+                            else rs[q][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in[q], off, 0, 0));
                         }
                     }
                 }
@@ -268,22 +366,6 @@ __device__ __forceinline__ void sweep(const Params &p)
                         lds_in[q * PLANE + lds_rw + k * RPI * PITCH] = rs[q][k];
             }
         };
-        auto load_direct = [&](int c, int slot) {
-            if constexpr (T::DIN > 0) {
-                if (c >= 0 && c < nchunks) {
-#pragma unroll
-                    for (int k = 0; k < K; ++k)
-#pragma unroll
-                        for (int q = 0; q < T::DIN; ++q) {
-                            if constexpr (ABL_NOLOAD) {
-                                rd[q][slot][k] = make_float2(0.25f + 1e-3f * k, 0.5f - 1e-3f * lane);
-                            } else {
-                                rd[q][slot][k] = din[q][(size_t)(c * K + k) * 64];
-                            }
-                        }
-                }
-            }
-        };
 
         const int c_first = REV ? nchunks - 1 : 0;
         const int dir = REV ? -1 : 1;
@@ -291,7 +373,12 @@ __device__ __forceinline__ void sweep(const Params &p)
         // ---- prologue ----
         if constexpr (T::DIN > 0) {
 #pragma unroll
-            for (int d = 0; d < PFD; ++d) load_direct(c_first + d * dir, d);
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int q = 0; q < T::DIN; ++q) {
+                    if constexpr (ABL_NOLOAD) rd[q][k] = make_float2(0.25f + 1e-3f * k, 0.5f - 1e-3f * lane);
+                    else rd[q][k] = load_state(q, c_first * K, k);
+                }
         }
         load_staged(c_first);
         write_staged();
@@ -300,21 +387,24 @@ __device__ __forceinline__ void sweep(const Params &p)
             const int c = REV ? nchunks - 1 - ci : ci;
             const int t0 = c * K;
             const bool more = ci + 1 < nchunks;
+            const int t0_next = more ? t0 + dir * K : t0;   // state rows to prefetch while this chunk runs
 
             if (more) load_staged(c + dir);
-            if constexpr (T::DIN > 0) load_direct(c + PFD * dir, PFD);
 
-            // ---- boundary fetch: K columns for the edge lane ----
-            if (has_pred) {
-                // fwd: lane 0 needs cols [t0, t0+K); rev: lane 63 needs cols [t0-63, t0+K-63)
+            // ---- boundary values for the edge lane: K broadcast LDS reads, off the dependency chain ----
+            u64 bcv[K];
+            {
+                // fwd: lane 0 at step t0+k needs column t0+k; rev: lane 63 needs column t0+k-63
                 const int c_lo = REV ? t0 - 63 : t0;
-                int need;  // progress value that guarantees those columns are published
-                if (REV) {
-                    const int lo = c_lo < 0 ? 0 : c_lo;
-                    need = (c_lo + K > 0 && c_lo < m) ? m - lo : 0;
-                } else {
-                    const int hi = c_lo + K < m ? c_lo + K : m;
-                    need = (c_lo < m) ? hi : 0;
+                int need = 0;  // progress value that guarantees those columns are published
+                if (has_pred) {
+                    if (REV) {
+                        const int lo = c_lo < 0 ? 0 : c_lo;
+                        need = (c_lo + K > 0 && c_lo < m) ? m - lo : 0;
+                    } else {
+                        const int hi = c_lo + K < m ? c_lo + K : m;
+                        need = (c_lo < m) ? hi : 0;
+                    }
                 }
                 if (need > 0) {
                     // bounded spin: a missed hand-off must never hang the device (results would be wrong,
@@ -323,12 +413,19 @@ __device__ __forceinline__ void sweep(const Params &p)
                         if (__builtin_amdgcn_readfirstlane(lds_load_i32(prog + 4 * pslot)) >= pbase + need) break;
                         __builtin_amdgcn_s_sleep(1);
                     }
-                    // fwd: lane l <- col c_lo + l (l < K) ; rev: lane 63-j <- col c_lo + K-1-j
-                    const int col = REV ? c_lo + K - 1 - (63 - lane) : c_lo + lane;
-                    const bool mine = REV ? (lane >= 64 - K) : (lane < K);
-                    bc = (mine && col >= 0 && col < m) ? bnd_in[col] : 0.0;
+                    if (c_lo >= 0 && c_lo + K <= m) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) bcv[k] = bnd_in[c_lo + k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            const int col = c_lo + k;
+                            bcv[k] = (col >= 0 && col < m) ? bnd_in[col] : edge_zero<KIND>();
+                        }
+                    }
                 } else {
-                    bc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) bcv[k] = edge_zero<KIND>();
                 }
             }
 
@@ -342,106 +439,190 @@ __device__ __forceinline__ void sweep(const Params &p)
                 }
             }
 
-            // ---- K steps ----
+            u64 hist[K];  // the edge-facing carry after each step (published below by one lane)
+
+            // ---- K steps; EDGE=false is the mask-free body for chunks fully inside the matrix ----
+            auto steps = [&](auto edge_tag) {
+                constexpr bool EDGE = decltype(edge_tag)::value;
 #pragma unroll
-            for (int kk = 0; kk < K; ++kk) {
-                const int k = REV ? K - 1 - kk : kk;
-                const int t = t0 + k;
-                const int col = t - lane;
-                const bool inside = (unsigned)col < (unsigned)m;
-                const bool dead = sw && (col == 0 || (i0 + lane) == 0);  // SW: padded row 1 / col 1
+                for (int kk = 0; kk < K; ++kk) {
+                    const int k = REV ? K - 1 - kk : kk;
+                    const int t = t0 + k;
+                    const int col = t - lane;
+                    const bool inside = !EDGE || (unsigned)col < (unsigned)m;
+                    const bool dead = EDGE && sw && (col == 0 || (i0 + lane) == 0);  // SW: padded row 1 / col 1
+                    const bool rowok = !EDGE || lane < rows;
 
-                if constexpr (PASS == PASS_FWD) {
-                    const float th = in0[k];
-                    const float ga = in1[k];
-                    const double up = dpp_f64<DPP_WAVE_SHR1>(bc, cy.a);
-                    bc = dpp_f64<DPP_WAVE_ROL1>(bc, bc);
-                    const double diag = cy.b, left = cy.a;
-                    const double ad = (double)ga;
-                    const double x = ad + up, y = ad + left;
-                    const double mx = fmax(fmax(x, diag), y);
-                    const float ex = fast_exp((float)(x - mx));
-                    const float em = fast_exp((float)(diag - mx));
-                    const float ey = fast_exp((float)(y - mx));
-                    const float ssum = (ex + em) + ey;
-                    const float inv = __builtin_amdgcn_rcpf(ssum);
-                    const double v = ((double)th + mx) + (double)fast_log(ssum);
-                    {
-                        float2 qq = make_float2(ex * inv, ey * inv);
-                        if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else dout[(size_t)t * 64] = qq;
+                    float2 q0, q1;
+                    if constexpr (T::DIN > 0) {
+                        q0 = rd[0][k];
+                        if constexpr (T::DIN > 1) q1 = rd[1][k];
+                        if constexpr (!ABL_NOLOAD) {  // refill the slot with the same step of the next chunk
+                            rd[0][k] = load_state(0, t0_next, k);
+                            if constexpr (T::DIN > 1) rd[1][k] = load_state(1, t0_next, k);
+                        }
                     }
-                    cy.b = up;
-                    cy.a = (col >= 0 && !dead) ? v : 0.0;
-                    coll = dpp_f64<DPP_WAVE_SHL1>(cy.a, coll);
-                    vt_keep = (t == t_final) ? cy.a : vt_keep;
-                } else if constexpr (PASS == PASS_AFWD) {
-                    const float zt = in0[k];
-                    const float za = in1[k];
-                    float2 q = rd[0][0][k];
-                    const double up = dpp_f64<DPP_WAVE_SHR1>(bc, cy.a);
-                    bc = dpp_f64<DPP_WAVE_ROL1>(bc, bc);
-                    const double diag = cy.b, left = cy.a;
-                    const bool live = inside && !dead;
-                    const double qx = live ? (double)q.x : 0.0, qy = live ? (double)q.y : 0.0;
-                    const double qm = live ? (1.0 - qx) - qy : 0.0;
-                    const double zad = (double)za;
-                    const double a0 = zad + up, a1 = diag, a2 = zad + left;
-                    const double tot = (qx * a0 + qm * a1) + qy * a2;
-                    const double vd = (double)zt + tot;
-                    {
-                        float2 qq = make_float2((float)(qx * (a0 - tot)), (float)(qy * (a2 - tot)));
-                        if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else dout[(size_t)t * 64] = qq;
+
+                    if constexpr (ABL_NOMATH) {
+                        if constexpr (T::DOUT > 0) {
+                            float2 qq = make_float2(in0[k], T::DIN > 0 ? q0.x + q0.y : in1[k]);
+                            store_state(t0, k, qq);
+                        }
+                        if constexpr (T::SOUT > 0) lds_out[lds_own + k] = q0.x + q0.y + (T::DIN > 1 ? q1.x + q1.y : 0.f) + (T::SIN > 0 ? in0[k] : 0.f);
+                        hist[k] = 0;
+                    } else if constexpr (PASS == PASS_FWD && KIND == CK_EXP) {
+                        // scaled exp-domain forward (see CK_EXP above)
+                        const float th = in0[k];
+                        const float ga = in1[k];
+                        const float ua = __uint_as_float(dpp_i32<DPP_IN>((int)lo32(bcv[k]), __float_as_int(cy.xa)));
+                        const int ue = dpp_i32<DPP_IN>((int)hi32(bcv[k]), cy.xe);
+                        // theta = (kt + ft) ln2, A = (ka + fa) ln2 with integer kt, ka and ft, fa in [0,1)
+                        const float tt = th * 1.44269504088896340736f;
+                        const float ta = ga * 1.44269504088896340736f;
+                        const float kt = __builtin_floorf(tt), ka = __builtin_floorf(ta);
+                        const float ct = __builtin_amdgcn_exp2f(tt - kt);  // in [1,2)
+                        const float ca = __builtin_amdgcn_exp2f(ta - ka);  // in [1,2)
+                        const int kai = (int)ka;
+                        const int ex = ue + kai, ey = cy.xe + kai, ed = cy.de;
+                        const int er = max(max(ex, ey), ed);
+                        const float u = __builtin_amdgcn_ldexpf(ua, ex - er);
+                        const float l = __builtin_amdgcn_ldexpf(cy.xa, ey - er);
+                        const float d = __builtin_amdgcn_ldexpf(cy.da, ed - er);
+                        const float ssum = __builtin_fmaf(ca, u + l, d);  // >= 0.5: the largest operand is unshifted
+                        const float tq = ca * __builtin_amdgcn_rcpf(ssum);
+                        {
+                            float2 qq = make_float2(tq * u, tq * l);
+                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
+                        }
+                        const float an = ct * ssum;
+                        float na = __builtin_amdgcn_frexp_mantf(an);
+                        int ne = er + (int)kt + __builtin_amdgcn_frexp_expf(an);
+                        cy.da = ua;
+                        cy.de = ue;
+                        if constexpr (EDGE) {
+                            const bool live = col >= 0 && !dead;
+                            na = live ? na : EXP_ONE_A;
+                            ne = live ? ne : EXP_ONE_E;
+                        }
+                        cy.xa = na;
+                        cy.xe = ne;
+                        hist[k] = pack2(__float_as_uint(na), (unsigned)ne);
+                        if constexpr (EDGE) vt_keep = (t == t_final) ? hist[k] : vt_keep;
+                    } else if constexpr (PASS == PASS_FWD) {
+                        const float th = in0[k];
+                        const float ga = in1[k];
+                        const double up = dpp_f64<DPP_IN>(__longlong_as_double((long long)bcv[k]), cy.a);
+                        const double diag = cy.b, left = cy.a;
+                        const double ad = (double)ga;
+                        const double x = ad + up, y = ad + left;
+                        const double mx = fmax(fmax(x, diag), y);
+                        const float ex = fast_exp((float)(x - mx));
+                        const float em = fast_exp((float)(diag - mx));
+                        const float ey = fast_exp((float)(y - mx));
+                        const float ssum = (ex + em) + ey;
+                        const float inv = __builtin_amdgcn_rcpf(ssum);
+                        const double v = ((double)th + mx) + (double)fast_log(ssum);
+                        {
+                            float2 qq = make_float2(ex * inv, ey * inv);
+                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
+                        }
+                        cy.b = up;
+                        cy.a = (!EDGE || (col >= 0 && !dead)) ? v : 0.0;
+                        hist[k] = (u64)__double_as_longlong(cy.a);
+                        if constexpr (EDGE) vt_keep = (t == t_final) ? hist[k] : vt_keep;
+                    } else if constexpr (PASS == PASS_AFWD) {
+                        const float zt = in0[k];
+                        const float za = in1[k];
+                        const double up = dpp_f64<DPP_IN>(__longlong_as_double((long long)bcv[k]), cy.a);
+                        const double diag = cy.b, left = cy.a;
+                        const bool live = inside && !dead;
+                        const double qx = live ? (double)q0.x : 0.0, qy = live ? (double)q0.y : 0.0;
+                        const double qm = live ? (1.0 - qx) - qy : 0.0;
+                        const double zad = (double)za;
+                        const double a0 = zad + up, a1 = diag, a2 = zad + left;
+                        const double tot = (qx * a0 + qm * a1) + qy * a2;
+                        const double vd = (double)zt + tot;
+                        {
+                            float2 qq = make_float2((float)(qx * (a0 - tot)), (float)(qy * (a2 - tot)));
+                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
+                        }
+                        cy.b = up;
+                        cy.a = inside ? vd : 0.0;
+                        hist[k] = (u64)__double_as_longlong(cy.a);
+                        if constexpr (EDGE) vt_keep = (t == t_final) ? hist[k] : vt_keep;
+                    } else if constexpr (PASS == PASS_BWD && KIND == CK_F32) {
+                        const float in = __uint_as_float(dpp_i32<DPP_IN>((int)lo32(bcv[k]), __float_as_int(cy.fa)));
+                        const bool live = inside && rowok && !dead;
+                        float e = in + cy.fb;
+                        if constexpr (EDGE) {
+                            e = (t == t_final) ? et : e;
+                            e = live ? e : 0.f;
+                        }
+                        const float qx = live ? q0.x : 0.f, qy = live ? q0.y : 0.f;
+                        const float qm = (1.f - qx) - qy;
+                        const float px = qx * e, pm = qm * e;
+                        cy.fb = qy * e;
+                        cy.fa = px + cy.fc;
+                        cy.fc = pm;
+                        lds_out[lds_own + k] = e;
+                        hist[k] = (u64)__float_as_uint(cy.fa);
+                    } else if constexpr (PASS == PASS_BWD) {
+                        const double in = dpp_f64<DPP_IN>(__longlong_as_double((long long)bcv[k]), cy.a);
+                        const bool live = inside && rowok && !dead;
+                        double e = in + cy.b;
+                        if constexpr (EDGE) {
+                            e = (t == t_final) ? (double)et : e;
+                            e = live ? e : 0.0;
+                        }
+                        const double qx = live ? (double)q0.x : 0.0, qy = live ? (double)q0.y : 0.0;
+                        const double qm = (1.0 - qx) - qy;
+                        const double px = qx * e, pm = qm * e;
+                        cy.b = qy * e;
+                        cy.a = px + cy.c;
+                        cy.c = pm;
+                        lds_out[lds_own + k] = (float)e;
+                        hist[k] = (u64)__double_as_longlong(cy.a);
+                    } else {  // PASS_ABWD
+                        const float ef = in0[k];
+                        const double in = dpp_f64<DPP_IN>(__longlong_as_double((long long)bcv[k]), cy.a);
+                        const bool cell = inside && rowok;
+                        const bool live = cell && !dead;
+                        const double ed = cell ? in + cy.b : 0.0;
+                        const double e = live ? (double)ef : 0.0;
+                        const double qx = live ? (double)q0.x : 0.0, qy = live ? (double)q0.y : 0.0;
+                        const double qm = live ? (1.0 - qx) - qy : 0.0;
+                        const double dx = live ? (double)q1.x : 0.0, dy = live ? (double)q1.y : 0.0;
+                        const double dm = -(dx + dy);
+                        const double gx = dx * e + qx * ed;
+                        const double gm = dm * e + qm * ed;
+                        cy.b = dy * e + qy * ed;
+                        cy.a = gx + cy.c;
+                        cy.c = gm;
+                        lds_out[lds_own + k] = (float)ed;
+                        hist[k] = (u64)__double_as_longlong(cy.a);
                     }
-                    cy.b = up;
-                    cy.a = inside ? vd : 0.0;
-                    coll = dpp_f64<DPP_WAVE_SHL1>(cy.a, coll);
-                    vt_keep = (t == t_final) ? cy.a : vt_keep;
-                } else if constexpr (PASS == PASS_BWD) {
-                    float2 q = rd[0][0][k];
-                    const double in = dpp_f64<DPP_WAVE_SHL1>(bc, cy.a);
-                    bc = dpp_f64<DPP_WAVE_ROR1>(bc, bc);
-                    const bool live = inside && lane < rows && !dead;
-                    double e = in + cy.b;
-                    e = (t == t_final) ? (double)et : e;
-                    e = live ? e : 0.0;
-                    const double qx = live ? (double)q.x : 0.0, qy = live ? (double)q.y : 0.0;
-                    const double qm = (1.0 - qx) - qy;
-                    const double px = qx * e, pm = qm * e;
-                    cy.b = qy * e;
-                    cy.a = px + cy.c;
-                    cy.c = pm;
-                    coll = dpp_f64<DPP_WAVE_SHR1>(cy.a, coll);
-                    lds_out[lds_own + k] = (float)e;
-                } else {  // PASS_ABWD
-                    float2 q = rd[0][0][k];
-                    float2 qd = rd[1][0][k];
-                    const float ef = in0[k];
-                    const double in = dpp_f64<DPP_WAVE_SHL1>(bc, cy.a);
-                    bc = dpp_f64<DPP_WAVE_ROR1>(bc, bc);
-                    const bool cell = inside && lane < rows;
-                    const bool live = cell && !dead;
-                    const double ed = cell ? in + cy.b : 0.0;
-                    const double e = live ? (double)ef : 0.0;
-                    const double qx = live ? (double)q.x : 0.0, qy = live ? (double)q.y : 0.0;
-                    const double qm = live ? (1.0 - qx) - qy : 0.0;
-                    const double dx = live ? (double)qd.x : 0.0, dy = live ? (double)qd.y : 0.0;
-                    const double dm = -(dx + dy);
-                    const double gx = dx * e + qx * ed;
-                    const double gm = dm * e + qm * ed;
-                    cy.b = dy * e + qy * ed;
-                    cy.a = gx + cy.c;
-                    cy.c = gm;
-                    coll = dpp_f64<DPP_WAVE_SHR1>(cy.a, coll);
-                    lds_out[lds_own + k] = (float)ed;
                 }
-            }
+            };
+            const bool interior = chunk_interior(c);
+            if (interior) steps(std::false_type{});
+            else steps(std::true_type{});
 
-            // ---- publish K boundary values for the next strip ----
+            // ---- publish K boundary values for the next strip (one lane, K LDS writes) ----
             if (has_succ) {
-                // fwd: lane 63-j holds col (t0+K-1-63) - j ; rev: lane j holds col t0 + j   (j < K newest)
-                const int col = REV ? t0 + lane : t0 + K - 1 - 63 - (63 - lane);
-                const bool mine = REV ? (lane < K) : (lane >= 64 - K);
-                if (mine && col >= 0 && col < m) bnd_out[col] = coll;
+                // fwd: lane 63 produced column t0+k-63 at step k; rev: lane 0 produced column t0+k
+                const int c_lo = REV ? t0 : t0 - 63;
+                if (lane == PUB_LANE) {
+                    if (c_lo >= 0 && c_lo + K <= m) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) bnd_out[c_lo + k] = hist[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            const int col = c_lo + k;
+                            if (col >= 0 && col < m) bnd_out[col] = hist[k];
+                        }
+                    }
+                }
                 int done;  // columns published so far (fwd: from the left; rev: from the right)
                 if (REV) {
                     done = t0 < m ? m - t0 : 0;
@@ -451,41 +632,53 @@ __device__ __forceinline__ void sweep(const Params &p)
                 }
                 // LDS executes a wave's DS instructions in order, so the data written above is visible to
                 // any wave that observes this word (the asm statements also stop compiler reordering)
-                if (lane == 0) lds_store_i32(prog + 4 * oslot, obase + done);
+                if (lane == PUB_LANE) lds_store_i32(prog + 4 * oslot, obase + done);
             }
 
             // ---- flush the staged output chunk (row-major, coalesced row segments) ----
             if constexpr (T::SOUT > 0) {
-                const int ubase = i0 * ld + t0;
+                float vals[K];
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const int row = k * RPI + r_l;
-                    const int col = t0 + s_l - row;
-                    const float val = lds_out[lds_rw + k * RPI * PITCH];
-                    const bool ok = (unsigned)col < (unsigned)m && (i0 + row) < n;
-                    const unsigned off = ok ? (unsigned)(lane_off + (ubase + k * RPI * (ld - 1)) * 4) : OOB;
-                    if constexpr (ABL_NOSTORE) {
-                        unsigned vv = __builtin_bit_cast(unsigned, val) ^ off;
-                        keep(vv);
-                    } else {
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rs_out, off, 0, 0);
+                for (int k = 0; k < K; ++k) vals[k] = lds_out[lds_rw + k * RPI * PITCH];
+                const int ubase = i0 * ld + t0;
+                if (interior) {  // every element is a real cell: uniform part of the address in the scalar offset
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        if constexpr (ABL_NOSTORE) {
+                            keep(vals[k]);
+                        } else {
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vals[k]), rs_out, voff[k], ubase * 4, 0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const int row = k * RPI + r_l;
+                        const int col = t0 + s_l - row;
+                        const bool ok = (unsigned)col < (unsigned)m && (i0 + row) < n;
+                        const unsigned off = ok ? voff[k] + (unsigned)(ubase * 4) : OOB;
+                        if constexpr (ABL_NOSTORE) {
+                            unsigned vv = __float_as_uint(vals[k]) ^ off;
+                            keep(vv);
+                        } else {
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vals[k]), rs_out, off, 0, 0);
+                        }
                     }
                 }
             }
 
-            // ---- rotate prefetch buffers ----
             if (more) write_staged();
-            if constexpr (T::DIN > 0) {
-#pragma unroll
-                for (int d = 0; d < PFD; ++d)
-#pragma unroll
-                    for (int k = 0; k < K; ++k)
-#pragma unroll
-                        for (int q = 0; q < T::DIN; ++q) rd[q][d][k] = rd[q][d + 1][k];
-            }
         }
         if constexpr (!REV) {
-            if (t_final >= 0) p.vout[b] = (float)vt_keep;
+            if (t_final >= 0) {
+                if constexpr (KIND == CK_EXP) {
+                    // V = e*ln2 + ln(a), once per pair, in float64
+                    p.vout[b] = (float)((double)(int)hi32(vt_keep) * 0.69314718055994530942 +
+                                        log((double)__uint_as_float(lo32(vt_keep))));
+                } else {
+                    p.vout[b] = (float)__longlong_as_double((long long)vt_keep);
+                }
+            }
         }
     }
 }
@@ -495,16 +688,16 @@ __device__ __forceinline__ void sweep(const Params &p)
 // ----------------------------------------------------------------------------------
 // kernels (one symbol per pass so that rocprofv3 names them)
 // ----------------------------------------------------------------------------------
-#define SDP_KERNEL(NAME, PASS, K, PFD)                                                     \
-    extern "C" __global__ void __launch_bounds__(256) NAME(const sdp::Params p)           \
-    {                                                                                      \
-        sdp::sweep<PASS, K, PFD>(p);                                                       \
+#define SDP_KERNEL(NAME, PASS, K)                                                               \
+    extern "C" __global__ void __launch_bounds__(sdp::max_waves(PASS) * 64) NAME(const sdp::Params p)  \
+    {                                                                                           \
+        sdp::sweep<PASS, K>(p);                                                                 \
     }
 
-SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, 0)
-SDP_KERNEL(sdp_bwd_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_PFD_BWD)
-SDP_KERNEL(sdp_adj_fwd_kernel, sdp::PASS_AFWD, SDP_K_AFWD, SDP_PFD_AFWD)
-SDP_KERNEL(sdp_adj_bwd_kernel, sdp::PASS_ABWD, SDP_K_ABWD, SDP_PFD_ABWD)
+SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD)
+SDP_KERNEL(sdp_bwd_kernel, sdp::PASS_BWD, SDP_K_BWD)
+SDP_KERNEL(sdp_adj_fwd_kernel, sdp::PASS_AFWD, SDP_K_AFWD)
+SDP_KERNEL(sdp_adj_bwd_kernel, sdp::PASS_ABWD, SDP_K_ABWD)
 
 // ----------------------------------------------------------------------------------
 // device self-test of the cross-lane semantics the sweep relies on
@@ -534,4 +727,8 @@ extern "C" __global__ void sdp_selftest_kernel(int *out)
     bad |= (neg != 0u) ? 32 : 0;
     bad |= (past != 0u) ? 64 : 0;
     out[lane] = bad;
+    // informational (sdp_probe): is the scalar offset part of the range check?  Read the word right
+    // after the buffer through soffset; 0 = checked (out of range), 7777 = not checked.
+    const unsigned via_s = __builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, 64 * 4, 0);
+    out[192 + lane] = (int)via_s;
 }

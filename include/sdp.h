@@ -94,6 +94,10 @@ int sdp_adjoint_backward_f32(const float *E, const float *state, const float *st
  * behaviour the kernels rely on.  Synchronises the device.  0 = ok. */
 int sdp_selftest(int device);
 
+/* Diagnostic: bit0 = the buffer instructions' scalar offset takes part in the hardware range check
+ * on this device (runs sdp_selftest on first use). */
+int sdp_probe(int device);
+
 /* Tuning knob for experiments: waves per workgroup (0 = automatic). Returns previous value.
  * Process-wide, not part of the drop-in surface. */
 int sdp_set_waves(int pass /*0 fwd,1 bwd,2 adj-fwd,3 adj-bwd*/, int waves);

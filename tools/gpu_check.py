@@ -79,6 +79,25 @@ def main():
         print(f"v{variant} lens {B}x{N}x{M}: " + " ".join(f"{k}={v:.2e}" for k, v in errs.items())
               + ("" if bad <= parity.TOL else "  <-- FAIL"), flush=True)
 
+    # extreme magnitudes (large match scores, very negative / positive gap scores)
+    for variant in (0, 1):
+        for name, ts, asc, ash in (("theta*40", 40.0, 1.0, 0.0), ("A*150", 1.0, 150.0, 0.0), ("theta*90,A*300", 90.0, 300.0, 0.0),
+                                   ("A+5", 1.0, 1.0, 5.0), ("theta*1e-3", 1e-3, 1e-3, 0.0)):
+            B, N, M = 2, 130, 97
+            theta, A = datagen.theta_A(5000, B, N, M)
+            theta = (theta * ts).astype(np.float32)
+            A = (A * asc + ash).astype(np.float32)
+            Z = datagen.normal(5001, (B, N, M))
+            ref = parity.oracle_all(theta, A, None, Z, variant)
+            got = parity.engine_all(theta, A, None, Z, variant)
+            errs = parity.compare(got, ref)
+            bad = max(errs.values())
+            bad = bad if np.isfinite(bad) else 9e9
+            worst = max(worst, bad)
+            nfail += bad > parity.TOL
+            print(f"v{variant} stress {name}: " + " ".join(f"{k}={v:.2e}" for k, v in errs.items())
+                  + ("" if bad <= parity.TOL else "  <-- FAIL"), flush=True)
+
     print(f"worst normalised error {worst:.3e}; failures {nfail}", flush=True)
 
     if "--time" in sys.argv:

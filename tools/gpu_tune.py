@@ -75,17 +75,34 @@ def main():
     main_lib = load(libs["main"])
     print("== waves x batch (main lib), N=M=512, us")
     for B in (64, 256, 512, 1024):
-        for W in (1, 2, 4):
+        for W in (1, 2, 4, 8):
+            if "--wb" not in sys.argv and B != 256:
+                continue
             r = run(main_lib, B, 512, 512, (W, W, W, W), "fba" if B == 256 else "fb")
             print(f"B={B:5d} W={W}: " + "  ".join(f"{k}={v:8.1f}" for k, v in r.items()), flush=True)
+    print("== aliasing experiments (main lib, B=256, W=4): dbg bit0 inputs, bit1 outputs, bit2 state alias pair 0")
+    for dbg in (0, 1, 2, 4, 5, 6, 7):
+        main_lib.sdp_set_waves(100, dbg)
+        r = run(main_lib, 256, 512, 512, (0, 0, 0, 0), "fb")
+        print(f"dbg={dbg}: " + "  ".join(f"{k}={v:8.1f}" for k, v in r.items()), flush=True)
+    main_lib.sdp_set_waves(100, 0)
     print("== variants at B=256 W=4, us")
     for name, path in libs.items():
-        if only and name not in only:
+        if (only and name not in only) or (not only and "--variants" not in sys.argv and name != "main"):
             continue
         r = run(load(path), 256, 512, 512, (0, 0, 0, 0), "fb")
         print(f"{name:10s}: " + "  ".join(f"{k}={v:8.1f}" for k, v in r.items()), flush=True)
     print("== shapes (main lib, W auto), us and cell-updates/s")
-    for (B, N, M) in ((256, 1024, 1024), (256, 128, 128), (2048, 64, 64), (256, 256, 1024), (256, 1024, 256)):
+    shapes = ((256, 512, 512), (256, 512, 500), (256, 512, 520), (256, 512, 528), (256, 512, 544), (256, 512, 576),
+              (256, 1024, 1024), (256, 1024, 1040), (256, 128, 128), (2048, 64, 64))
+    if "--pitch" in sys.argv:
+        for name in ("abl13", "abl14", "abl12"):
+            if name in libs:
+                l = load(libs[name])
+                for (B, N, M) in ((256, 512, 512), (256, 512, 528)):
+                    r = run(l, B, N, M)
+                    print(f"{name} B={B} N={N} M={M}: fwd={r['fwd']:.1f} bwd={r['bwd']:.1f}", flush=True)
+    for (B, N, M) in shapes:
         r = run(main_lib, B, N, M)
         cu = 2.0 * B * N * M / ((r["fwd"] + r["bwd"]) * 1e-6)
         print(f"B={B} N={N} M={M}: fwd={r['fwd']:.1f} bwd={r['bwd']:.1f}  {cu:.3e} cu/s", flush=True)
