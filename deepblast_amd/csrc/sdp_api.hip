@@ -67,7 +67,7 @@ int launch(int pass, sdp::Params &p, int device, void *stream)
     size_t off = (size_t)nslot * p.mcap * sizeof(double) + 64;  // boundary rows + progress words
     off = (off + 15) & ~(size_t)15;
     p.stage_off = (int)off;
-    const size_t lds = off + (size_t)W * pi.nstage * 64 * (pi.K + 1) * sizeof(float);
+    const size_t lds = off + (size_t)W * sdp::stage_floats(pass, pi.K) * sizeof(float);
     e = hipFuncSetAttribute(pi.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     void *args[] = {&p};

@@ -204,8 +204,9 @@ __device__ __forceinline__ void sweep(const Params &p)
     constexpr bool REV = T::REV;
     constexpr int KIND = Kind<PASS>::value;
     constexpr int RPI = 64 / K;    // tensor rows covered by one staged load/store instruction
-    constexpr int PITCH = K + 1;   // LDS pitch of a staged chunk (floats)
+    constexpr int PITCH = K + 1;   // LDS pitch of a staged input chunk (floats)
     constexpr int PLANE = 64 * PITCH;
+    constexpr int PO = stage_out_pitch(K);  // LDS pitch of the staged output ring: two chunks per row + 1
     constexpr int NSTAGE = T::SIN + T::SOUT;
     constexpr int ND = T::DIN > 0 ? T::DIN : 1;
     constexpr int NS = T::SIN > 0 ? T::SIN : 1;
@@ -237,7 +238,7 @@ __device__ __forceinline__ void sweep(const Params &p)
     const int nslot = W > 1 ? W : 2;
     u64 *bnd = reinterpret_cast<u64 *>(smem);
     const unsigned prog = (unsigned)(uintptr_t)(bnd + (size_t)nslot * p.mcap);  // LDS byte address of word 0
-    float *stage = reinterpret_cast<float *>(smem + p.stage_off) + (size_t)wave * (NSTAGE > 0 ? NSTAGE : 1) * PLANE;
+    float *stage = reinterpret_cast<float *>(smem + p.stage_off) + (size_t)wave * stage_floats(PASS, K);
     float *lds_in = stage;
     float *lds_out = stage + T::SIN * PLANE;
 
@@ -327,6 +328,26 @@ __device__ __forceinline__ void sweep(const Params &p)
         unsigned voff[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) voff[k] = (unsigned)(lane_off + (k * RPI) * (ld - 1) * 4) + (ABL_ALIGNED ? (unsigned)(k * RPI + r_l) * 4u : 0u);
+
+        // Staged OUTPUT geometry.  Results are written to LDS by step ([lane][step mod 2K]) and leave as
+        // K-column blocks aligned to K columns of the row-major tensor (full 128-B lines for K = 32):
+        // after chunk t0, row r owns the complete block starting at column t0 - K*floor(r/K); its
+        // element e was produced at step offset s = (r mod K) + e, i.e. in this chunk (s < K) or in the
+        // previously processed one (s >= K).  fo_off0 is the LDS index when the current chunk has
+        // parity 0, fo_dk the change when it has parity 1, fo_voff the global byte offset (row i0, t0 = 0).
+        int fo_off0[K], fo_dk[K];
+        unsigned fo_voff[K];
+        if constexpr (T::SOUT > 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int r = k * RPI + r_l;
+                const int sfull = (r % K) + s_l;
+                const bool prev = sfull >= K;
+                fo_off0[k] = r * PO + (prev ? sfull - K : sfull) + (prev ? K : 0);
+                fo_dk[k] = prev ? -K : K;
+                fo_voff[k] = (unsigned)((r * ld - K * (r / K) + s_l) * 4);
+            }
+        }
 
         // Chunk c of this strip touches only real cells of a full, unmasked strip: its addresses are all in
         // range, so the uniform part can ride in the scalar offset (no per-instruction VALU add, and no
@@ -440,6 +461,8 @@ __device__ __forceinline__ void sweep(const Params &p)
             }
 
             u64 hist[K];  // the edge-facing carry after each step (published below by one lane)
+            const int par = c & 1;
+            float *lo = lds_out + lane * PO + par * K;  // this lane's row, this chunk's half of the ring
 
             // ---- K steps; EDGE=false is the mask-free body for chunks fully inside the matrix ----
             auto steps = [&](auto edge_tag) {
@@ -468,7 +491,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                             float2 qq = make_float2(in0[k], T::DIN > 0 ? q0.x + q0.y : in1[k]);
                             store_state(t0, k, qq);
                         }
-                        if constexpr (T::SOUT > 0) lds_out[lds_own + k] = q0.x + q0.y + (T::DIN > 1 ? q1.x + q1.y : 0.f) + (T::SIN > 0 ? in0[k] : 0.f);
+                        if constexpr (T::SOUT > 0) lo[k] = q0.x + q0.y + (T::DIN > 1 ? q1.x + q1.y : 0.f) + (T::SIN > 0 ? in0[k] : 0.f);
                         hist[k] = 0;
                     } else if constexpr (PASS == PASS_FWD && KIND == CK_EXP) {
                         // scaled exp-domain forward (see CK_EXP above)
@@ -564,7 +587,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         cy.fb = qy * e;
                         cy.fa = px + cy.fc;
                         cy.fc = pm;
-                        lds_out[lds_own + k] = e;
+                        lo[k] = e;
                         hist[k] = (u64)__float_as_uint(cy.fa);
                     } else if constexpr (PASS == PASS_BWD) {
                         const double in = dpp_f64<DPP_IN>(__longlong_as_double((long long)bcv[k]), cy.a);
@@ -580,7 +603,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         cy.b = qy * e;
                         cy.a = px + cy.c;
                         cy.c = pm;
-                        lds_out[lds_own + k] = (float)e;
+                        lo[k] = (float)e;
                         hist[k] = (u64)__double_as_longlong(cy.a);
                     } else {  // PASS_ABWD
                         const float ef = in0[k];
@@ -598,7 +621,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         cy.b = dy * e + qy * ed;
                         cy.a = gx + cy.c;
                         cy.c = gm;
-                        lds_out[lds_own + k] = (float)ed;
+                        lo[k] = (float)ed;
                         hist[k] = (u64)__double_as_longlong(cy.a);
                     }
                 }
@@ -635,28 +658,27 @@ __device__ __forceinline__ void sweep(const Params &p)
                 if (lane == PUB_LANE) lds_store_i32(prog + 4 * oslot, obase + done);
             }
 
-            // ---- flush the staged output chunk (row-major, coalesced row segments) ----
+            // ---- flush: one K-column aligned block per row (see fo_* above) ----
             if constexpr (T::SOUT > 0) {
                 float vals[K];
 #pragma unroll
-                for (int k = 0; k < K; ++k) vals[k] = lds_out[lds_rw + k * RPI * PITCH];
-                const int ubase = i0 * ld + t0;
-                if (interior) {  // every element is a real cell: uniform part of the address in the scalar offset
+                for (int k = 0; k < K; ++k) vals[k] = lds_out[fo_off0[k] + par * fo_dk[k]];
+                const int ubase = (i0 * ld + t0) * 4;
+                // all K*64 elements are real cells: rows of a full strip, columns t0-K*(64/K-1) .. t0+K-1
+                const bool flush_plain = rows == 64 && t0 >= K * (64 / K - 1) && t0 + K <= m;
+                if (flush_plain) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        if constexpr (ABL_NOSTORE) {
-                            keep(vals[k]);
-                        } else {
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vals[k]), rs_out, voff[k], ubase * 4, 0);
-                        }
+                        if constexpr (ABL_NOSTORE) keep(vals[k]);
+                        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vals[k]), rs_out, fo_voff[k], ubase, 0);
                     }
                 } else {
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         const int row = k * RPI + r_l;
-                        const int col = t0 + s_l - row;
+                        const int col = t0 - K * (row / K) + s_l;
                         const bool ok = (unsigned)col < (unsigned)m && (i0 + row) < n;
-                        const unsigned off = ok ? voff[k] + (unsigned)(ubase * 4) : OOB;
+                        const unsigned off = ok ? fo_voff[k] + (unsigned)ubase : OOB;
                         if constexpr (ABL_NOSTORE) {
                             unsigned vv = __float_as_uint(vals[k]) ^ off;
                             keep(vv);
