@@ -59,15 +59,19 @@ int launch(int pass, sdp::Params &p, int device, void *stream)
     int W = g_waves[pass] > 0 ? g_waves[pass] : SDP_DEFAULT_WAVES;
     if (W > sdp::max_waves(pass)) W = sdp::max_waves(pass);
     if (W > nstrips) W = nstrips;
-    const int nslot = W > 1 ? W : 2;
     p.nstrips_max = nstrips;
     p.tpad = sdp::state_tpad(p.M);
     p.mcap = (p.M + 63) / 64 * 64;
     p.dbg = g_dbg;
-    size_t off = (size_t)nslot * p.mcap * sizeof(double) + 64;  // boundary rows + progress words
-    off = (off + 15) & ~(size_t)15;
+    size_t off = 0, lds = 0;
+    for (;; --W) {  // fewer waves if the boundary rows (long M) plus staging exceed the 160 KiB of LDS
+        const int nslot = W > 1 ? W : 2;
+        off = (size_t)nslot * p.mcap * sizeof(double) + 64;  // boundary rows + progress words
+        off = (off + 15) & ~(size_t)15;
+        lds = off + (size_t)W * sdp::stage_floats(pass, pi.K) * sizeof(float);
+        if (lds <= 160 * 1024 || W == 1) break;
+    }
     p.stage_off = (int)off;
-    const size_t lds = off + (size_t)W * sdp::stage_floats(pass, pi.K) * sizeof(float);
     e = hipFuncSetAttribute(pi.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     void *args[] = {&p};

@@ -63,13 +63,13 @@ struct Params {
     int dbg;             // experiment switches (sdp_set_waves pass 100): bit0 inputs, bit1 outputs, bit2 state: all pairs alias pair 0
 };
 
-// per-wave LDS staging (floats): inputs are [64][K+1] per plane, the output ring is [64][2K+1]
+// per-wave LDS staging (floats): input planes are rings [64][2K], the output ring is [64][2K+1]
 __host__ __device__ constexpr int stage_out_pitch(int K) { return 2 * K + 1; }
 __host__ __device__ constexpr int stage_floats(int pass, int K)
 {
     const int nin = (pass == PASS_FWD || pass == PASS_AFWD) ? 2 : (pass == PASS_ABWD ? 1 : 0);
     const int nout = (pass == PASS_BWD || pass == PASS_ABWD) ? 1 : 0;
-    return nin * 64 * (K + 1) + nout * 64 * stage_out_pitch(K);
+    return nin * 64 * (2 * K) + nout * 64 * stage_out_pitch(K);
 }
 
 // state geometry (shared by host and device)

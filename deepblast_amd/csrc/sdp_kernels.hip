@@ -204,8 +204,9 @@ __device__ __forceinline__ void sweep(const Params &p)
     constexpr bool REV = T::REV;
     constexpr int KIND = Kind<PASS>::value;
     constexpr int RPI = 64 / K;    // tensor rows covered by one staged load/store instruction
-    constexpr int PITCH = K + 1;   // LDS pitch of a staged input chunk (floats)
+    constexpr int PITCH = 2 * K;   // LDS pitch of a staged input plane: a ring of two K-column blocks per row
     constexpr int PLANE = 64 * PITCH;
+    constexpr int QMAX = (63 + K - 1) / K;  // largest ceil(r/K) over the 64 rows of a strip
     constexpr int PO = stage_out_pitch(K);  // LDS pitch of the staged output ring: two chunks per row + 1
     constexpr int NSTAGE = T::SIN + T::SOUT;
     constexpr int ND = T::DIN > 0 ? T::DIN : 1;
@@ -263,8 +264,6 @@ __device__ __forceinline__ void sweep(const Params &p)
     const int r_l = lane / K, s_l = lane % K;
     const int ld = p.M;
     const int lane_off = (r_l * ld + s_l - r_l) * 4;   // byte offset of this lane's element for k = 0, i0 = t0 = 0
-    const int lds_rw = r_l * PITCH + s_l;              // LDS slot written (inputs) / read (outputs) by this lane for k = 0
-    const int lds_own = lane * PITCH;                  // LDS row this lane reads (inputs) / writes (outputs) per step
 
     const float et = (PASS == PASS_BWD) ? p.vin[b] : 0.f;
 
@@ -324,10 +323,24 @@ __device__ __forceinline__ void sweep(const Params &p)
         float2 rd[ND][K];  // skewed state rows: slot k holds step t0+k of the current chunk and is
                            // refilled with the same slot of the next chunk right after it is consumed
 
-        // byte offset of this lane's element in staged instruction k, relative to (row i0, step 0)
-        unsigned voff[K];
+        // Staged INPUT geometry.  Row-major tensors enter as K-column blocks aligned to K columns (full
+        // 128-B lines for K = 32).  During chunk c (steps cK .. cK+K-1) row r needs columns cK-r .. cK-r+K-1,
+        // which lie in blocks c-q and c-q+1 with q = ceil(r/K); each row keeps exactly those two blocks in
+        // an LDS ring (block j in half j&1), and one new block per row per chunk is prefetched into
+        // registers a chunk ahead ("block set" bb = block bb-q of every row).
+        //   li_voff : global byte offset of this lane's element of block set 0 (row i0)
+        //   li_w    : LDS index it is written to when bb is even (odd: the other half, ^K)
+        unsigned li_voff[K];
+        int li_w[K];
+        if constexpr (T::SIN > 0) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) voff[k] = (unsigned)(lane_off + (k * RPI) * (ld - 1) * 4) + (ABL_ALIGNED ? (unsigned)(k * RPI + r_l) * 4u : 0u);
+            for (int k = 0; k < K; ++k) {
+                const int r = k * RPI + r_l;
+                const int q = (r + K - 1) / K;
+                li_voff[k] = (unsigned)((r * ld - K * q + s_l) * 4);
+                li_w[k] = r * PITCH + s_l + K * (q & 1);
+            }
+        }
 
         // Staged OUTPUT geometry.  Results are written to LDS by step ([lane][step mod 2K]) and leave as
         // K-column blocks aligned to K columns of the row-major tensor (full 128-B lines for K = 32):
@@ -349,26 +362,26 @@ __device__ __forceinline__ void sweep(const Params &p)
             }
         }
 
-        // Chunk c of this strip touches only real cells of a full, unmasked strip: its addresses are all in
-        // range, so the uniform part can ride in the scalar offset (no per-instruction VALU add, and no
-        // reliance on how the hardware range-checks the scalar offset).
+        // Chunk c of this strip touches only real cells of a full, unmasked strip: no masking needed.
         auto chunk_interior = [&](int c) { return plain_strip && c * K >= 63 && c * K + K < m; };
 
-        auto load_staged = [&](int c) {
+        auto load_block = [&](int bb) {  // block set bb -> registers
             if constexpr (T::SIN > 0) {
-                const int ubase = (i0 * ld + c * K) * 4;
-                if (chunk_interior(c)) {
+                const int ubase = (i0 * ld + bb * K) * 4;
+                // every address in range: the uniform part may ride in the scalar offset (no VALU add and no
+                // reliance on how the hardware range-checks the scalar offset)
+                if (rows == 64 && bb >= QMAX && (bb + 1) * K <= m) {
 #pragma unroll
                     for (int k = 0; k < K; ++k)
 #pragma unroll
                         for (int q = 0; q < T::SIN; ++q) {
-                            if constexpr (ABL_NOLOAD) rs[q][k] = __uint_as_float(voff[k] & 0x3fffffu) * 1e30f;
-                            else rs[q][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in[q], voff[k], ubase, 0));
+                            if constexpr (ABL_NOLOAD) rs[q][k] = __uint_as_float(li_voff[k] & 0x3fffffu) * 1e30f;
+                            else rs[q][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in[q], li_voff[k], ubase, 0));
                         }
                 } else {
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        const unsigned off = voff[k] + (unsigned)ubase;
+                        const unsigned off = li_voff[k] + (unsigned)ubase;  // negative -> huge -> out of range -> 0
 #pragma unroll
                         for (int q = 0; q < T::SIN; ++q) {
                             if constexpr (ABL_NOLOAD) rs[q][k] = __uint_as_float(off & 0x3fffffu) * 1e30f;
@@ -378,13 +391,13 @@ __device__ __forceinline__ void sweep(const Params &p)
                 }
             }
         };
-        auto write_staged = [&]() {
+        auto write_block = [&](int bb) {  // registers -> LDS ring
             if constexpr (T::SIN > 0) {
+                const int flip = (bb & 1) * K;
 #pragma unroll
                 for (int k = 0; k < K; ++k)
 #pragma unroll
-                    for (int q = 0; q < T::SIN; ++q)
-                        lds_in[q * PLANE + lds_rw + k * RPI * PITCH] = rs[q][k];
+                    for (int q = 0; q < T::SIN; ++q) lds_in[q * PLANE + (li_w[k] ^ flip)] = rs[q][k];
             }
         };
 
@@ -401,8 +414,10 @@ __device__ __forceinline__ void sweep(const Params &p)
                     else rd[q][k] = load_state(q, c_first * K, k);
                 }
         }
-        load_staged(c_first);
-        write_staged();
+        load_block(c_first);
+        write_block(c_first);
+        load_block(c_first + 1);
+        write_block(c_first + 1);
 
         for (int ci = 0; ci < nchunks; ++ci) {
             const int c = REV ? nchunks - 1 - ci : ci;
@@ -410,7 +425,8 @@ __device__ __forceinline__ void sweep(const Params &p)
             const bool more = ci + 1 < nchunks;
             const int t0_next = more ? t0 + dir * K : t0;   // state rows to prefetch while this chunk runs
 
-            if (more) load_staged(c + dir);
+            const int bb_new = REV ? c - 1 : c + 2;  // block set that chunk c+dir needs in addition
+            if (more) load_block(bb_new);
 
             // ---- boundary values for the edge lane: K broadcast LDS reads, off the dependency chain ----
             u64 bcv[K];
@@ -453,10 +469,12 @@ __device__ __forceinline__ void sweep(const Params &p)
             // ---- staged inputs of this chunk: one burst of LDS reads, off the dependency chain ----
             float in0[K], in1[K];
             if constexpr (T::SIN > 0) {
+                const int c0 = t0 - lane;  // this lane's column at step t0; ring position = column mod 2K
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    in0[k] = lds_in[lds_own + k];
-                    if constexpr (T::SIN > 1) in1[k] = lds_in[PLANE + lds_own + k];
+                    const int idx = lane * PITCH + ((c0 + k) & (2 * K - 1));
+                    in0[k] = lds_in[idx];
+                    if constexpr (T::SIN > 1) in1[k] = lds_in[PLANE + idx];
                 }
             }
 
@@ -689,7 +707,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                 }
             }
 
-            if (more) write_staged();
+            if (more) write_block(bb_new);
         }
         if constexpr (!REV) {
             if (t_final >= 0) {
