@@ -200,7 +200,7 @@ def main():
                                    f", B={B} per GPU, N={N}, M={M}, random theta/A (BASELINE.json configs[1])",
                        "global_batch": B * world, "N": N, "M": M, "variant": args.variant,
                        "parallelism": f"batch-sharded x{world}", "gather": args.gather if world > 1 else "none",
-                       "arith": "f64 carries, f32 exp/log, f32 storage"},
+                       "arith": "fwd: scaled exp-domain f32 (exact power-of-two rescaling); bwd: f32; adjoint pair: f64 carries; f32 storage"},
             "kernel_ms": ms,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
