@@ -100,7 +100,8 @@ def traceback(grad):
         upper = floor if j <= 0 else g[i, j - 1]
         if left == floor and diag == floor and upper == floor:
             break
-        cands = (left, diag, upper)
+        # the reference compares through torch.Tensor([...]), i.e. in float32, first maximum wins
+        cands = (np.float32(left), np.float32(diag), np.float32(upper))
         best = 0
         for k in (1, 2):
             if cands[k] > cands[best]:

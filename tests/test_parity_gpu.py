@@ -117,6 +117,46 @@ def test_headline_config_full_batch():
     assert abs(float(got["E"][0, -1, -1]) - 1.0) < 1e-6  # E[N,M] == Et (quirk 4)
 
 
+def test_config4_smith_waterman_full_batch():
+    """BASELINE.json configs[3]: SmithWatermanDecoder, B=256, N=M=512 -- reference semantics (3-state
+    recurrence skipping padded row/col 1, sw.py:54-55,107-110), whole batch against the oracle."""
+    B, N, M = 256, 512, 512
+    theta, A = datagen.theta_A(1, B, N, M)
+    ref = parity.oracle_all(theta, A, None, None, 1, omp=True)
+    got = parity.engine_all(theta, A, None, None, 1)
+    _assert(parity.compare(got, ref))
+    assert not got["E"][:, 0, :].any() and not got["E"][:, :, 0].any()  # first row / column never aligned
+
+
+def test_config3_variable_length_padded_batch():
+    """BASELINE.json configs[2]: B=256 pairs with N_b, M_b ~ U[64,1024] padded to (256,1024,1024).
+    Reference semantics (alignment.py:117-124) = DP over the full padded matrix: checked on the whole batch
+    through batch-independence against B=1 runs of selected pairs and against the oracle for those pairs;
+    lengths-aware mode: checked against per-item sliced oracle calls (alignment.py:165-170) for a sample."""
+    B = 256
+    lens = datagen.lengths(2, B, 64, 1024)
+    N, M = int(lens[:, 0].max()), int(lens[:, 1].max())
+    theta, A = datagen.theta_A(2, B, N, M)
+    for b in range(B):  # padding value 0 outside each pair's block (BASELINE.md config C3)
+        theta[b, lens[b, 0]:, :] = 0
+        theta[b, :, lens[b, 1]:] = 0
+        A[b, lens[b, 0]:, :] = 0
+        A[b, :, lens[b, 1]:] = 0
+    sel = [0, 17, 101, 255]
+    full = parity.engine_all(theta, A, None, None, 0)
+    ref = parity.oracle_all(theta[sel], A[sel], None, None, 0, omp=True)
+    _assert(parity.compare({"Vt": full["Vt"][sel], "E": full["E"][sel]}, ref), "padded")
+    alone = parity.engine_all(theta[sel], A[sel], None, None, 0)
+    assert np.array_equal(alone["E"], full["E"][sel]) and np.array_equal(alone["Vt"], full["Vt"][sel])
+    aware = parity.engine_all(theta, A, None, None, 0, lens=lens)
+    refl = parity.oracle_lens(theta[sel], A[sel], None, None, 0, lens[sel])
+    _assert(parity.compare({"Vt": aware["Vt"][sel], "E": aware["E"][sel]}, refl), "lengths-aware")
+    for b in sel:
+        n, m = lens[b]
+        assert not aware["E"][b, n:, :].any() and not aware["E"][b, :, m:].any()
+        assert abs(float(aware["E"][b, n - 1, m - 1]) - 1.0) < 1e-6  # terminal cell of the true block
+
+
 def test_max_cols_is_enforced():
     import torch
     from deepblast_amd._engine import get_engine

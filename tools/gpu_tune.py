@@ -90,7 +90,7 @@ def main():
     for name, path in libs.items():
         if (only and name not in only) or (not only and "--variants" not in sys.argv and name != "main"):
             continue
-        r = run(load(path), 256, 512, 512, (0, 0, 0, 0), "fb")
+        r = run(load(path), 256, 512, 512, (0, 0, 0, 0), "fba" if "--adj" in sys.argv else "fb")
         print(f"{name:10s}: " + "  ".join(f"{k}={v:8.1f}" for k, v in r.items()), flush=True)
     print("== shapes (main lib, W auto), us and cell-updates/s")
     shapes = ((256, 512, 512), (256, 512, 500), (256, 512, 520), (256, 512, 528), (256, 512, 544), (256, 512, 576),
