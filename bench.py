@@ -150,7 +150,8 @@ def main():
             out = aligner.align(theta, A)      # Vt = dec(theta, A); dVt.sum()/dtheta; all-gather Vt
             return out["E_local"]
         t = theta.detach().requires_grad_(True)
-        aln = dec.decode(t, A)                 # forward + backward kernels (create_graph)
+        a = A.detach().requires_grad_(True)    # decode() differentiates w.r.t. (theta, A) like the reference
+        aln = dec.decode(t, a)                 # forward + backward kernels (create_graph)
         (aln * Zl).sum().backward()            # adjoint forward + adjoint backward kernels
         return t.grad
 

@@ -43,6 +43,10 @@ def make_functions(variant, prefix, allow_none_operator=False):
             E = eng.backward(Et.detach(), Q, tuple(theta.shape), variant, lens)
             ctx.save_for_backward(Q, E)
             ctx.others = (operator, lens)
+            # The cotangent of the pass-through A output is all zeros whenever nothing consumes it (the
+            # reference materialises it, nw.py:357-383, and feeds the zeros to the adjoint sweep).  Asking
+            # autograd not to materialise lets the kernel skip reading a (B,N,M) tensor of zeros.
+            ctx.set_materialize_grads(False)
             return E, A
 
         @staticmethod
@@ -50,6 +54,8 @@ def make_functions(variant, prefix, allow_none_operator=False):
             Q, E = ctx.saved_tensors
             _, lens = ctx.others
             eng = _engine.get_engine()
+            if Ztheta is None:
+                Ztheta = torch.zeros_like(E)
             Vtd, Qd = eng.adjoint_forward(Q, Ztheta, ZA, variant, lens)
             Ed = eng.adjoint_backward(E, Q, Qd, variant, lens)
             return Ed, None, Vtd, None, None, None

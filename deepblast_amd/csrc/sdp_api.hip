@@ -72,8 +72,14 @@ int launch(int pass, sdp::Params &p, int device, void *stream)
         if (lds <= 160 * 1024 || W == 1) break;
     }
     p.stage_off = (int)off;
-    e = hipFuncSetAttribute(pi.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    // raise the dynamic-LDS limit once per (process, device, kernel) -- it is sticky, and the value is the
+    // 160 KiB the hardware has, so concurrent callers cannot disagree
+    static thread_local unsigned long long lds_raised[4] = {0, 0, 0, 0};  // bit d = done on device d
+    if (device >= 64 || !(lds_raised[pass] >> device & 1ull)) {
+        e = hipFuncSetAttribute(pi.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        if (device < 64) lds_raised[pass] |= 1ull << device;
+    }
     void *args[] = {&p};
     e = hipLaunchKernel(pi.kernel, dim3(p.B), dim3(64 * W), args, lds, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hipLaunchKernel");

@@ -85,6 +85,9 @@ constexpr unsigned OOB = 0x80000000u;
 #ifndef SDP_ABL
 #define SDP_ABL 0
 #endif
+#ifndef SDP_LDPLACE
+#define SDP_LDPLACE 0
+#endif
 constexpr bool ABL_NOSTORE = (SDP_ABL & 1) != 0;
 constexpr bool ABL_NOLOAD = (SDP_ABL & 2) != 0;
 constexpr bool ABL_NOSYNC = (SDP_ABL & 4) != 0;
@@ -365,31 +368,24 @@ __device__ __forceinline__ void sweep(const Params &p)
         // Chunk c of this strip touches only real cells of a full, unmasked strip: no masking needed.
         auto chunk_interior = [&](int c) { return plain_strip && c * K >= 63 && c * K + K < m; };
 
-        auto load_block = [&](int bb) {  // block set bb -> registers
+        // every address of block set bb in range: the uniform part may ride in the scalar offset (no VALU
+        // add and no reliance on how the hardware range-checks the scalar offset)
+        auto block_plain = [&](int bb) { return rows == 64 && bb >= QMAX && (bb + 1) * K <= m; };
+        auto load_block_k = [&](int bb, bool plain, int k) {  // instruction k of block set bb -> registers
             if constexpr (T::SIN > 0) {
                 const int ubase = (i0 * ld + bb * K) * 4;
-                // every address in range: the uniform part may ride in the scalar offset (no VALU add and no
-                // reliance on how the hardware range-checks the scalar offset)
-                if (rows == 64 && bb >= QMAX && (bb + 1) * K <= m) {
+                const unsigned off = plain ? li_voff[k] : li_voff[k] + (unsigned)ubase;  // negative -> huge -> 0
 #pragma unroll
-                    for (int k = 0; k < K; ++k)
-#pragma unroll
-                        for (int q = 0; q < T::SIN; ++q) {
-                            if constexpr (ABL_NOLOAD) rs[q][k] = __uint_as_float(li_voff[k] & 0x3fffffu) * 1e30f;
-                            else rs[q][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in[q], li_voff[k], ubase, 0));
-                        }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        const unsigned off = li_voff[k] + (unsigned)ubase;  // negative -> huge -> out of range -> 0
-#pragma unroll
-                        for (int q = 0; q < T::SIN; ++q) {
-                            if constexpr (ABL_NOLOAD) rs[q][k] = __uint_as_float(off & 0x3fffffu) * 1e30f;
-                            else rs[q][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in[q], off, 0, 0));
-                        }
-                    }
+                for (int q = 0; q < T::SIN; ++q) {
+                    if constexpr (ABL_NOLOAD) rs[q][k] = __uint_as_float((off + ubase) & 0x3fffffu) * 1e30f;
+                    else rs[q][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in[q], off, plain ? ubase : 0, 0));
                 }
             }
+        };
+        auto load_block = [&](int bb) {  // whole block set at once (prologue)
+            const bool plain = block_plain(bb);
+#pragma unroll
+            for (int k = 0; k < K; ++k) load_block_k(bb, plain, k);
         };
         auto write_block = [&](int bb) {  // registers -> LDS ring
             if constexpr (T::SIN > 0) {
@@ -425,8 +421,14 @@ __device__ __forceinline__ void sweep(const Params &p)
             const bool more = ci + 1 < nchunks;
             const int t0_next = more ? t0 + dir * K : t0;   // state rows to prefetch while this chunk runs
 
-            const int bb_new = REV ? c - 1 : c + 2;  // block set that chunk c+dir needs in addition
-            if (more) load_block(bb_new);
+            // block set that chunk c+dir needs in addition; its loads are issued one per step below
+            // (the last chunk re-reads its own set: harmless, keeps the step body branch-free)
+            const int bb_new = more ? (REV ? c - 1 : c + 2) : c;
+            const bool bb_plain = block_plain(bb_new);
+            if constexpr (SDP_LDPLACE == 0) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) load_block_k(bb_new, bb_plain, k);
+            }
 
             // ---- boundary values for the edge lane: K broadcast LDS reads, off the dependency chain ----
             u64 bcv[K];
@@ -478,6 +480,25 @@ __device__ __forceinline__ void sweep(const Params &p)
                 }
             }
 
+            // ---- exp-domain forward: everything that does not depend on the recurrence is computed for the
+            // whole chunk up front (K independent instruction streams the scheduler can interleave), so that
+            // the serial per-step chain below carries only the alignment, one fma and the renormalisation.
+            // theta = (kt + ft) ln2, A = (ka + fa) ln2 with integer kt, ka and ft, fa in [0,1): c* = 2^f* in [1,2)
+            float ctv[K], cav[K];
+            int ktv[K], kav[K];
+            if constexpr (PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float tt = in0[k] * 1.44269504088896340736f;
+                    const float ta = in1[k] * 1.44269504088896340736f;
+                    const float kt = __builtin_floorf(tt), ka = __builtin_floorf(ta);
+                    ctv[k] = __builtin_amdgcn_exp2f(tt - kt);
+                    cav[k] = __builtin_amdgcn_exp2f(ta - ka);
+                    ktv[k] = (int)kt;
+                    kav[k] = (int)ka;
+                }
+            }
+
             u64 hist[K];  // the edge-facing carry after each step (published below by one lane)
             const int par = c & 1;
             float *lo = lds_out + lane * PO + par * K;  // this lane's row, this chunk's half of the ring
@@ -493,6 +514,17 @@ __device__ __forceinline__ void sweep(const Params &p)
                     const bool inside = !EDGE || (unsigned)col < (unsigned)m;
                     const bool dead = EDGE && sw && (col == 0 || (i0 + lane) == 0);  // SW: padded row 1 / col 1
                     const bool rowok = !EDGE || lane < rows;
+
+                    // staged-input prefetch placement (SDP_LDPLACE): 0 = burst before the steps, 1 = one
+                    // instruction per step, 2 = two per step over the first half of the chunk
+                    if constexpr (SDP_LDPLACE == 1) {
+                        load_block_k(bb_new, bb_plain, kk);
+                    } else if constexpr (SDP_LDPLACE == 2) {
+                        if (kk < K / 2) {
+                            load_block_k(bb_new, bb_plain, 2 * kk);
+                            load_block_k(bb_new, bb_plain, 2 * kk + 1);
+                        }
+                    }
 
                     float2 q0, q1;
                     if constexpr (T::DIN > 0) {
@@ -513,17 +545,10 @@ __device__ __forceinline__ void sweep(const Params &p)
                         hist[k] = 0;
                     } else if constexpr (PASS == PASS_FWD && KIND == CK_EXP) {
                         // scaled exp-domain forward (see CK_EXP above)
-                        const float th = in0[k];
-                        const float ga = in1[k];
                         const float ua = __uint_as_float(dpp_i32<DPP_IN>((int)lo32(bcv[k]), __float_as_int(cy.xa)));
                         const int ue = dpp_i32<DPP_IN>((int)hi32(bcv[k]), cy.xe);
-                        // theta = (kt + ft) ln2, A = (ka + fa) ln2 with integer kt, ka and ft, fa in [0,1)
-                        const float tt = th * 1.44269504088896340736f;
-                        const float ta = ga * 1.44269504088896340736f;
-                        const float kt = __builtin_floorf(tt), ka = __builtin_floorf(ta);
-                        const float ct = __builtin_amdgcn_exp2f(tt - kt);  // in [1,2)
-                        const float ca = __builtin_amdgcn_exp2f(ta - ka);  // in [1,2)
-                        const int kai = (int)ka;
+                        const float ct = ctv[k], ca = cav[k];
+                        const int kai = kav[k];
                         const int ex = ue + kai, ey = cy.xe + kai, ed = cy.de;
                         const int er = max(max(ex, ey), ed);
                         const float u = __builtin_amdgcn_ldexpf(ua, ex - er);
@@ -537,7 +562,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         }
                         const float an = ct * ssum;
                         float na = __builtin_amdgcn_frexp_mantf(an);
-                        int ne = er + (int)kt + __builtin_amdgcn_frexp_expf(an);
+                        int ne = er + ktv[k] + __builtin_amdgcn_frexp_expf(an);
                         cy.da = ua;
                         cy.de = ue;
                         if constexpr (EDGE) {
