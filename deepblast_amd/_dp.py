@@ -144,6 +144,16 @@ class _Decoder(nn.Module):
     def traceback(self, grad):
         return traceback(grad)
 
+    def traceback_batch(self, grad, lengths=None):
+        """Extension: the same walk for a whole (B, N, M) batch on the device, one pair per lane,
+        instead of one host walk per pair (alignment.py:165-170).  -> list of B lists of (i, j, state);
+        raises IndexError if any walk leaves its matrix, like the per-pair version."""
+        states, counts = _engine.get_engine().traceback(grad, lengths)
+        states, counts = states.cpu().numpy(), counts.cpu().numpy()
+        if (counts < 0).any():
+            raise IndexError(f"traceback walked off the matrix for pairs {np.nonzero(counts < 0)[0].tolist()}")
+        return [[tuple(int(v) for v in row) for row in states[b, :counts[b]]] for b in range(len(counts))]
+
     def decode(self, theta, A, lengths=None):
         """Expected alignment matrix dVt/dtheta, differentiable (nw_cuda.py:319-325)."""
         with torch.enable_grad():

@@ -127,6 +127,21 @@ class HipEngine:
         _lib.check(rc, "sdp_adjoint_backward_f32")
         return Ed
 
+    def traceback(self, grad, lens=None):
+        """Batched traceback on the device -> (states (B,cap,3) int32, counts (B,) int32)."""
+        dev = self._dev(grad)
+        grad = grad.detach().to(torch.float32).contiguous()
+        B, N, M = grad.shape
+        lens = self._lens(lens, B, grad.device)
+        cap = self.lib.sdp_traceback_capacity(N, M)
+        states = torch.empty((B, cap, 3), dtype=torch.int32, device=grad.device)
+        counts = torch.empty(B, dtype=torch.int32, device=grad.device)
+        with torch.cuda.device(dev), self._bracket("sdp_traceback_kernel"):
+            rc = self.lib.sdp_traceback_i32(_ptr(grad), _ptr(states), _ptr(counts), B, N, M, _ptr(lens), dev,
+                                            self._stream(dev))
+        _lib.check(rc, "sdp_traceback_i32")
+        return states, counts
+
     def selftest(self, device=0):
         _lib.check(self.lib.sdp_selftest(device), "sdp_selftest")
 

@@ -185,6 +185,22 @@ int sdp_adjoint_backward_f32(const float *E, const float *state, const float *st
     return launch(sdp::PASS_ABWD, p, device, stream);
 }
 
+int sdp_traceback_capacity(int N, int M) { return (N > 0 && M > 0) ? N + M + 2 : 0; }
+
+int sdp_traceback_i32(const float *grad, int32_t *states, int32_t *counts, int B, int N, int M, const int32_t *lens,
+                      int device, void *stream)
+{
+    if (!grad || !states || !counts) return fail(SDP_E_NULLPTR, "sdp_traceback_i32: null pointer");
+    if (B <= 0 || N <= 0 || M <= 0) return fail(SDP_E_SHAPE, "B, N and M must be positive");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    hipLaunchKernelGGL(sdp_traceback_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, grad, states, counts,
+                       lens, B, N, M, sdp_traceback_capacity(N, M));
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "sdp_traceback_kernel");
+    return 0;
+}
+
 static int g_probe = -1;
 
 int sdp_probe(int device)

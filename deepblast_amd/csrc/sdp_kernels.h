@@ -84,6 +84,7 @@ __global__ void sdp_bwd_kernel(const sdp::Params p);
 __global__ void sdp_adj_fwd_kernel(const sdp::Params p);
 __global__ void sdp_adj_bwd_kernel(const sdp::Params p);
 __global__ void sdp_selftest_kernel(int *out);
+__global__ void sdp_traceback_kernel(const float *grad, int *states, int *counts, const int *lens, int B, int N, int M, int cap);
 }
 
 #endif  // SDP_KERNELS_H_

@@ -765,6 +765,86 @@ SDP_KERNEL(sdp_adj_fwd_kernel, sdp::PASS_AFWD, SDP_K_AFWD)
 SDP_KERNEL(sdp_adj_bwd_kernel, sdp::PASS_ABWD, SDP_K_ABWD)
 
 // ----------------------------------------------------------------------------------
+// batched traceback: the reference's greedy arg-max walk (deepblast/nw.py:401-444,
+// sw.py:328-371), one pair per lane.  Integer work, bit-identical to the host version in
+// deepblast_amd/_dp.py::traceback, including Python's negative-index wrap when exactly one of
+// (i, j) is 0; a walk that leaves the matrix (the reference raises IndexError) sets count = -1.
+// Latency-bound by construction (<= N+M dependent 3-load steps per pair); pairs run in parallel.
+// ----------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64) sdp_traceback_kernel(const float *grad, int *states, int *counts,
+                                                                      const int *lens, int B, int N, int M, int cap)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    int n = N, m = M;
+    if (lens) {
+        n = lens[2 * b];
+        m = lens[2 * b + 1];
+        n = n < 1 ? 1 : (n > N ? N : n);
+        m = m < 1 ? 1 : (m > M ? M : m);
+    }
+    const float *g = grad + (size_t)b * N * M;
+    int *out = states + (size_t)b * cap * 3;
+    const float floor_v = -100000.f;
+    auto at = [&](int i, int j, bool &bad) -> float {  // python indexing into the (n, m) block
+        if (i < 0) i += n;
+        if (j < 0) j += m;
+        if (i < 0 || i >= n || j < 0 || j >= m) {
+            bad = true;
+            return 0.f;
+        }
+        return g[(size_t)i * M + j];
+    };
+    int i = n - 1, j = m - 1, cnt = 0;
+    bool bad = false;
+    out[0] = i, out[1] = j, out[2] = 1;
+    cnt = 1;
+    while (!bad) {
+        const float left = i <= 0 ? floor_v : at(i - 1, j, bad);
+        const float diag = (i <= 0 && j <= 0) ? floor_v : at(i - 1, j - 1, bad);
+        const float upper = j <= 0 ? floor_v : at(i, j - 1, bad);
+        if (bad || (left == floor_v && diag == floor_v && upper == floor_v)) break;
+        int best = 0;
+        float bv = left;
+        if (diag > bv) best = 1, bv = diag;
+        if (upper > bv) best = 2, bv = upper;
+        if (best == 0) i -= 1;
+        else if (best == 1) i -= 1, j -= 1;
+        else j -= 1;
+        if (cnt >= cap) {
+            bad = true;
+            break;
+        }
+        out[3 * cnt] = i, out[3 * cnt + 1] = j, out[3 * cnt + 2] = best;
+        ++cnt;
+    }
+    while (!bad && i > 0) {
+        i -= 1;
+        if (cnt >= cap) { bad = true; break; }
+        out[3 * cnt] = i, out[3 * cnt + 1] = j, out[3 * cnt + 2] = 0;
+        ++cnt;
+    }
+    while (!bad && j > 0) {
+        j -= 1;
+        if (cnt >= cap) { bad = true; break; }
+        out[3 * cnt] = i, out[3 * cnt + 1] = j, out[3 * cnt + 2] = 2;
+        ++cnt;
+    }
+    if (bad) {
+        counts[b] = -1;
+        return;
+    }
+    for (int a = 0, z = cnt - 1; a < z; ++a, --z) {  // the reference returns the walk reversed
+        for (int q = 0; q < 3; ++q) {
+            const int tmp = out[3 * a + q];
+            out[3 * a + q] = out[3 * z + q];
+            out[3 * z + q] = tmp;
+        }
+    }
+    counts[b] = cnt;
+}
+
+// ----------------------------------------------------------------------------------
 // device self-test of the cross-lane semantics the sweep relies on
 // ----------------------------------------------------------------------------------
 extern "C" __global__ void sdp_selftest_kernel(int *out)

@@ -90,6 +90,14 @@ int sdp_adjoint_backward_f32(const float *E, const float *state, const float *st
                              int B, int N, int M, const int32_t *lens, int variant, int device,
                              void *stream);
 
+/* Batched traceback (reference: Decoder.traceback, deepblast/nw.py:401-444, called once per pair by
+ * NeuralAligner.traceback, alignment.py:165-170).  grad is (B,N,M); states receives, per pair, up to
+ * sdp_traceback_capacity(N,M) triples (i, j, state) in the reference's order (start of the alignment first),
+ * counts[b] the number of triples, or -1 where the reference's walk would raise IndexError. */
+int sdp_traceback_capacity(int N, int M);
+int sdp_traceback_i32(const float *grad, int32_t *states, int32_t *counts, int B, int N, int M,
+                      const int32_t *lens, int device, void *stream);
+
 /* Runs a few-microsecond device check of the cross-lane (DPP) and buffer-addressing
  * behaviour the kernels rely on.  Synchronises the device.  0 = ok. */
 int sdp_selftest(int device);

@@ -137,3 +137,66 @@ def test_padded_batch_reference_semantics_and_lengths_extension():
     refl = parity.oracle_lens(theta, A, None, None, 0, lens)
     assert parity.rel_err(v.detach().cpu().numpy(), refl["Vt"]) <= parity.TOL
     assert parity.abs_err(t.grad.cpu().numpy(), refl["E"]) <= parity.TOL
+
+
+def test_batched_device_traceback_matches_host(golden_dir):
+    """sdp_traceback_i32 (one pair per lane) is integer-identical to the per-pair host walk
+    (nw.py:401-444), on real expected-alignment matrices, with per-pair lengths, and on the reference's
+    traceback fixtures including the walks that raise IndexError."""
+    import time
+    from deepblast_amd._dp import traceback as host_traceback
+    from deepblast_amd._engine import get_engine
+    B, N, M = 48, 96, 130
+    theta, A = datagen.theta_A(31, B, N, M)
+    theta = (theta * 3.0).astype(np.float32)
+    lens = datagen.lengths(32, B, 1, 96)
+    lens[0] = (N, M)
+    dec = NeedlemanWunschDecoder("softmax")
+    for ln in (None, torch.from_numpy(lens).cuda()):
+        t = torch.from_numpy(theta).cuda().requires_grad_()
+        a = torch.from_numpy(A).cuda().requires_grad_()
+        aln = dec.decode(t, a, ln).detach()
+        states, counts = get_engine().traceback(aln, ln)
+        states, counts = states.cpu().numpy(), counts.cpu().numpy()
+        E = aln.cpu().numpy()
+        n_ok = 0
+        for b in range(B):
+            n, m = (N, M) if ln is None else lens[b]
+            try:  # degenerate blocks (e.g. a single row) make the reference walk leave the matrix
+                want = host_traceback(E[b, :n, :m])
+            except IndexError:
+                assert counts[b] == -1, b
+                continue
+            assert [tuple(r) for r in states[b, :counts[b]].tolist()] == want, b
+            n_ok += 1
+        assert n_ok >= B - 8
+        if ln is None:
+            assert dec.traceback_batch(aln) == [host_traceback(E[b]) for b in range(B)]
+    # fixtures from the reference (float32 and float64 inputs, some raising IndexError)
+    d = np.load(os.path.join(golden_dir, "g8_tracebacks.npz"))
+    for k in range(int(d["count"])):
+        g = torch.from_numpy(d[f"t{k}_grad"].astype(np.float32)).cuda()[None]
+        if bool(d[f"t{k}_ok"]):
+            assert dec.traceback_batch(g)[0] == [tuple(r) for r in d[f"t{k}_states"].tolist()], k
+        else:
+            with pytest.raises(IndexError):
+                dec.traceback_batch(g)
+    # one launch for a large batch vs the per-pair host loop (alignment.py:165-170): timing for DESIGN.md
+    B, N, M = 256, 512, 512
+    theta, A = datagen.theta_A(33, B, N, M)
+    t = torch.from_numpy(theta).cuda().requires_grad_()
+    a = torch.from_numpy(A).cuda().requires_grad_()
+    aln = dec.decode(t, a).detach()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    states, counts = get_engine().traceback(aln)
+    torch.cuda.synchronize()
+    t_dev = time.perf_counter() - t0
+    E = aln.cpu().numpy()
+    t0 = time.perf_counter()
+    host = [host_traceback(E[b]) for b in range(8)]
+    t_host = (time.perf_counter() - t0) / 8 * B
+    st, ct = states.cpu().numpy(), counts.cpu().numpy()
+    for b in range(8):
+        assert [tuple(r) for r in st[b, :ct[b]].tolist()] == host[b]
+    print(f"traceback B={B} {N}x{M}: device {t_dev * 1e3:.2f} ms, host loop (extrapolated) {t_host * 1e3:.0f} ms")

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 SHAPES = [(1, 1, 1), (2, 1, 7), (2, 7, 1), (2, 2, 2), (3, 5, 4), (2, 16, 16), (2, 17, 33), (2, 37, 101),
           (2, 64, 64), (2, 63, 65), (2, 65, 63), (2, 65, 64), (2, 101, 37), (2, 128, 128), (2, 129, 70),
           (2, 200, 300), (3, 257, 255), (2, 320, 90), (3, 512, 512), (1, 300, 1024), (1, 1024, 1024),
-          (1, 70, 2048)]
+          (1, 70, 2048), (1, 300, 2048), (2, 1100, 40)]
 
 
 def _assert(errs, what=""):
