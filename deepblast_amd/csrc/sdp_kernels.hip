@@ -88,6 +88,14 @@ constexpr unsigned OOB = 0x80000000u;
 #ifndef SDP_LDPLACE
 #define SDP_LDPLACE 0
 #endif
+// cache policy: bit0 state stores, bit1 state loads, bit2 staged loads, bit3 staged stores use nt (aux=2).
+// The skewed state is written once and read once much later, so it streams past the caches (measured
+// -3 % fwd, -5 % bwd); the row-major tensors are re-touched by neighbouring chunks and keep the default.
+#ifndef SDP_NT
+#define SDP_NT 3
+#endif
+constexpr int AUX_ST_STORE = (SDP_NT & 1) ? 2 : 0, AUX_ST_LOAD = (SDP_NT & 2) ? 2 : 0;
+constexpr int AUX_IN_LOAD = (SDP_NT & 4) ? 2 : 0, AUX_OUT_STORE = (SDP_NT & 8) ? 2 : 0;
 constexpr bool ABL_NOSTORE = (SDP_ABL & 1) != 0;
 constexpr bool ABL_NOLOAD = (SDP_ABL & 2) != 0;
 constexpr bool ABL_NOSYNC = (SDP_ABL & 4) != 0;
@@ -301,7 +309,7 @@ __device__ __forceinline__ void sweep(const Params &p)
         __amdgpu_buffer_rsrc_t rs_dout = make_rsrc(T::DOUT ? (const void *)(p.dout + st_base) : (const void *)p.vout,
                                                    T::DOUT ? st_bytes : 0u);
         auto load_state = [&](int q, int t_base, int k) {  // row t_base + k
-            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_din[q], st_lane + (k & 7) * 512, (t_base + (k & ~7)) * 512, 0);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_din[q], st_lane + (k & 7) * 512, (t_base + (k & ~7)) * 512, AUX_ST_LOAD);
             // NB: copy the elements to scalars first -- __builtin_bit_cast applied directly to a vector
             // element lvalue (v[1]) reads element 0 with this compiler.
             const unsigned lo = v[0], hi = v[1];
@@ -312,7 +320,7 @@ __device__ __forceinline__ void sweep(const Params &p)
             u32x2 v;
             v[0] = __float_as_uint(qq.x);
             v[1] = __float_as_uint(qq.y);
-            __builtin_amdgcn_raw_buffer_store_b64(v, rs_dout, st_lane + (k & 7) * 512, (t_base + (k & ~7)) * 512, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(v, rs_dout, st_lane + (k & 7) * 512, (t_base + (k & ~7)) * 512, AUX_ST_STORE);
         };
 
         Carry cy;
@@ -378,7 +386,7 @@ __device__ __forceinline__ void sweep(const Params &p)
 #pragma unroll
                 for (int q = 0; q < T::SIN; ++q) {
                     if constexpr (ABL_NOLOAD) rs[q][k] = __uint_as_float((off + ubase) & 0x3fffffu) * 1e30f;
-                    else rs[q][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in[q], off, plain ? ubase : 0, 0));
+                    else rs[q][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in[q], off, plain ? ubase : 0, AUX_IN_LOAD));
                 }
             }
         };
@@ -713,7 +721,7 @@ __device__ __forceinline__ void sweep(const Params &p)
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         if constexpr (ABL_NOSTORE) keep(vals[k]);
-                        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vals[k]), rs_out, fo_voff[k], ubase, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vals[k]), rs_out, fo_voff[k], ubase, AUX_OUT_STORE);
                     }
                 } else {
 #pragma unroll
