@@ -2,25 +2,24 @@
 //
 // Replaces the four Numba-CUDA kernels of the reference (one thread per pair, serial
 // O(N*M) loop: deepblast/nw_cuda.py:46-165, sw_cuda.py:46-165) with an anti-diagonal
-// sweep designed for CDNA4.  Arithmetic follows the CPU reference deepblast/nw.py
-// (float64 carries, float32 storage; A indexed [i-1,j-1], nw.py:56-58 -- NOT the GPU
-// reference's A[last, j-1], nw_cuda.py:61-63).
+// sweep designed for CDNA4.  Results follow the CPU reference deepblast/nw.py (A indexed
+// [i-1,j-1], nw.py:56-58 -- NOT the GPU reference's A[last, j-1], nw_cuda.py:61-63) to
+// <= 1e-4; see "carries" below for the arithmetic each pass uses.
 //
 // Mapping:
 //   * one workgroup per pair, W <= 4 wavefronts (one per SIMD);
 //   * the N rows are cut into strips of 64; wave w owns strips w, w+W, ...;
 //   * inside a strip lane l owns row i0+l and at step t sits on column t-l, so the
 //     64 lanes of a wave always lie on one anti-diagonal.  The two predecessors from
-//     row i-1 arrive from lane l-1 through one DPP wave shift of a float64 carry (no
+//     row i-1 arrive from lane l-1 through one DPP full-wave shift of the carry (no
 //     LDS, no barrier); the row-i predecessor is the lane's own register;
 //   * strip-to-strip hand-off (bottom row of strip s -> lane 0 of strip s+1) goes
-//     through a float64 row buffer in LDS, published K columns at a time with a
-//     monotonic progress word (no s_barrier anywhere);
-//   * row-major tensors (theta, A, Ztheta, ZA, E, Ed) are moved in parallelogram
-//     chunks of 64 rows x K steps: coalesced buffer loads of K-element row segments
-//     -> registers (prefetched one chunk ahead) -> LDS (pitch K+1, conflict-free for
-//     both the row-segment writes and the skewed per-lane reads) -> per-step ds_read;
-//     outputs take the mirrored path;
+//     through an 8-byte-slot row buffer in LDS, published K columns at a time with a
+//     monotonic progress word (no s_barrier anywhere in the sweep);
+//   * row-major tensors (theta, A, Ztheta, ZA, E, Ed) cross the skew through LDS in
+//     K-column blocks aligned to K columns (full 128-byte lines for K = 32): inputs
+//     live in a per-row ring of two blocks, prefetched through registers one chunk
+//     ahead; outputs are written to LDS by step and leave as aligned blocks;
 //   * the saved state (reference: Q, (B,N+2,M+2,3) fp32) is private to this library,
 //     so it is stored ALREADY SKEWED: state[pair][strip][t][lane] = (qx, qy) as
 //     float2 (qm = 1 - qx - qy).  Forward writes and backward reads are then single
@@ -77,11 +76,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, un
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
 }
 
-constexpr unsigned OOB = 0x80000000u;
+constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every buffer we build
 
 // Ablation switches for timing experiments (tools/gpu_tune.py builds variants with -DSDP_ABL=mask);
-// results are wrong when any bit is set.  bit0: no global stores, bit1: no global loads,
-// bit2: no strip hand-off waits.
+// results are wrong when any bit is set.  bit0: no global stores, bit1: no global loads, bit2: no strip
+// hand-off waits, bit3: keep every load/store but replace the recurrence by a copy.
 #ifndef SDP_ABL
 #define SDP_ABL 0
 #endif
@@ -100,7 +99,6 @@ constexpr bool ABL_NOSTORE = (SDP_ABL & 1) != 0;
 constexpr bool ABL_NOLOAD = (SDP_ABL & 2) != 0;
 constexpr bool ABL_NOSYNC = (SDP_ABL & 4) != 0;
 constexpr bool ABL_NOMATH = (SDP_ABL & 8) != 0;
-constexpr bool ABL_ALIGNED = (SDP_ABL & 16) != 0;  // drop the skew from staged global addresses (wrong cells, full-line aligned)  // keep every load/store, replace the recurrence by a copy
 // Progress words live in LDS and are polled by other waves.  They are accessed with explicit DS
 // instructions: a volatile access through a generic pointer compiles to flat_load + vmcnt(0),
 // which drains every outstanding prefetch at each poll.
@@ -119,7 +117,7 @@ template <class X>
 __device__ __forceinline__ void keep(X &x)
 {
     asm volatile("" : "+v"(x));
-}  // voffset that is out of range for every buffer we build
+}
 
 // ----------------------------------------------------------------------------------
 // pass descriptions
