@@ -87,6 +87,9 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #ifndef SDP_LDPLACE
 #define SDP_LDPLACE 0
 #endif
+#ifndef SDP_PREPASS
+#define SDP_PREPASS 1
+#endif
 // cache policy: bit0 state stores, bit1 state loads, bit2 staged loads, bit3 staged stores use nt (aux=2).
 // The skewed state is written once and read once much later, so it streams past the caches (measured
 // -3 % fwd, -5 % bwd); the row-major tensors are re-touched by neighbouring chunks and keep the default.
@@ -167,10 +170,14 @@ enum { CK_F64 = 0, CK_F32 = 1, CK_EXP = 2 };
 #ifndef SDP_BWD_KIND
 #define SDP_BWD_KIND 1
 #endif
+#ifndef SDP_ABWD_KIND
+#define SDP_ABWD_KIND 0
+#endif
 
 template <int PASS>
 struct Kind {
-    static constexpr int value = PASS == PASS_FWD ? SDP_FWD_KIND : (PASS == PASS_BWD ? SDP_BWD_KIND : CK_F64);
+    static constexpr int value = PASS == PASS_FWD ? SDP_FWD_KIND
+                                 : (PASS == PASS_BWD ? SDP_BWD_KIND : (PASS == PASS_ABWD ? SDP_ABWD_KIND : CK_F64));
 };
 
 typedef unsigned long long u64;  // one boundary slot (LDS) / one edge value in registers
@@ -492,7 +499,7 @@ __device__ __forceinline__ void sweep(const Params &p)
             // theta = (kt + ft) ln2, A = (ka + fa) ln2 with integer kt, ka and ft, fa in [0,1): c* = 2^f* in [1,2)
             float ctv[K], cav[K];
             int ktv[K], kav[K];
-            if constexpr (PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH) {
+            if constexpr (PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_PREPASS) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const float tt = in0[k] * 1.44269504088896340736f;
@@ -553,8 +560,18 @@ __device__ __forceinline__ void sweep(const Params &p)
                         // scaled exp-domain forward (see CK_EXP above)
                         const float ua = __uint_as_float(dpp_i32<DPP_IN>((int)lo32(bcv[k]), __float_as_int(cy.xa)));
                         const int ue = dpp_i32<DPP_IN>((int)hi32(bcv[k]), cy.xe);
-                        const float ct = ctv[k], ca = cav[k];
-                        const int kai = kav[k];
+                        float ct, ca;
+                        int kai, kti;
+                        if constexpr (SDP_PREPASS) {
+                            ct = ctv[k], ca = cav[k], kai = kav[k], kti = ktv[k];
+                        } else {
+                            const float tt = in0[k] * 1.44269504088896340736f;
+                            const float ta = in1[k] * 1.44269504088896340736f;
+                            const float kt = __builtin_floorf(tt), ka = __builtin_floorf(ta);
+                            ct = __builtin_amdgcn_exp2f(tt - kt);
+                            ca = __builtin_amdgcn_exp2f(ta - ka);
+                            kti = (int)kt, kai = (int)ka;
+                        }
                         const int ex = ue + kai, ey = cy.xe + kai, ed = cy.de;
                         const int er = max(max(ex, ey), ed);
                         const float u = __builtin_amdgcn_ldexpf(ua, ex - er);
@@ -568,7 +585,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         }
                         const float an = ct * ssum;
                         float na = __builtin_amdgcn_frexp_mantf(an);
-                        int ne = er + ktv[k] + __builtin_amdgcn_frexp_expf(an);
+                        int ne = er + kti + __builtin_amdgcn_frexp_expf(an);
                         cy.da = ua;
                         cy.de = ue;
                         if constexpr (EDGE) {
@@ -654,6 +671,24 @@ __device__ __forceinline__ void sweep(const Params &p)
                         cy.c = pm;
                         lo[k] = (float)e;
                         hist[k] = (u64)__double_as_longlong(cy.a);
+                    } else if constexpr (PASS == PASS_ABWD && KIND == CK_F32) {
+                        const float ef = in0[k];
+                        const float in = __uint_as_float(dpp_i32<DPP_IN>((int)lo32(bcv[k]), __float_as_int(cy.fa)));
+                        const bool cell = inside && rowok;
+                        const bool live = cell && !dead;
+                        const float ed = cell ? in + cy.fb : 0.f;
+                        const float e = live ? ef : 0.f;
+                        const float qx = live ? q0.x : 0.f, qy = live ? q0.y : 0.f;
+                        const float qm = live ? (1.f - qx) - qy : 0.f;
+                        const float dx = live ? q1.x : 0.f, dy = live ? q1.y : 0.f;
+                        const float dm = -(dx + dy);
+                        const float gx = dx * e + qx * ed;
+                        const float gm = dm * e + qm * ed;
+                        cy.fb = dy * e + qy * ed;
+                        cy.fa = gx + cy.fc;
+                        cy.fc = gm;
+                        lo[k] = ed;
+                        hist[k] = (u64)__float_as_uint(cy.fa);
                     } else {  // PASS_ABWD
                         const float ef = in0[k];
                         const double in = dpp_f64<DPP_IN>(__longlong_as_double((long long)bcv[k]), cy.a);

@@ -30,6 +30,8 @@ __global__ void lat(long long *out, float seed)
     // nchain independent chains interleaved (1 = pure latency; more = throughput)
     double da[4] = {d, d + 1, d + 2, d + 3};
     float fa[4] = {f, f + 1, f + 2, f + 3};
+    int ia[4] = {(int)seed, (int)seed + 1, (int)seed + 2, (int)seed + 3};
+    int i2 = (int)(seed * 3.f) + threadIdx.x, i3 = (int)(seed * 5.f) - threadIdx.x;
     long long t0 = clock64();
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
@@ -52,12 +54,19 @@ __global__ void lat(long long *out, float seed)
                 if constexpr (OP == 13) fa[c] = __shfl_up(fa[c], 1);                          // ds_bpermute path
                 if constexpr (OP == 14) fa[c] = dpp_f32<0x111>(f3, fa[c]);                    // dpp row_shr:1
                 if constexpr (OP == 15) da[c] = dpp_f64<0x138>(d3, da[c]) + d2;               // dpp f64 + add_f64
+                if constexpr (OP == 16) fa[c] = __builtin_amdgcn_ldexpf(fa[c], ia[c] & 3) + f3;         // ldexp + add
+                if constexpr (OP == 17) fa[c] = __builtin_amdgcn_frexp_mantf(fa[c]) + f2;              // frexp_mant + add
+                if constexpr (OP == 18) { ia[c] = __builtin_amdgcn_frexp_expf(fa[c]) + ia[c]; fa[c] = __int_as_float((ia[c] & 0xff) | 0x3f800000); }  // frexp_exp + add + and_or
+                if constexpr (OP == 19) ia[c] = max(max(ia[c], i2), i3) + 1;                             // max3_i32 + add
+                if constexpr (OP == 20) ia[c] = ia[c] + i2 + i3;                                        // add3
+                if constexpr (OP == 21) fa[c] = __builtin_floorf(fa[c] * f2) + f3;                      // mul + floor + add
+                if constexpr (OP == 22) { ia[c] = (int)fa[c]; fa[c] = (float)ia[c] * f2; }               // cvt_i32_f32 + cvt_f32_i32 + mul
             }
         }
     }
     long long t1 = clock64();
     double acc = 0;
-    for (int c = 0; c < 4; ++c) acc += da[c] + fa[c];
+    for (int c = 0; c < 4; ++c) acc += da[c] + fa[c] + ia[c];
     if (threadIdx.x == 0) out[0] = t1 - t0;
     if (acc == 12345.678) out[1] = 1;
 }
@@ -100,5 +109,12 @@ int main()
     run<10>("dpp wave_shr f32 + fma", d);
     run<15>("dpp wave_shr f64 + add_f64", d);
     run<13>("__shfl_up (bpermute)", d);
+    run<16>("v_ldexp_f32 + add", d);
+    run<17>("v_frexp_mant_f32 + add", d);
+    run<18>("v_frexp_exp_i32 + add + and_or", d);
+    run<19>("v_max3_i32 + add", d);
+    run<20>("v_add3_u32", d);
+    run<21>("mul + v_floor_f32 + add", d);
+    run<22>("cvt_i32_f32 + cvt_f32_i32 + mul", d);
     return 0;
 }
