@@ -157,6 +157,39 @@ def test_config3_variable_length_padded_batch():
         assert abs(float(aware["E"][b, n - 1, m - 1]) - 1.0) < 1e-6  # terminal cell of the true block
 
 
+@pytest.mark.parametrize("waves", [1, 2, 3, 4])
+def test_every_wave_count_gives_identical_results(waves):
+    """The strip hand-off (LDS row buffer + progress words) must not depend on how many wavefronts share a
+    pair: results with W = 1, 2, 3, 4 waves are bit-identical (same arithmetic, different schedule)."""
+    from deepblast_amd._engine import get_engine
+    lib = get_engine().lib
+    B, N, M = 3, 400, 333   # 7 strips: every wave owns several, W = 3 does not divide them evenly
+    theta, A = datagen.theta_A(61, B, N, M)
+    Z = datagen.normal(62, (B, N, M))
+    ref = parity.oracle_all(theta, A, None, Z, 0)
+    base = parity.engine_all(theta, A, None, Z, 0)
+    try:
+        for p in range(4):
+            lib.sdp_set_waves(p, waves)
+        got = parity.engine_all(theta, A, None, Z, 0)
+    finally:
+        for p in range(4):
+            lib.sdp_set_waves(p, 0)
+    _assert(parity.compare(got, ref), f"W={waves}")
+    for k in ("Vt", "E", "Ed", "Vtd"):
+        assert np.array_equal(got[k], base[k]), (waves, k)
+
+
+def test_repeated_calls_are_deterministic():
+    B, N, M = 16, 257, 300
+    theta, A = datagen.theta_A(63, B, N, M)
+    Z = datagen.normal(64, (B, N, M))
+    a = parity.engine_all(theta, A, None, Z, 1)
+    b = parity.engine_all(theta, A, None, Z, 1)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
 def test_max_cols_is_enforced():
     import torch
     from deepblast_amd._engine import get_engine
