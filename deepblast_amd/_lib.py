@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdp_hip.so")
+# SDP_LIB_PATH lets experiments (tools/gpu_tune.py variants) run the whole test-suite on another build
+LIB_PATH = os.environ.get("SDP_LIB_PATH") or os.path.join(_HERE, "libsdp_hip.so")
 
 SDP_NW, SDP_SW = 0, 1
 
