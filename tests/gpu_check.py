@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Diagnostic sweep on a GPU box: selftest, parity table over many shapes, quick timing.
-Usage: python tools/gpu_check.py [--quick] [--time]"""
+"""(test infrastructure) Diagnostic sweep on a GPU box: selftest, parity table over many shapes, quick timing.
+Usage: python tests/gpu_check.py [--quick] [--time]"""
 import os
 import sys
 import time
@@ -9,7 +9,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # parity.py / datagen.py live here
 
 import torch  # noqa: E402
 
