@@ -34,6 +34,10 @@ SIGNATURES = {
     "sdp_traceback_capacity": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "sdp_traceback_i32": (ctypes.c_int, [_c_f32p, _c_i32p, _c_i32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i32p,
                                          ctypes.c_int, ctypes.c_void_p]),
+    "sdp_loss_forward_f32": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_i32p, ctypes.c_void_p, _c_i32p, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "sdp_loss_backward_f32": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_i32p, _c_f32p, _c_f32p, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "sdp_selftest": (ctypes.c_int, [ctypes.c_int]),
     "sdp_probe": (ctypes.c_int, [ctypes.c_int]),
     "sdp_set_waves": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),

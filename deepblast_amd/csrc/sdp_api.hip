@@ -201,6 +201,39 @@ int sdp_traceback_i32(const float *grad, int32_t *states, int32_t *counts, int B
     return 0;
 }
 
+int sdp_loss_forward_f32(const float *ref, const float *pred, const float *G, const int32_t *lens, double *acc, int32_t *cnt,
+                         int B, int N, int M, int kind, int device, void *stream)
+{
+    if (!ref || !pred || !G || !acc || !cnt) return fail(SDP_E_NULLPTR, "sdp_loss_forward_f32: null pointer");
+    if (B <= 0 || N <= 0 || M <= 0) return fail(SDP_E_SHAPE, "B, N and M must be positive");
+    if (kind < 0 || kind > 2) return fail(SDP_E_VARIANT, "loss kind must be 0 (cross entropy), 1 (path) or 2 (alignment)");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    hipLaunchKernelGGL(sdp_loss_fwd_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, ref, pred, G, lens, acc, cnt, N, M, kind);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "sdp_loss_fwd_kernel");
+    return 0;
+}
+
+int sdp_loss_backward_f32(const float *ref, const float *pred, const float *G, const int32_t *lens, const float *scale,
+                          float *grad, int B, int N, int M, int kind, int device, void *stream)
+{
+    if (!ref || !pred || !G || !scale || !grad) return fail(SDP_E_NULLPTR, "sdp_loss_backward_f32: null pointer");
+    if (B <= 0 || N <= 0 || M <= 0) return fail(SDP_E_SHAPE, "B, N and M must be positive");
+    if (kind < 0 || kind > 2) return fail(SDP_E_VARIANT, "loss kind must be 0 (cross entropy), 1 (path) or 2 (alignment)");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    const long long cells = (long long)N * M;
+    int gx = (int)((cells + 256 * 8 - 1) / (256 * 8));
+    if (gx < 1) gx = 1;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(sdp_loss_bwd_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, ref, pred, G, lens, scale, grad, N, M,
+                       kind);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "sdp_loss_bwd_kernel");
+    return 0;
+}
+
 static int g_probe = -1;
 
 int sdp_probe(int device)

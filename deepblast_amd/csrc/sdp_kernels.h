@@ -84,6 +84,8 @@ __global__ void sdp_bwd_kernel(const sdp::Params p);
 __global__ void sdp_adj_fwd_kernel(const sdp::Params p);
 __global__ void sdp_adj_bwd_kernel(const sdp::Params p);
 __global__ void sdp_selftest_kernel(int *out);
+__global__ void sdp_loss_fwd_kernel(const float *ref, const float *pred, const float *G, const int *lens, double *acc, int *cnt, int N, int M, int kind);
+__global__ void sdp_loss_bwd_kernel(const float *ref, const float *pred, const float *G, const int *lens, const float *scale, float *grad, int N, int M, int kind);
 __global__ void sdp_traceback_kernel(const float *grad, int *states, int *counts, const int *lens, int B, int N, int M, int cap);
 }
 

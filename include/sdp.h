@@ -98,6 +98,22 @@ int sdp_traceback_capacity(int N, int M);
 int sdp_traceback_i32(const float *grad, int32_t *states, int32_t *counts, int B, int N, int M,
                       const int32_t *lens, int device, void *stream);
 
+/* Masked alignment losses (reference: deepblast/losses.py -- MatrixCrossEntropy :9-48, SoftPathLoss :51-79,
+ * SoftAlignmentLoss :82-118; evaluated there with a Python loop over the batch, trainer.py:154-171).
+ * ref = Ytrue (kinds 0, 2) or the path-distance matrix P (kind 1); pred = predicted alignment matrix;
+ * G = mask (non-zero = counted); all (B,N,M) fp32.  Forward: acc[b] = per-pair masked sum (see kernel
+ * header), cnt[b] = number of counted cells.  Backward: grad (B,N,M), written in full, = scale[b] times the
+ * per-element derivative factor.  The Python layer (deepblast_amd/losses.py) turns acc/cnt into the
+ * reference's scalar and supplies scale. */
+#define SDP_LOSS_CROSS_ENTROPY 0
+#define SDP_LOSS_PATH 1
+#define SDP_LOSS_ALIGNMENT 2
+int sdp_loss_forward_f32(const float *ref, const float *pred, const float *G, const int32_t *lens, double *acc,
+                         int32_t *cnt, int B, int N, int M, int kind, int device, void *stream);
+int sdp_loss_backward_f32(const float *ref, const float *pred, const float *G, const int32_t *lens,
+                          const float *scale, float *grad, int B, int N, int M, int kind, int device,
+                          void *stream);
+
 /* Runs a few-microsecond device check of the cross-lane (DPP) and buffer-addressing
  * behaviour the kernels rely on.  Synchronises the device.  0 = ok. */
 int sdp_selftest(int device);
