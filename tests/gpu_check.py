@@ -98,6 +98,42 @@ def main():
             print(f"v{variant} stress {name}: " + " ".join(f"{k}={v:.2e}" for k, v in errs.items())
                   + ("" if bad <= parity.TOL else "  <-- FAIL"), flush=True)
 
+    if "--fuzz" in sys.argv:
+        nf = int(sys.argv[sys.argv.index("--fuzz") + 1])
+        rng = np.random.default_rng(12345)
+        fworst = 0.0
+        for it in range(nf):
+            B = int(rng.integers(1, 5))
+            N = int(rng.choice([rng.integers(1, 40), rng.integers(40, 200), rng.integers(200, 700)]))
+            M = int(rng.choice([rng.integers(1, 40), rng.integers(40, 200), rng.integers(200, 900)]))
+            variant = int(rng.integers(0, 2))
+            theta, A = datagen.theta_A(10000 + it, B, N, M)
+            theta = (theta * float(rng.choice([0.1, 1.0, 5.0]))).astype(np.float32)
+            A = (A * float(rng.choice([0.1, 1.0, 10.0])) + float(rng.choice([0.0, 0.0, 0.5]))).astype(np.float32)
+            Z = datagen.normal(20000 + it, (B, N, M))
+            use_lens = bool(rng.integers(0, 2))
+            try:
+                if use_lens:
+                    lens = np.stack([rng.integers(1, N + 1, B), rng.integers(1, M + 1, B)], axis=1).astype(np.int32)
+                    ref = parity.oracle_lens(theta, A, None, Z, variant, lens)
+                    got = parity.engine_all(theta, A, None, Z, variant, lens=lens)
+                else:
+                    Et = (0.5 + datagen.uniform(30000 + it, (B,))).astype(np.float32)
+                    ref = parity.oracle_all(theta, A, Et, Z, variant)
+                    got = parity.engine_all(theta, A, Et, Z, variant)
+                errs = parity.compare(got, ref)
+                bad = max(errs.values())
+                bad = bad if np.isfinite(bad) else 9e9
+            except Exception as e:
+                print("fuzz EXCEPTION", it, B, N, M, variant, use_lens, e, flush=True)
+                bad = 9e9
+            fworst = max(fworst, bad)
+            if bad > parity.TOL:
+                nfail += 1
+                print(f"fuzz FAIL it={it} B={B} N={N} M={M} v={variant} lens={use_lens}: {errs}", flush=True)
+        worst = max(worst, fworst)
+        print(f"fuzz: {nf} random cases, worst {fworst:.3e}", flush=True)
+
     print(f"worst normalised error {worst:.3e}; failures {nfail}", flush=True)
 
     if "--time" in sys.argv:

@@ -190,6 +190,29 @@ def test_repeated_calls_are_deterministic():
         assert np.array_equal(a[k], b[k]), k
 
 
+def test_random_shapes_scales_and_lengths():
+    """Seeded fuzz: random (B, N, M), input scales, variant and optional per-pair lengths, all four passes."""
+    rng = np.random.default_rng(2024)
+    for it in range(60):
+        B = int(rng.integers(1, 5))
+        N = int(rng.choice([rng.integers(1, 40), rng.integers(40, 200), rng.integers(200, 600)]))
+        M = int(rng.choice([rng.integers(1, 40), rng.integers(40, 200), rng.integers(200, 800)]))
+        variant = int(rng.integers(0, 2))
+        theta, A = datagen.theta_A(10000 + it, B, N, M)
+        theta = (theta * float(rng.choice([0.1, 1.0, 5.0]))).astype(np.float32)
+        A = (A * float(rng.choice([0.1, 1.0, 10.0])) + float(rng.choice([0.0, 0.0, 0.5]))).astype(np.float32)
+        Z = datagen.normal(20000 + it, (B, N, M))
+        if rng.integers(0, 2):
+            lens = np.stack([rng.integers(1, N + 1, B), rng.integers(1, M + 1, B)], axis=1).astype(np.int32)
+            ref = parity.oracle_lens(theta, A, None, Z, variant, lens)
+            got = parity.engine_all(theta, A, None, Z, variant, lens=lens)
+        else:
+            Et = (0.5 + datagen.uniform(30000 + it, (B,))).astype(np.float32)
+            ref = parity.oracle_all(theta, A, Et, Z, variant)
+            got = parity.engine_all(theta, A, Et, Z, variant)
+        _assert(parity.compare(got, ref), f"fuzz {it}: B={B} N={N} M={M} variant={variant}")
+
+
 def test_max_cols_is_enforced():
     import torch
     from deepblast_amd._engine import get_engine
