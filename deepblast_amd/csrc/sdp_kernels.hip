@@ -552,7 +552,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                     if constexpr (ABL_NOMATH) {
                         if constexpr (T::DOUT > 0) {
                             float2 qq = make_float2(in0[k], T::DIN > 0 ? q0.x + q0.y : in1[k]);
-                            store_state(t0, k, qq);
+                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
                         }
                         if constexpr (T::SOUT > 0) lo[k] = q0.x + q0.y + (T::DIN > 1 ? q1.x + q1.y : 0.f) + (T::SIN > 0 ? in0[k] : 0.f);
                         hist[k] = 0;
