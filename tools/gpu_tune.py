@@ -58,6 +58,7 @@ def run(lib, B, N, M, waves=(0, 0, 0, 0), passes="fb"):
     assert f() == 0
     out["fwd"] = timeit(f)
     out["bwd"] = timeit(b)
+    out["fwd;bwd"] = timeit(lambda: (f(), b()))
     if "a" in passes:
         af = lambda: lib.sdp_adjoint_forward_f32(st.data_ptr(), z.data_ptr(), None, vt.data_ptr(), std.data_ptr(), B, N, M, None, 0, 0, stream)
         ab = lambda: lib.sdp_adjoint_backward_f32(E.data_ptr(), st.data_ptr(), std.data_ptr(), Ed.data_ptr(), B, N, M, None, 0, 0, stream)
