@@ -504,8 +504,10 @@ __device__ __forceinline__ void sweep(const Params &p)
             if constexpr (PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_PREPASS) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const float tt = in0[k] * 1.44269504088896340736f;
-                    const float ta = in1[k] * 1.44269504088896340736f;
+                    // clamped to +-2^20 bits so that A = -inf (a forbidden gap) behaves like the reference's
+                    // exp(-inf) = 0 instead of producing inf - inf
+                    const float tt = __builtin_amdgcn_fmed3f(in0[k] * 1.44269504088896340736f, -1048576.f, 1048576.f);
+                    const float ta = __builtin_amdgcn_fmed3f(in1[k] * 1.44269504088896340736f, -1048576.f, 1048576.f);
                     const float kt = __builtin_floorf(tt), ka = __builtin_floorf(ta);
                     ctv[k] = __builtin_amdgcn_exp2f(tt - kt);
                     cav[k] = __builtin_amdgcn_exp2f(ta - ka);
@@ -567,8 +569,8 @@ __device__ __forceinline__ void sweep(const Params &p)
                         if constexpr (SDP_PREPASS) {
                             ct = ctv[k], ca = cav[k], kai = kav[k], kti = ktv[k];
                         } else {
-                            const float tt = in0[k] * 1.44269504088896340736f;
-                            const float ta = in1[k] * 1.44269504088896340736f;
+                            const float tt = __builtin_amdgcn_fmed3f(in0[k] * 1.44269504088896340736f, -1048576.f, 1048576.f);
+                            const float ta = __builtin_amdgcn_fmed3f(in1[k] * 1.44269504088896340736f, -1048576.f, 1048576.f);
                             const float kt = __builtin_floorf(tt), ka = __builtin_floorf(ta);
                             ct = __builtin_amdgcn_exp2f(tt - kt);
                             ca = __builtin_amdgcn_exp2f(ta - ka);

@@ -190,6 +190,21 @@ def test_repeated_calls_are_deterministic():
         assert np.array_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("variant", [0, 1], ids=["nw", "sw"])
+def test_forbidden_gaps_minus_infinity(variant):
+    """A = -inf (a forbidden gap) is legal in the reference: exp(-inf) = 0 removes the x/y terms (nw.py:10-27).
+    The exp-domain forward clamps the exponent instead of forming inf - inf."""
+    B, N, M = 2, 90, 130
+    theta, A = datagen.theta_A(81, B, N, M)
+    A[datagen.uniform(82, (B, N, M)) < 0.05] = -np.inf
+    A[0, 10:20, :] = -np.inf
+    Z = datagen.normal(83, (B, N, M))
+    ref = parity.oracle_all(theta, A, None, Z, variant)
+    got = parity.engine_all(theta, A, None, Z, variant)
+    assert np.isfinite(got["E"]).all() and np.isfinite(got["Vt"]).all()
+    _assert(parity.compare(got, ref))
+
+
 def test_random_shapes_scales_and_lengths():
     """Seeded fuzz: random (B, N, M), input scales, variant and optional per-pair lengths, all four passes."""
     rng = np.random.default_rng(2024)
