@@ -29,7 +29,10 @@ def build(force=False, extra=(), out=None):
     newest = max(os.path.getmtime(f) for f in SRC + HDR)
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest:
         return OUT
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # -ffp-contract=off: every fused multiply-add in the kernels is written explicitly, so that the different
+    # builds of a sweep (chunk length, masked / mask-free body) round identically and results do not depend on
+    # which build or which body a cell happens to run in
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
            *extra, *SRC, "-o", OUT]
     subprocess.check_call(cmd)

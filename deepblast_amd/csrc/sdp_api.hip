@@ -26,19 +26,41 @@ int fail_hip(hipError_t e, const char *what)
     return (int)e;
 }
 
-struct PassInfo {
+struct Variant {
     const void *kernel;
-    int K, nstage;
+    int K, maxw, id;
 };
 
-PassInfo pass_info(int pass)
+// kernel builds: [0] fwd, [1] bwd (throughput: K=32, <= 4 waves), [2] adj-fwd, [3] adj-bwd,
+// [4] bwd (latency: K=16, <= 8 waves)
+Variant variant(int id)
 {
-    switch (pass) {
-    case sdp::PASS_FWD: return {(const void *)sdp_fwd_kernel, SDP_K_FWD, 2};
-    case sdp::PASS_BWD: return {(const void *)sdp_bwd_kernel, SDP_K_BWD, 1};
-    case sdp::PASS_AFWD: return {(const void *)sdp_adj_fwd_kernel, SDP_K_AFWD, 2};
-    default: return {(const void *)sdp_adj_bwd_kernel, SDP_K_ABWD, 2};
+    switch (id) {
+    case 0: return {(const void *)sdp_fwd_kernel, SDP_K_FWD, SDP_MAXW_FWD, 0};
+    case 1: return {(const void *)sdp_bwd_kernel, SDP_K_BWD, SDP_MAXW_BWD, 1};
+    case 2: return {(const void *)sdp_adj_fwd_kernel, SDP_K_AFWD, SDP_MAXW_AFWD, 2};
+    case 3: return {(const void *)sdp_adj_bwd_kernel, SDP_K_ABWD, SDP_MAXW_ABWD, 3};
+    default: return {(const void *)sdp_bwd_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 4};
     }
+}
+
+int num_cus(int device)
+{
+    static thread_local int cached[64] = {0};
+    if (device >= 0 && device < 64 && cached[device] > 0) return cached[device];
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0) n = 256;
+    if (device >= 0 && device < 64) cached[device] = n;
+    return n;
+}
+
+size_t lds_bytes(int pass, int K, int W, int mcap, size_t *stage_off)
+{
+    const int nslot = W > 1 ? W : 2;
+    size_t off = (size_t)nslot * mcap * sizeof(double) + 64;  // boundary rows + progress words
+    off = (off + 15) & ~(size_t)15;
+    if (stage_off) *stage_off = off;
+    return off + (size_t)W * sdp::stage_floats(pass, K) * sizeof(float);
 }
 
 int check_shape(int B, int N, int M, int variant)
@@ -54,34 +76,42 @@ int launch(int pass, sdp::Params &p, int device, void *stream)
 {
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
-    const PassInfo pi = pass_info(pass);
     const int nstrips = sdp::state_nstrips(p.N);
-    int W = g_waves[pass] > 0 ? g_waves[pass] : SDP_DEFAULT_WAVES;
-    if (W > sdp::max_waves(pass)) W = sdp::max_waves(pass);
-    if (W > nstrips) W = nstrips;
     p.nstrips_max = nstrips;
     p.tpad = sdp::state_tpad(p.M);
     p.mcap = (p.M + 63) / 64 * 64;
     p.dbg = g_dbg;
+
+    // Waves per pair.  A batch that fills the GPU (one pair per CU) is bound by HBM and runs best with one
+    // wave per SIMD; a smaller batch is bound by the length of the strip pipeline of a single pair, which
+    // more waves (and the shorter-chunk build of the backward sweep) shorten.
+    const bool full = p.B * 4 >= num_cus(device) * 3;
+    Variant v = variant(pass);
+    int W = g_waves[pass];
+    if (W <= 0) W = (pass == sdp::PASS_FWD || pass == sdp::PASS_BWD) ? (full ? 4 : 8) : SDP_DEFAULT_WAVES;
+    if (pass == sdp::PASS_BWD) {
+        // the throughput build needs 4 waves' worth of LDS; fall back to the latency build when it does not fit
+        const int w4 = nstrips < 4 ? nstrips : 4;
+        if (W > SDP_MAXW_BWD || lds_bytes(pass, SDP_K_BWD, w4, p.mcap, nullptr) > 160 * 1024) v = variant(4);
+    }
+    if (W > v.maxw) W = v.maxw;
+    if (W > nstrips) W = nstrips;
     size_t off = 0, lds = 0;
     for (;; --W) {  // fewer waves if the boundary rows (long M) plus staging exceed the 160 KiB of LDS
-        const int nslot = W > 1 ? W : 2;
-        off = (size_t)nslot * p.mcap * sizeof(double) + 64;  // boundary rows + progress words
-        off = (off + 15) & ~(size_t)15;
-        lds = off + (size_t)W * sdp::stage_floats(pass, pi.K) * sizeof(float);
+        lds = lds_bytes(pass, v.K, W, p.mcap, &off);
         if (lds <= 160 * 1024 || W == 1) break;
     }
     p.stage_off = (int)off;
-    // raise the dynamic-LDS limit once per (process, device, kernel) -- it is sticky, and the value is the
+    // raise the dynamic-LDS limit once per (thread, device, kernel) -- it is sticky, and the value is the
     // 160 KiB the hardware has, so concurrent callers cannot disagree
-    static thread_local unsigned long long lds_raised[4] = {0, 0, 0, 0};  // bit d = done on device d
-    if (device >= 64 || !(lds_raised[pass] >> device & 1ull)) {
-        e = hipFuncSetAttribute(pi.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static thread_local unsigned long long lds_raised[5] = {0, 0, 0, 0, 0};  // bit d = done on device d
+    if (device >= 64 || !(lds_raised[v.id] >> device & 1ull)) {
+        e = hipFuncSetAttribute(v.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-        if (device < 64) lds_raised[pass] |= 1ull << device;
+        if (device < 64) lds_raised[v.id] |= 1ull << device;
     }
     void *args[] = {&p};
-    e = hipLaunchKernel(pi.kernel, dim3(p.B), dim3(64 * W), args, lds, (hipStream_t)stream);
+    e = hipLaunchKernel(v.kernel, dim3(p.B), dim3(64 * W), args, lds, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hipLaunchKernel");
     return 0;
 }

@@ -11,7 +11,7 @@
 // chunk length K per pass (steps per staged chunk; must divide 64).  K is also the prefetch
 // distance of the skewed state rows, in steps.
 #ifndef SDP_K_FWD
-#define SDP_K_FWD 32
+#define SDP_K_FWD 16
 #endif
 #ifndef SDP_K_BWD
 #define SDP_K_BWD 32
@@ -26,10 +26,24 @@
 // Largest workgroup (in waves) each kernel is compiled for; the VGPR budget per wave is
 // 512 / (waves per SIMD), so 8 waves leave 256 registers, 4 waves the full 512.
 #ifndef SDP_MAXW_FWD
-#define SDP_MAXW_FWD 4
+#define SDP_MAXW_FWD 8
 #endif
-#ifndef SDP_MAXW_REV
-#define SDP_MAXW_REV 4
+#ifndef SDP_MAXW_BWD
+#define SDP_MAXW_BWD 4
+#endif
+// Second build of the backward sweep for batches that do not fill the GPU: shorter chunks and up to 8
+// waves shorten the strip pipeline (the kernel is then bound by per-pair latency, not by HBM).
+#ifndef SDP_K_BWD_LAT
+#define SDP_K_BWD_LAT 16
+#endif
+#ifndef SDP_MAXW_BWD_LAT
+#define SDP_MAXW_BWD_LAT 8
+#endif
+#ifndef SDP_MAXW_AFWD
+#define SDP_MAXW_AFWD 4
+#endif
+#ifndef SDP_MAXW_ABWD
+#define SDP_MAXW_ABWD 4
 #endif
 #ifndef SDP_DEFAULT_WAVES
 #define SDP_DEFAULT_WAVES 4
@@ -39,7 +53,10 @@ namespace sdp {
 
 enum { PASS_FWD = 0, PASS_BWD = 1, PASS_AFWD = 2, PASS_ABWD = 3 };
 
-constexpr int max_waves(int pass) { return pass == PASS_FWD ? SDP_MAXW_FWD : SDP_MAXW_REV; }
+constexpr int max_waves(int pass)
+{
+    return pass == PASS_FWD ? SDP_MAXW_FWD : (pass == PASS_BWD ? SDP_MAXW_BWD : (pass == PASS_AFWD ? SDP_MAXW_AFWD : SDP_MAXW_ABWD));
+}
 
 constexpr int MAX_COLS = 2048;     // boundary rows live in LDS (4 x MAX_COLS x 8 B = 64 KiB)
 constexpr int PROG_STRIDE = 4096;  // > MAX_COLS: progress words are (use index)*PROG_STRIDE + columns
@@ -81,6 +98,7 @@ __host__ __device__ inline int state_tpad(int M) { return (M + 63 + 63) / 64 * 6
 extern "C" {
 __global__ void sdp_fwd_kernel(const sdp::Params p);
 __global__ void sdp_bwd_kernel(const sdp::Params p);
+__global__ void sdp_bwd_lat_kernel(const sdp::Params p);
 __global__ void sdp_adj_fwd_kernel(const sdp::Params p);
 __global__ void sdp_adj_bwd_kernel(const sdp::Params p);
 __global__ void sdp_selftest_kernel(int *out);

@@ -633,7 +633,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         const double qm = live ? (1.0 - qx) - qy : 0.0;
                         const double zad = (double)za;
                         const double a0 = zad + up, a1 = diag, a2 = zad + left;
-                        const double tot = (qx * a0 + qm * a1) + qy * a2;
+                        const double tot = __builtin_fma(qy, a2, __builtin_fma(qm, a1, qx * a0));
                         const double vd = (double)zt + tot;
                         {
                             float2 qq = make_float2((float)(qx * (a0 - tot)), (float)(qy * (a2 - tot)));
@@ -653,10 +653,9 @@ __device__ __forceinline__ void sweep(const Params &p)
                         }
                         const float qx = live ? q0.x : 0.f, qy = live ? q0.y : 0.f;
                         const float qm = (1.f - qx) - qy;
-                        const float px = qx * e, pm = qm * e;
                         cy.fb = qy * e;
-                        cy.fa = px + cy.fc;
-                        cy.fc = pm;
+                        cy.fa = __builtin_fmaf(qx, e, cy.fc);  // px + pm of the previous step
+                        cy.fc = qm * e;
                         lo[k] = e;
                         hist[k] = (u64)__float_as_uint(cy.fa);
                     } else if constexpr (PASS == PASS_BWD) {
@@ -669,10 +668,9 @@ __device__ __forceinline__ void sweep(const Params &p)
                         }
                         const double qx = live ? (double)q0.x : 0.0, qy = live ? (double)q0.y : 0.0;
                         const double qm = (1.0 - qx) - qy;
-                        const double px = qx * e, pm = qm * e;
                         cy.b = qy * e;
-                        cy.a = px + cy.c;
-                        cy.c = pm;
+                        cy.a = __builtin_fma(qx, e, cy.c);  // px + pm of the previous step
+                        cy.c = qm * e;
                         lo[k] = (float)e;
                         hist[k] = (u64)__double_as_longlong(cy.a);
                     } else if constexpr (PASS == PASS_ABWD && KIND == CK_F32) {
@@ -704,11 +702,9 @@ __device__ __forceinline__ void sweep(const Params &p)
                         const double qm = live ? (1.0 - qx) - qy : 0.0;
                         const double dx = live ? (double)q1.x : 0.0, dy = live ? (double)q1.y : 0.0;
                         const double dm = -(dx + dy);
-                        const double gx = dx * e + qx * ed;
-                        const double gm = dm * e + qm * ed;
-                        cy.b = dy * e + qy * ed;
-                        cy.a = gx + cy.c;
-                        cy.c = gm;
+                        cy.b = __builtin_fma(dy, e, qy * ed);
+                        cy.a = __builtin_fma(dx, e, __builtin_fma(qx, ed, cy.c));  // gx + gm of the previous step
+                        cy.c = __builtin_fma(dm, e, qm * ed);
                         lo[k] = (float)ed;
                         hist[k] = (u64)__double_as_longlong(cy.a);
                     }
@@ -798,16 +794,17 @@ __device__ __forceinline__ void sweep(const Params &p)
 // ----------------------------------------------------------------------------------
 // kernels (one symbol per pass so that rocprofv3 names them)
 // ----------------------------------------------------------------------------------
-#define SDP_KERNEL(NAME, PASS, K)                                                               \
-    extern "C" __global__ void __launch_bounds__(sdp::max_waves(PASS) * 64) NAME(const sdp::Params p)  \
-    {                                                                                           \
-        sdp::sweep<PASS, K>(p);                                                                 \
+#define SDP_KERNEL(NAME, PASS, K, MAXW)                                                    \
+    extern "C" __global__ void __launch_bounds__((MAXW) * 64) NAME(const sdp::Params p)    \
+    {                                                                                      \
+        sdp::sweep<PASS, K>(p);                                                            \
     }
 
-SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD)
-SDP_KERNEL(sdp_bwd_kernel, sdp::PASS_BWD, SDP_K_BWD)
-SDP_KERNEL(sdp_adj_fwd_kernel, sdp::PASS_AFWD, SDP_K_AFWD)
-SDP_KERNEL(sdp_adj_bwd_kernel, sdp::PASS_ABWD, SDP_K_ABWD)
+SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD)
+SDP_KERNEL(sdp_bwd_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD)
+SDP_KERNEL(sdp_bwd_lat_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT)
+SDP_KERNEL(sdp_adj_fwd_kernel, sdp::PASS_AFWD, SDP_K_AFWD, SDP_MAXW_AFWD)
+SDP_KERNEL(sdp_adj_bwd_kernel, sdp::PASS_ABWD, SDP_K_ABWD, SDP_MAXW_ABWD)
 
 // ----------------------------------------------------------------------------------
 // batched traceback: the reference's greedy arg-max walk (deepblast/nw.py:401-444,
