@@ -104,6 +104,7 @@ constexpr bool ABL_NOSTORE = (SDP_ABL & 1) != 0;
 constexpr bool ABL_NOLOAD = (SDP_ABL & 2) != 0;
 constexpr bool ABL_NOSYNC = (SDP_ABL & 4) != 0;
 constexpr bool ABL_NOMATH = (SDP_ABL & 8) != 0;
+constexpr bool ABL_NOLDS = (SDP_ABL & 16) != 0;  // staged inputs bypass LDS (wrong data, same dependencies)
 // Progress words live in LDS and are polled by other waves.  They are accessed with explicit DS
 // instructions: a volatile access through a generic pointer compiles to flat_load + vmcnt(0),
 // which drains every outstanding prefetch at each poll.
@@ -189,6 +190,8 @@ __device__ __forceinline__ unsigned lo32(u64 x) { return (unsigned)x; }
 __device__ __forceinline__ unsigned hi32(u64 x) { return (unsigned)(x >> 32); }
 
 // V = 0 in the exp-domain representation: 0.5 * 2^1
+// largest |theta|, |A| (natural-log units) for the forward sweep's fast form: 40 * log2(e) < 58 bits
+constexpr float EXP_FAST_LIM = 40.f;
 constexpr float EXP_ONE_A = 0.5f;
 constexpr int EXP_ONE_E = 1;
 
@@ -297,7 +300,8 @@ __device__ __forceinline__ void sweep(const Params &p)
         const u64 *bnd_in = bnd + (size_t)pslot * p.mcap;
         u64 *bnd_out = bnd + (size_t)oslot * p.mcap;
         // chunks in which every lane sits on a real, non-special cell need no masking at all
-        const bool plain_strip = rows == 64 && !(sw && s == 0) && s != nstrips - 1;
+        // (the terminal cell of the last strip is met at t >= m-1, which interior chunks never contain)
+        const bool plain_strip = rows == 64 && !(sw && s == 0);
 
         // step at which this lane meets the terminal cell (n-1, m-1) of the pair; -1 if never
         const int t_final = (s == nstrips - 1 && lane == rows - 1) ? (m - 1 + lane) : -1;
@@ -403,7 +407,7 @@ __device__ __forceinline__ void sweep(const Params &p)
             for (int k = 0; k < K; ++k) load_block_k(bb, plain, k);
         };
         auto write_block = [&](int bb) {  // registers -> LDS ring
-            if constexpr (T::SIN > 0) {
+            if constexpr (T::SIN > 0 && !ABL_NOLDS) {
                 const int flip = (bb & 1) * K;
 #pragma unroll
                 for (int k = 0; k < K; ++k)
@@ -490,6 +494,11 @@ __device__ __forceinline__ void sweep(const Params &p)
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const int idx = lane * PITCH + ((c0 + k) & (2 * K - 1));
+                    if constexpr (ABL_NOLDS) {
+                        in0[k] = rs[0][k];
+                        if constexpr (T::SIN > 1) in1[k] = rs[1][k];
+                        continue;
+                    }
                     in0[k] = lds_in[idx];
                     if constexpr (T::SIN > 1) in1[k] = lds_in[PLANE + idx];
                 }
@@ -501,18 +510,39 @@ __device__ __forceinline__ void sweep(const Params &p)
             // theta = (kt + ft) ln2, A = (ka + fa) ln2 with integer kt, ka and ft, fa in [0,1): c* = 2^f* in [1,2)
             float ctv[K], cav[K];
             int ktv[K], kav[K];
+            const bool interior = chunk_interior(c);
+            // Fast form for interior chunks whose |theta|, |A| all stay below EXP_FAST_LIM (decided per wave and
+            // chunk from the data alone): 2^tt and 2^ta are then ordinary floats that can multiply the aligned
+            // sum directly -- alpha stays within 2^+-118 before it is renormalised -- so the integer/fraction
+            // split and the two exponent additions drop out of the per-step work.
+            bool fast = false;
             if constexpr (PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_PREPASS) {
+                if (interior) {
+                    float rng = 0.f;
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    // clamped to +-2^20 bits so that A = -inf (a forbidden gap) behaves like the reference's
-                    // exp(-inf) = 0 instead of producing inf - inf
-                    const float tt = __builtin_amdgcn_fmed3f(in0[k] * 1.44269504088896340736f, -1048576.f, 1048576.f);
-                    const float ta = __builtin_amdgcn_fmed3f(in1[k] * 1.44269504088896340736f, -1048576.f, 1048576.f);
-                    const float kt = __builtin_floorf(tt), ka = __builtin_floorf(ta);
-                    ctv[k] = __builtin_amdgcn_exp2f(tt - kt);
-                    cav[k] = __builtin_amdgcn_exp2f(ta - ka);
-                    ktv[k] = (int)kt;
-                    kav[k] = (int)ka;
+                    for (int k = 0; k < K; ++k) rng = __builtin_fmaxf(rng, __builtin_fmaxf(__builtin_fabsf(in0[k]), __builtin_fabsf(in1[k])));
+                    fast = __builtin_amdgcn_ballot_w64(!(rng <= EXP_FAST_LIM)) == 0;
+                }
+                if (fast) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        ctv[k] = __builtin_amdgcn_exp2f(in0[k] * 1.44269504088896340736f);
+                        cav[k] = __builtin_amdgcn_exp2f(in1[k] * 1.44269504088896340736f);
+                        ktv[k] = kav[k] = 0;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        // clamped to +-2^20 bits so that A = -inf (a forbidden gap) behaves like the reference's
+                        // exp(-inf) = 0 instead of producing inf - inf
+                        const float tt = __builtin_amdgcn_fmed3f(in0[k] * 1.44269504088896340736f, -1048576.f, 1048576.f);
+                        const float ta = __builtin_amdgcn_fmed3f(in1[k] * 1.44269504088896340736f, -1048576.f, 1048576.f);
+                        const float kt = __builtin_floorf(tt), ka = __builtin_floorf(ta);
+                        ctv[k] = __builtin_amdgcn_exp2f(tt - kt);
+                        cav[k] = __builtin_amdgcn_exp2f(ta - ka);
+                        ktv[k] = (int)kt;
+                        kav[k] = (int)ka;
+                    }
                 }
             }
 
@@ -521,8 +551,9 @@ __device__ __forceinline__ void sweep(const Params &p)
             float *lo = lds_out + lane * PO + par * K;  // this lane's row, this chunk's half of the ring
 
             // ---- K steps; EDGE=false is the mask-free body for chunks fully inside the matrix ----
-            auto steps = [&](auto edge_tag) {
+            auto steps = [&](auto edge_tag, auto fast_tag) {
                 constexpr bool EDGE = decltype(edge_tag)::value;
+                constexpr bool FAST = decltype(fast_tag)::value;  // exp-domain forward only, see above
 #pragma unroll
                 for (int kk = 0; kk < K; ++kk) {
                     const int k = REV ? K - 1 - kk : kk;
@@ -566,7 +597,9 @@ __device__ __forceinline__ void sweep(const Params &p)
                         const int ue = dpp_i32<DPP_IN>((int)hi32(bcv[k]), cy.xe);
                         float ct, ca;
                         int kai, kti;
-                        if constexpr (SDP_PREPASS) {
+                        if constexpr (FAST) {
+                            ct = ctv[k], ca = cav[k], kai = 0, kti = 0;
+                        } else if constexpr (SDP_PREPASS) {
                             ct = ctv[k], ca = cav[k], kai = kav[k], kti = ktv[k];
                         } else {
                             const float tt = __builtin_amdgcn_fmed3f(in0[k] * 1.44269504088896340736f, -1048576.f, 1048576.f);
@@ -710,9 +743,14 @@ __device__ __forceinline__ void sweep(const Params &p)
                     }
                 }
             };
-            const bool interior = chunk_interior(c);
-            if (interior) steps(std::false_type{});
-            else steps(std::true_type{});
+            if constexpr (PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_PREPASS) {
+                if (fast) steps(std::false_type{}, std::true_type{});
+                else if (interior) steps(std::false_type{}, std::false_type{});
+                else steps(std::true_type{}, std::false_type{});
+            } else {
+                if (interior) steps(std::false_type{}, std::false_type{});
+                else steps(std::true_type{}, std::false_type{});
+            }
 
             // ---- publish K boundary values for the next strip (one lane, K LDS writes) ----
             if (has_succ) {
