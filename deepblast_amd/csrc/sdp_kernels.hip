@@ -84,11 +84,11 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #ifndef SDP_ABL
 #define SDP_ABL 0
 #endif
-#ifndef SDP_LDPLACE
-#define SDP_LDPLACE 0
-#endif
 #ifndef SDP_PREPASS
 #define SDP_PREPASS 1
+#endif
+#ifndef SDP_WF
+#define SDP_WF 1  // forward sweep: try the windowed form on interior chunks
 #endif
 // cache policy: bit0 state stores, bit1 state loads, bit2 staged loads, bit3 staged stores use nt (aux=2).
 // The skewed state is read exactly once, so its loads stream past the caches (nt); its stores keep the
@@ -190,8 +190,19 @@ __device__ __forceinline__ unsigned lo32(u64 x) { return (unsigned)x; }
 __device__ __forceinline__ unsigned hi32(u64 x) { return (unsigned)(x >> 32); }
 
 // V = 0 in the exp-domain representation: 0.5 * 2^1
-// largest |theta|, |A| (natural-log units) for the forward sweep's fast form: 40 * log2(e) < 58 bits
-constexpr float EXP_FAST_LIM = 40.f;
+// Windowed form of the exp-domain forward (see steps_wf in sweep): values of one chunk are plain floats relative
+// to a per-lane exponent ("frame").  After the K steps every value a lane produced must lie in [WF_LO, WF_HI]:
+//   * overflow anywhere in a step gives inf (or NaN), which stays in the lane's value and trips the upper test;
+//   * the factors 2^theta and 2^A of every step must not exceed WF_FMAX = 2^12 (|theta|, |A| <= 8.3; anything
+//     else, including NaN, goes to the normalised form).  Then a value >= WF_LO = 2^-60 proves that the sum it
+//     was made from was a normal float (>= 2^-72), and values <= WF_HI = 2^110 keep every sum below 2^124, so its
+//     reciprocal is a normal float too.  A = -inf (2^A = 0) is fine.
+// A chunk that fails a test is redone in the per-step-normalised form; nothing was committed before the test.
+// WF_HI also leaves room for the consumers of published values (value * 2^A * 2 + ... stays below 2^128).
+constexpr unsigned WF_HI = 0x76800000u;  // 2^110
+constexpr unsigned WF_LO = 0x21800000u;  // 2^-60
+constexpr unsigned WF_FMAX = 0x45800000u;  // 2^12
+constexpr int FRAME_NONE = (int)0x80000000;  // published chunk is not in one frame (per-value exponents apply)
 constexpr float EXP_ONE_A = 0.5f;
 constexpr int EXP_ONE_E = 1;
 
@@ -201,6 +212,9 @@ __device__ __forceinline__ u64 edge_zero()
     if constexpr (KIND == CK_EXP) return pack2(__float_as_uint(EXP_ONE_A), (unsigned)EXP_ONE_E);
     else return 0ull;  // +0.0 as f64 and as f32
 }
+
+// bank-spreading permutation of the staged-input ring (see "Staged INPUT geometry"): 0,4,1,5,2,6,3,7
+__device__ __forceinline__ constexpr int ring_pi(int x) { return ((x & 1) << 2) | (x >> 1); }
 
 // per-lane recurrence state carried from step to step
 struct Carry {
@@ -224,9 +238,13 @@ __device__ __forceinline__ void sweep(const Params &p)
     using T = Traits<PASS>;
     constexpr bool REV = T::REV;
     constexpr int KIND = Kind<PASS>::value;
-    constexpr int RPI = 64 / K;    // tensor rows covered by one staged load/store instruction
+    constexpr int RPI = 64 / K;    // tensor rows covered by one staged (dword) store instruction
     constexpr int PITCH = 2 * K;   // LDS pitch of a staged input plane: a ring of two K-column blocks per row
+    constexpr int RING = 2 * K;
     constexpr int PLANE = 64 * PITCH;
+    constexpr int LPR = K / 4;     // staged loads move 4 columns per lane: lanes per K-column block of a row,
+    constexpr int RPL = 64 / LPR;  // rows per load instruction,
+    constexpr int NLD = K / 4;     // load instructions per plane and chunk
     constexpr int QMAX = (63 + K - 1) / K;  // largest ceil(r/K) over the 64 rows of a strip
     constexpr int PO = stage_out_pitch(K);  // LDS pitch of the staged output ring: two chunks per row + 1
     constexpr int NSTAGE = T::SIN + T::SOUT;
@@ -257,14 +275,20 @@ __device__ __forceinline__ void sweep(const Params &p)
     const bool sw = p.variant == SDP_SW;
 
     // ---- LDS carve: boundary rows (8-byte slots), progress words, per-wave staging ----
-    const int nslot = W > 1 ? W : 2;
+    // Two boundary rows suffice for any number of waves: strip s+2 can only overwrite column c of the row it
+    // shares with strip s after strip s+1 -- the reader of that row -- has produced its own column c.  The
+    // progress words are per wave (strips that share a word are processed one after the other by that wave).
+    constexpr int nslot = 2;
     u64 *bnd = reinterpret_cast<u64 *>(smem);
     const unsigned prog = (unsigned)(uintptr_t)(bnd + (size_t)nslot * p.mcap);  // LDS byte address of word 0
+    // frame words (forward sweep): one per boundary row and producer chunk, FRAME_NONE or the common exponent of
+    // the K values that chunk published
+    int *frm = reinterpret_cast<int *>(bnd + (size_t)nslot * p.mcap) + 16;
     float *stage = reinterpret_cast<float *>(smem + p.stage_off) + (size_t)wave * stage_floats(PASS, K);
     float *lds_in = stage;
     float *lds_out = stage + T::SIN * PLANE;
 
-    if (threadIdx.x < (unsigned)nslot) lds_store_i32(prog + 4 * threadIdx.x, 0);
+    if (threadIdx.x < (unsigned)W) lds_store_i32(prog + 4 * threadIdx.x, 0);
     __syncthreads();
     if (wave >= nstrips) return;
 
@@ -283,6 +307,7 @@ __device__ __forceinline__ void sweep(const Params &p)
 
     // per-lane constants of the staged-chunk geometry: lane -> (row r_l within RPI, step s_l)
     const int r_l = lane / K, s_l = lane % K;
+    const int r4_l = lane / LPR, cg_l = lane % LPR;  // staged loads: lane -> (row within RPL, 4-column group)
     const int ld = p.M;
     const int lane_off = (r_l * ld + s_l - r_l) * 4;   // byte offset of this lane's element for k = 0, i0 = t0 = 0
 
@@ -295,10 +320,14 @@ __device__ __forceinline__ void sweep(const Params &p)
         const bool has_pred = REV ? (s + 1 < nstrips) : (s > 0);   // strip whose boundary we consume
         const bool has_succ = REV ? (s > 0) : (s + 1 < nstrips);   // strip that consumes ours
         const int pidx = sidx - 1;                                  // producer's position in processing order
-        const int pslot = has_pred ? pidx % nslot : 0, pbase = has_pred ? (pidx / nslot) * PROG_STRIDE : 0;
-        const int oslot = sidx % nslot, obase = (sidx / nslot) * PROG_STRIDE;
+        const int pslot = has_pred ? pidx % nslot : 0, oslot = sidx % nslot;                 // boundary rows
+        const int pword = has_pred ? pidx % W : 0, pbase = has_pred ? (pidx / W) * PROG_STRIDE : 0;  // progress words
+        const int oword = sidx % W, obase = (sidx / W) * PROG_STRIDE;
         const u64 *bnd_in = bnd + (size_t)pslot * p.mcap;
         u64 *bnd_out = bnd + (size_t)oslot * p.mcap;
+        const int *frm_in = frm + pslot * FRAME_CAP;
+        int *frm_out = frm + oslot * FRAME_CAP;
+        int wf_skip = 0;  // chunks to leave to the normalised form after a failed windowed attempt
         // chunks in which every lane sits on a real, non-special cell need no masking at all
         // (the terminal cell of the last strip is met at t >= m-1, which interior chunks never contain)
         const bool plain_strip = rows == 64 && !(sw && s == 0);
@@ -345,22 +374,27 @@ __device__ __forceinline__ void sweep(const Params &p)
         float2 rd[ND][K];  // skewed state rows: slot k holds step t0+k of the current chunk and is
                            // refilled with the same slot of the next chunk right after it is consumed
 
-        // Staged INPUT geometry.  Row-major tensors enter as K-column blocks aligned to K columns (full
-        // 128-B lines for K = 32).  During chunk c (steps cK .. cK+K-1) row r needs columns cK-r .. cK-r+K-1,
-        // which lie in blocks c-q and c-q+1 with q = ceil(r/K); each row keeps exactly those two blocks in
-        // an LDS ring (block j in half j&1), and one new block per row per chunk is prefetched into
-        // registers a chunk ahead ("block set" bb = block bb-q of every row).
-        //   li_voff : global byte offset of this lane's element of block set 0 (row i0)
-        //   li_w    : LDS index it is written to when bb is even (odd: the other half, ^K)
-        unsigned li_voff[K];
-        int li_w[K];
+        // Staged INPUT geometry.  Row-major tensors enter as K-column blocks, four columns (one dwordx4) per
+        // lane; row r's blocks start at columns K*j - (r mod 4).  During chunk c (steps cK .. cK+K-1) row r needs
+        // columns cK-r .. cK-r+K-1, which lie in its blocks c-q and c-q+1 with q = ceil(4*floor(r/4)/K); each row
+        // keeps exactly those two blocks in an LDS ring of 2K columns, and one new block per row per chunk is
+        // prefetched into registers a chunk ahead ("block set" bb = block bb-q of every row).
+        // Ring position of column j of row r: (j + r + 4*pi(r mod 8)) mod 2K.  The "+r" cancels the skew -- lane
+        // l finds step t at position (t + 4*pi(l mod 8)) mod 2K -- and together with the (r mod 4) shift of the
+        // blocks it makes every loaded dwordx4 land on one aligned 16-byte slot: K/4 ds_write_b128 per plane on
+        // the way in, K/4 ds_read_b128 per plane on the way out, addresses differing between lanes by constants.
+        // pi = (0,4,1,5,2,6,3,7) spreads both access patterns over the banks.
+        //   li_voff : global byte offset of this lane's 4 columns of block set 0 (row i0)
+        //   li_w    : LDS index they are written to when bb is even (odd: the other half, ^K)
+        unsigned li_voff[NLD];
+        int li_w[NLD];
         if constexpr (T::SIN > 0) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const int r = k * RPI + r_l;
-                const int q = (r + K - 1) / K;
-                li_voff[k] = (unsigned)((r * ld - K * q + s_l) * 4);
-                li_w[k] = r * PITCH + s_l + K * (q & 1);
+            for (int i = 0; i < NLD; ++i) {
+                const int r = i * RPL + r4_l;
+                const int q = ((r & ~3) + K - 1) / K;
+                li_voff[i] = (unsigned)((r * ld - K * q - (r & 3) + 4 * cg_l) * 4);
+                li_w[i] = r * PITCH + ((4 * cg_l + K * (q & 1) + (r & ~3) + 4 * ring_pi(r & 7)) & (RING - 1));
             }
         }
 
@@ -390,29 +424,42 @@ __device__ __forceinline__ void sweep(const Params &p)
         // every address of block set bb in range: the uniform part may ride in the scalar offset (no VALU
         // add and no reliance on how the hardware range-checks the scalar offset)
         auto block_plain = [&](int bb) { return rows == 64 && bb >= QMAX && (bb + 1) * K <= m; };
-        auto load_block_k = [&](int bb, bool plain, int k) {  // instruction k of block set bb -> registers
+        auto load_block_i = [&](int bb, bool plain, int i) {  // instruction i of block set bb -> registers
             if constexpr (T::SIN > 0) {
                 const int ubase = (i0 * ld + bb * K) * 4;
-                const unsigned off = plain ? li_voff[k] : li_voff[k] + (unsigned)ubase;  // negative -> huge -> 0
+                const unsigned off = plain ? li_voff[i] : li_voff[i] + (unsigned)ubase;  // negative -> huge -> 0
 #pragma unroll
                 for (int q = 0; q < T::SIN; ++q) {
-                    if constexpr (ABL_NOLOAD) rs[q][k] = __uint_as_float((off + ubase) & 0x3fffffu) * 1e30f;
-                    else rs[q][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in[q], off, plain ? ubase : 0, AUX_IN_LOAD));
+                    if constexpr (ABL_NOLOAD) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) rs[q][4 * i + j] = __uint_as_float((off + ubase + j) & 0x3fffffu) * 1e30f;
+                    } else {
+                        // each dword is range-checked on its own (tools/ubench/bufx4.hip), and only dword
+                        // alignment is needed, so M need not be a multiple of 4
+                        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_in[q], off, plain ? ubase : 0, AUX_IN_LOAD);
+                        const unsigned v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+                        rs[q][4 * i] = __uint_as_float(v0);
+                        rs[q][4 * i + 1] = __uint_as_float(v1);
+                        rs[q][4 * i + 2] = __uint_as_float(v2);
+                        rs[q][4 * i + 3] = __uint_as_float(v3);
+                    }
                 }
             }
         };
-        auto load_block = [&](int bb) {  // whole block set at once (prologue)
+        auto load_block = [&](int bb) {  // whole block set at once
             const bool plain = block_plain(bb);
 #pragma unroll
-            for (int k = 0; k < K; ++k) load_block_k(bb, plain, k);
+            for (int i = 0; i < NLD; ++i) load_block_i(bb, plain, i);
         };
         auto write_block = [&](int bb) {  // registers -> LDS ring
             if constexpr (T::SIN > 0 && !ABL_NOLDS) {
                 const int flip = (bb & 1) * K;
 #pragma unroll
-                for (int k = 0; k < K; ++k)
+                for (int i = 0; i < NLD; ++i)
 #pragma unroll
-                    for (int q = 0; q < T::SIN; ++q) lds_in[q * PLANE + (li_w[k] ^ flip)] = rs[q][k];
+                    for (int q = 0; q < T::SIN; ++q)
+                        *reinterpret_cast<float4 *>(lds_in + q * PLANE + (li_w[i] ^ flip)) =
+                            make_float4(rs[q][4 * i], rs[q][4 * i + 1], rs[q][4 * i + 2], rs[q][4 * i + 3]);
             }
         };
 
@@ -443,11 +490,7 @@ __device__ __forceinline__ void sweep(const Params &p)
             // block set that chunk c+dir needs in addition; its loads are issued one per step below
             // (the last chunk re-reads its own set: harmless, keeps the step body branch-free)
             const int bb_new = more ? (REV ? c - 1 : c + 2) : c;
-            const bool bb_plain = block_plain(bb_new);
-            if constexpr (SDP_LDPLACE == 0) {
-#pragma unroll
-                for (int k = 0; k < K; ++k) load_block_k(bb_new, bb_plain, k);
-            }
+            load_block(bb_new);
 
             // ---- boundary values for the edge lane: K broadcast LDS reads, off the dependency chain ----
             u64 bcv[K];
@@ -468,7 +511,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                     // bounded spin: a missed hand-off must never hang the device (results would be wrong,
                     // which the parity tests catch); ~0.2 s at the cap
                     for (int spin = 0; !ABL_NOSYNC && spin < (1 << 21); ++spin) {
-                        if (__builtin_amdgcn_readfirstlane(lds_load_i32(prog + 4 * pslot)) >= pbase + need) break;
+                        if (__builtin_amdgcn_readfirstlane(lds_load_i32(prog + 4 * pword)) >= pbase + need) break;
                         __builtin_amdgcn_s_sleep(1);
                     }
                     if (c_lo >= 0 && c_lo + K <= m) {
@@ -490,17 +533,24 @@ __device__ __forceinline__ void sweep(const Params &p)
             // ---- staged inputs of this chunk: one burst of LDS reads, off the dependency chain ----
             float in0[K], in1[K];
             if constexpr (T::SIN > 0) {
-                const int c0 = t0 - lane;  // this lane's column at step t0; ring position = column mod 2K
+                if constexpr (ABL_NOLDS) {
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const int idx = lane * PITCH + ((c0 + k) & (2 * K - 1));
-                    if constexpr (ABL_NOLDS) {
+                    for (int k = 0; k < K; ++k) {
                         in0[k] = rs[0][k];
                         if constexpr (T::SIN > 1) in1[k] = rs[1][k];
-                        continue;
                     }
-                    in0[k] = lds_in[idx];
-                    if constexpr (T::SIN > 1) in1[k] = lds_in[PLANE + idx];
+                } else {
+                    const int pr = (t0 & (RING - 1)) + 4 * ring_pi(lane & 7);  // ring position of step t0 for this lane
+#pragma unroll
+                    for (int g = 0; g < K / 4; ++g) {
+                        const int idx = lane * PITCH + ((pr + 4 * g) & (RING - 1));
+                        const float4 v0 = *reinterpret_cast<const float4 *>(lds_in + idx);
+                        in0[4 * g] = v0.x, in0[4 * g + 1] = v0.y, in0[4 * g + 2] = v0.z, in0[4 * g + 3] = v0.w;
+                        if constexpr (T::SIN > 1) {
+                            const float4 v1 = *reinterpret_cast<const float4 *>(lds_in + PLANE + idx);
+                            in1[4 * g] = v1.x, in1[4 * g + 1] = v1.y, in1[4 * g + 2] = v1.z, in1[4 * g + 3] = v1.w;
+                        }
+                    }
                 }
             }
 
@@ -511,26 +561,8 @@ __device__ __forceinline__ void sweep(const Params &p)
             float ctv[K], cav[K];
             int ktv[K], kav[K];
             const bool interior = chunk_interior(c);
-            // Fast form for interior chunks whose |theta|, |A| all stay below EXP_FAST_LIM (decided per wave and
-            // chunk from the data alone): 2^tt and 2^ta are then ordinary floats that can multiply the aligned
-            // sum directly -- alpha stays within 2^+-118 before it is renormalised -- so the integer/fraction
-            // split and the two exponent additions drop out of the per-step work.
-            bool fast = false;
-            if constexpr (PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_PREPASS) {
-                if (interior) {
-                    float rng = 0.f;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) rng = __builtin_fmaxf(rng, __builtin_fmaxf(__builtin_fabsf(in0[k]), __builtin_fabsf(in1[k])));
-                    fast = __builtin_amdgcn_ballot_w64(!(rng <= EXP_FAST_LIM)) == 0;
-                }
-                if (fast) {
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        ctv[k] = __builtin_amdgcn_exp2f(in0[k] * 1.44269504088896340736f);
-                        cav[k] = __builtin_amdgcn_exp2f(in1[k] * 1.44269504088896340736f);
-                        ktv[k] = kav[k] = 0;
-                    }
-                } else {
+            auto prepass = [&]() {
+                if constexpr (PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_PREPASS) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         // clamped to +-2^20 bits so that A = -inf (a forbidden gap) behaves like the reference's
@@ -544,16 +576,15 @@ __device__ __forceinline__ void sweep(const Params &p)
                         kav[k] = (int)ka;
                     }
                 }
-            }
+            };
 
             u64 hist[K];  // the edge-facing carry after each step (published below by one lane)
             const int par = c & 1;
             float *lo = lds_out + lane * PO + par * K;  // this lane's row, this chunk's half of the ring
 
             // ---- K steps; EDGE=false is the mask-free body for chunks fully inside the matrix ----
-            auto steps = [&](auto edge_tag, auto fast_tag) {
+            auto steps = [&](auto edge_tag) {
                 constexpr bool EDGE = decltype(edge_tag)::value;
-                constexpr bool FAST = decltype(fast_tag)::value;  // exp-domain forward only, see above
 #pragma unroll
                 for (int kk = 0; kk < K; ++kk) {
                     const int k = REV ? K - 1 - kk : kk;
@@ -562,17 +593,6 @@ __device__ __forceinline__ void sweep(const Params &p)
                     const bool inside = !EDGE || (unsigned)col < (unsigned)m;
                     const bool dead = EDGE && sw && (col == 0 || (i0 + lane) == 0);  // SW: padded row 1 / col 1
                     const bool rowok = !EDGE || lane < rows;
-
-                    // staged-input prefetch placement (SDP_LDPLACE): 0 = burst before the steps, 1 = one
-                    // instruction per step, 2 = two per step over the first half of the chunk
-                    if constexpr (SDP_LDPLACE == 1) {
-                        load_block_k(bb_new, bb_plain, kk);
-                    } else if constexpr (SDP_LDPLACE == 2) {
-                        if (kk < K / 2) {
-                            load_block_k(bb_new, bb_plain, 2 * kk);
-                            load_block_k(bb_new, bb_plain, 2 * kk + 1);
-                        }
-                    }
 
                     float2 q0, q1;
                     if constexpr (T::DIN > 0) {
@@ -597,9 +617,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         const int ue = dpp_i32<DPP_IN>((int)hi32(bcv[k]), cy.xe);
                         float ct, ca;
                         int kai, kti;
-                        if constexpr (FAST) {
-                            ct = ctv[k], ca = cav[k], kai = 0, kti = 0;
-                        } else if constexpr (SDP_PREPASS) {
+                        if constexpr (SDP_PREPASS) {
                             ct = ctv[k], ca = cav[k], kai = kav[k], kti = ktv[k];
                         } else {
                             const float tt = __builtin_amdgcn_fmed3f(in0[k] * 1.44269504088896340736f, -1048576.f, 1048576.f);
@@ -614,7 +632,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         const float u = __builtin_amdgcn_ldexpf(ua, ex - er);
                         const float l = __builtin_amdgcn_ldexpf(cy.xa, ey - er);
                         const float d = __builtin_amdgcn_ldexpf(cy.da, ed - er);
-                        const float ssum = __builtin_fmaf(ca, u + l, d);  // >= 0.5: the largest operand is unshifted
+                        const float ssum = __builtin_fmaf(ca, u + l, d);  // the operand with the largest exponent is unshifted
                         const float tq = ca * __builtin_amdgcn_rcpf(ssum);
                         {
                             float2 qq = make_float2(tq * u, tq * l);
@@ -743,13 +761,105 @@ __device__ __forceinline__ void sweep(const Params &p)
                     }
                 }
             };
-            if constexpr (PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_PREPASS) {
-                if (fast) steps(std::false_type{}, std::true_type{});
-                else if (interior) steps(std::false_type{}, std::false_type{});
-                else steps(std::true_type{}, std::false_type{});
-            } else {
-                if (interior) steps(std::false_type{}, std::false_type{});
-                else steps(std::true_type{}, std::false_type{});
+            // ---- windowed exp-domain forward for interior chunks ----
+            // For the K steps of the chunk every lane keeps its values as plain floats relative to one exponent R
+            // (its "frame": the exponent of its own last value), the neighbour's values arrive scaled by the exact
+            // power of two 2^(R_neighbour - R), and the renormalisation happens once per chunk instead of once per
+            // step: a step is then one DPP move, five multiply/adds, one reciprocal and the range bookkeeping.
+            // All scalings are exact powers of two, so the results are those of the per-step-normalised form up to
+            // how 2^theta is split.  The strip above hands over its K values in one frame too (frame word); lane 0
+            // adopts that frame, so its boundary values need no conversion.
+            // Returns 1 = done, 0 = not applicable here, -1 = a value left the safe range (nothing was committed).
+            auto steps_wf = [&](int &frame) -> int {
+                int fa = 0, fb = 0;
+                if (has_pred) {
+                    fa = __builtin_amdgcn_readfirstlane(frm_in[(t0 + 63) / K]);  // chunk that produced column t0
+                    fb = __builtin_amdgcn_readfirstlane(frm_in[(t0 + 64) / K]);  // ... columns t0+1 .. t0+K-1
+                    if (fa == FRAME_NONE || fb == FRAME_NONE) return 0;
+                }
+                const int R = (has_pred && lane == 0) ? fb : cy.xe;
+                float x = __builtin_amdgcn_ldexpf(cy.xa, cy.xe - R);
+                float d = __builtin_amdgcn_ldexpf(cy.da, cy.de - R);
+                const int Rn = dpp_i32<DPP_IN>(R, R);
+                const float sc = __builtin_amdgcn_ldexpf(1.f, Rn - R);
+                unsigned mx = max(__float_as_uint(x), __float_as_uint(d)), mn = __float_as_uint(x), mc = 0;
+                float bf[K];  // lane 0's `up` values in its frame
+                if (has_pred) {
+                    bf[0] = __builtin_amdgcn_ldexpf(__uint_as_float(lo32(bcv[0])), fa - R);
+#pragma unroll
+                    for (int k = 1; k < K; ++k) bf[k] = __uint_as_float(lo32(bcv[k]));
+                } else {
+                    const float z = __builtin_amdgcn_ldexpf(EXP_ONE_A, EXP_ONE_E - R);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) bf[k] = z;
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float ct = __builtin_amdgcn_exp2f(in0[k] * 1.44269504088896340736f);
+                    const float ca = __builtin_amdgcn_exp2f(in1[k] * 1.44269504088896340736f);
+                    const float ua = __uint_as_float(dpp_i32<DPP_IN>(__float_as_int(bf[k]), __float_as_int(x)));
+                    const float u = ua * sc;
+                    const float ssum = __builtin_fmaf(ca, u + x, d);
+                    const float tq = ca * __builtin_amdgcn_rcpf(ssum);
+                    {
+                        float2 qq = make_float2(tq * u, tq * x);
+                        if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
+                    }
+                    d = u;
+                    x = ct * ssum;
+                    mx = max(max(mx, __float_as_uint(u)), __float_as_uint(x));
+                    mn = min(mn, __float_as_uint(x));
+                    mc = max(max(mc, __float_as_uint(ct)), __float_as_uint(ca));
+                    hist[k] = pack2(__float_as_uint(x), (unsigned)R);
+                }
+                if (__builtin_amdgcn_ballot_w64(mx > WF_HI || mn < WF_LO || mc > WF_FMAX) != 0) return -1;
+                cy.xa = __builtin_amdgcn_frexp_mantf(x);
+                cy.xe = R + __builtin_amdgcn_frexp_expf(x);
+                cy.da = __builtin_amdgcn_frexp_mantf(d);
+                cy.de = R + __builtin_amdgcn_frexp_expf(d);
+                frame = R;
+                return 1;
+            };
+
+            bool wf_done = false;
+            int wf_frame = FRAME_NONE;
+            if constexpr (PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_WF) {
+                if (interior && wf_skip == 0) {
+                    const int rc = steps_wf(wf_frame);
+                    wf_done = rc > 0;
+                    if (rc < 0) wf_skip = 2;  // values move too fast for one frame per chunk here: try again later
+                } else if (wf_skip > 0) {
+                    --wf_skip;
+                }
+            }
+            if (!wf_done) {
+                wf_frame = FRAME_NONE;
+                prepass();
+                if (interior) steps(std::false_type{});
+                else steps(std::true_type{});
+            }
+
+            // The normalised form publishes its K values in one frame as well whenever they fit (exact rescaling
+            // to the exponent of the last one), so that the strip below can use the windowed form regardless of
+            // how this chunk was computed.  Only the publishing lane's values matter.
+            if constexpr (PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_WF) {
+                if (!wf_done && has_succ) {
+                    const int R = (int)hi32(hist[K - 1]);
+                    float av[K];
+                    unsigned mx = 0, mn = ~0u;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        av[k] = __builtin_amdgcn_ldexpf(__uint_as_float(lo32(hist[k])), (int)hi32(hist[k]) - R);
+                        mx = max(mx, __float_as_uint(av[k]));
+                        mn = min(mn, __float_as_uint(av[k]));
+                    }
+                    const bool fits = mx <= WF_HI && mn >= WF_LO;
+                    if ((__builtin_amdgcn_ballot_w64(fits) >> PUB_LANE) & 1ull) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) hist[k] = pack2(__float_as_uint(av[k]), (unsigned)R);
+                        wf_frame = R;
+                    }
+                }
             }
 
             // ---- publish K boundary values for the next strip (one lane, K LDS writes) ----
@@ -777,7 +887,10 @@ __device__ __forceinline__ void sweep(const Params &p)
                 }
                 // LDS executes a wave's DS instructions in order, so the data written above is visible to
                 // any wave that observes this word (the asm statements also stop compiler reordering)
-                if (lane == PUB_LANE) lds_store_i32(prog + 4 * oslot, obase + done);
+                if constexpr (PASS == PASS_FWD && KIND == CK_EXP) {
+                    if (lane == PUB_LANE) frm_out[c] = wf_frame;
+                }
+                if (lane == PUB_LANE) lds_store_i32(prog + 4 * oword, obase + done);
             }
 
             // ---- flush: one K-column aligned block per row (see fo_* above) ----

@@ -5,10 +5,10 @@ on, and checks their invariants exhaustively -- these are the formulas a future 
 
   1. the (strip, step, lane) -> cell schedule visits every cell exactly once and respects the DP
      dependencies (predecessors are older steps of the same lane / the lane above / the strip above);
-  2. input staging: with blocks of K columns aligned to K, during chunk c row r only ever needs blocks
-     c-q and c-q+1 (q = ceil(r/K)), the ring slot (block & 1) never collides, and the block prefetched for
-     chunk c+1 overwrites a slot that chunk c no longer needs; the per-lane ring read index is
-     (t - lane) mod 2K;
+  2. input staging: row r's K-column blocks start at columns K*j - (r mod 4); during chunk c the row only
+     needs blocks c-q and c-q+1 (q = ceil(4*floor(r/4)/K)); the ring position of column j is
+     (j + r + 4*pi(r mod 8)) mod 2K, so that every dwordx4 lands on an aligned 16-byte slot, lane l reads step
+     t at (t + 4*pi(l mod 8)) mod 2K, and the block prefetched for chunk c+1 only overwrites dead data;
   3. output flush: the aligned K-column blocks written after every chunk cover every cell exactly once,
      and each element is read from the half of the 2-chunk LDS ring the kernel formula says.
 """
@@ -44,37 +44,55 @@ def test_schedule_visits_every_cell_once_in_dependency_order(N, M, K):
     assert (when[:-1, :][~same_strip] == when[1:, :][~same_strip] + 63).all()
 
 
+def ring_pi(x):
+    return ((x & 1) << 2) | (x >> 1)
+
+
 @pytest.mark.parametrize("K", [16, 32])
 @pytest.mark.parametrize("M", [1, 31, 64, 100, 257, 512])
 @pytest.mark.parametrize("rev", [False, True])
 def test_input_ring_holds_exactly_the_needed_blocks(M, K, rev):
+    """Model the staged-input ring literally: lanes load dwordx4 groups of row r's blocks (which start at
+    columns K*j - (r mod 4)), write each group to one aligned 16-byte slot, and lane l reads the K values of a
+    chunk as K/4 aligned 16-byte groups at position (t + 4*pi(l mod 8)) mod 2K.  Check that every value read
+    for a real column is that column, that writes only overwrite dead data, and that all slots are aligned."""
     nchunks = ceil_div(M + 63, K)
+    RING = 2 * K
+    LPR, RPL, NLD = K // 4, 64 // (K // 4), K // 4
     order = range(nchunks - 1, -1, -1) if rev else range(nchunks)
     c_first = nchunks - 1 if rev else 0
-    for r in range(64):
-        q = ceil_div(r, K)
-        ring = {}                                            # slot -> block index
+    ring = np.full((64, RING), -10**9, dtype=np.int64)      # holds the column index stored in each position
 
-        def write(bb):
-            ring[(bb - q) & 1] = bb - q
+    def write_block(bb):
+        flip = (bb & 1) * K
+        for i in range(NLD):
+            for lane in range(64):
+                r4, cg = lane // LPR, lane % LPR
+                r = i * RPL + r4
+                q = ceil_div(r & ~3, K)
+                col0 = K * (bb - q) - (r & 3) + 4 * cg          # li_voff without the row term
+                w = ((4 * cg + K * (q & 1) + (r & ~3) + 4 * ring_pi(r & 7)) & (RING - 1)) ^ flip
+                assert w % 4 == 0                               # one aligned ds_write_b128
+                assert w == (col0 + r + 4 * ring_pi(r & 7)) % RING
+                ring[r, w:w + 4] = np.arange(col0, col0 + 4)
 
-        write(c_first)
-        write(c_first + 1)
-        for c in order:
-            need = {(c * K + k - r) // K for k in range(K)}  # blocks touched by this row during chunk c
-            assert need <= {c - q, c - q + 1}
-            for blk in need:
-                assert ring[blk & 1] == blk, (r, c, blk, ring)
-            for k in range(K):                               # per-lane read index = column mod 2K
-                col = c * K + k - r
-                assert (col % (2 * K)) // K == (col // K) & 1
-            nxt = c - 1 if rev else c + 1
-            if 0 <= nxt < nchunks:
-                bb_new = c - 1 if rev else c + 2
-                victim = ring[(bb_new - q) & 1]
-                nxt_need = {nxt - q, nxt - q + 1}
-                assert victim not in nxt_need                # the overwritten block is dead
-                write(bb_new)
+    write_block(c_first)
+    write_block(c_first + 1)
+    for c in order:
+        t0 = c * K
+        for lane in range(64):
+            pr = (t0 & (RING - 1)) + 4 * ring_pi(lane & 7)
+            for g in range(K // 4):
+                idx = (pr + 4 * g) & (RING - 1)
+                assert idx % 4 == 0                             # one aligned ds_read_b128
+                for e in range(4):
+                    col = t0 + 4 * g + e - lane
+                    if 0 <= col < M:
+                        assert ring[lane, idx + e] == col, (c, lane, g, e)
+        nxt = c - 1 if rev else c + 1
+        if 0 <= nxt < nchunks:
+            write_block(c - 1 if rev else c + 2)
+            # the block just written must not have destroyed anything chunk `nxt` reads (checked when it runs)
 
 
 @pytest.mark.parametrize("K", [16, 32])
