@@ -4,7 +4,7 @@ Mirrors the reference's Function pair (deepblast/nw_cuda.py:168-262, nw.py:315-3
 
     Function.forward(theta, A, operator)            -> Vt            saves (theta, A, state)
     Function.backward(Et)                           -> (E, A, None)  via FunctionBackward.apply
-    FunctionBackward.forward(theta, A, Et, Q, op)   -> (E, A)        saves (state, E)
+    FunctionBackward.forward(theta, A, Et, Q, op)   -> (E, A)        saves (theta, A, E)
     FunctionBackward.backward(Ztheta, ZA)           -> (Ed, None, Vtd, None, None)
 
 and keeps its gradient-flow quirks: the first-order "gradient" returned
@@ -12,7 +12,8 @@ for A is A itself (nw.py:337-339,355); the second-order gradient w.r.t. A is Non
 (nw.py:386); Et may be non-uniform.
 
 Differences that are part of the design, not of the maths: `Q` is an opaque state tensor
-(flat fp32, library-private layout) instead of (B,N+2,M+2,3), and E is produced directly
+(library-private layout, 6 bytes per cell; the second-order path recomputes it at full fp32
+precision) instead of (B,N+2,M+2,3), and E is produced directly
 as (B,N,M) -- the reference's E[:,1:-1,1:-1] -- without materialising the zero border.
 """
 import numpy as np
@@ -41,7 +42,7 @@ def make_functions(variant, prefix, allow_none_operator=False):
         def forward(ctx, theta, A, Et, Q, operator, lens=None):
             eng = _engine.get_engine()
             E = eng.backward(Et.detach(), Q, tuple(theta.shape), variant, lens)
-            ctx.save_for_backward(Q, E)
+            ctx.save_for_backward(theta, A, E)
             ctx.others = (operator, lens)
             # The cotangent of the pass-through A output is all zeros whenever nothing consumes it (the
             # reference materialises it, nw.py:357-383, and feeds the zeros to the adjoint sweep).  Asking
@@ -51,11 +52,16 @@ def make_functions(variant, prefix, allow_none_operator=False):
 
         @staticmethod
         def backward(ctx, Ztheta, ZA):
-            Q, E = ctx.saved_tensors
+            theta, A, E = ctx.saved_tensors
             _, lens = ctx.others
             eng = _engine.get_engine()
             if Ztheta is None:
                 Ztheta = torch.zeros_like(E)
+            # The saved state is the compact one (6 B/cell) the backward sweep reads.  The adjoint sweeps
+            # multiply the weights with directional derivatives of any magnitude and need them at full
+            # fp32 precision, so the second-order path -- rare next to the first-order one -- re-runs
+            # the forward sweep in its exact-state form instead of making every forward pay for it.
+            _, Q = eng.forward(theta.detach(), A.detach(), variant, lens, exact_state=True)
             Vtd, Qd = eng.adjoint_forward(Q, Ztheta, ZA, variant, lens)
             Ed = eng.adjoint_backward(E, Q, Qd, variant, lens)
             return Ed, None, Vtd, None, None, None

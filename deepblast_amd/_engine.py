@@ -27,6 +27,9 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+EXACT_STATE = 0x100  # include/sdp.h: SDP_EXACT_STATE
+
+
 class HipEngine:
     """Thin veneer over libsdp_hip.so.  All tensors must be fp32, contiguous, on one ROCm device."""
 
@@ -57,8 +60,9 @@ class HipEngine:
     def max_cols(self):
         return self.lib.sdp_max_cols()
 
-    def new_state(self, B, N, M, device):
-        nbytes = self.lib.sdp_state_bytes(B, N, M)
+    def new_state(self, B, N, M, device, derivative=False):
+        """Opaque buffer for Q (6 bytes per cell) or, with derivative=True, for Qd (float2 per cell)."""
+        nbytes = (self.lib.sdp_state_d_bytes if derivative else self.lib.sdp_state_bytes)(B, N, M)
         return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
 
     @staticmethod
@@ -71,13 +75,18 @@ class HipEngine:
         return lens
 
     # ---- the four passes -----------------------------------------------------------
-    def forward(self, theta, A, variant, lens=None):
-        """-> (Vt (B,), state).  Replaces _forward_pass_kernel (nw_cuda.py:74-79)."""
+    def forward(self, theta, A, variant, lens=None, exact_state=False):
+        """-> (Vt (B,), state).  Replaces _forward_pass_kernel (nw_cuda.py:74-79).
+
+        exact_state=False: the compact state the backward sweep reads; True: Q as float2, which the two
+        adjoint sweeps need (include/sdp.h, SDP_EXACT_STATE)."""
         dev = self._dev(theta)
         theta, A = theta.contiguous(), A.contiguous()
         B, N, M = theta.shape
         lens = self._lens(lens, B, theta.device)
-        state = self.new_state(B, N, M, theta.device)
+        state = self.new_state(B, N, M, theta.device, derivative=exact_state)
+        if exact_state:
+            variant = variant | EXACT_STATE
         Vt = torch.empty(B, dtype=torch.float32, device=theta.device)
         with torch.cuda.device(dev), self._bracket("sdp_fwd_kernel"):
             rc = self.lib.sdp_forward_f32(_ptr(theta), _ptr(A), _ptr(state), _ptr(Vt), B, N, M, _ptr(lens),
@@ -106,7 +115,7 @@ class HipEngine:
         if ZA is not None:
             ZA = ZA.to(torch.float32).contiguous()
         lens = self._lens(lens, B, state.device)
-        state_d = self.new_state(B, N, M, state.device)
+        state_d = self.new_state(B, N, M, state.device, derivative=True)
         Vtd = torch.empty(B, dtype=torch.float32, device=state.device)
         with torch.cuda.device(dev), self._bracket("sdp_adj_fwd_kernel"):
             rc = self.lib.sdp_adjoint_forward_f32(_ptr(state), _ptr(Ztheta), _ptr(ZA), _ptr(Vtd), _ptr(state_d),

@@ -32,7 +32,7 @@ struct Variant {
 };
 
 // kernel builds: [0] fwd, [1] bwd (throughput: K=32, <= 4 waves), [2] adj-fwd, [3] adj-bwd,
-// [4] bwd (latency: K=16, <= 8 waves)
+// [4] bwd (latency: K=16, <= 8 waves), [5] fwd writing the exact (float2) state for the adjoint sweeps
 Variant variant(int id)
 {
     switch (id) {
@@ -40,6 +40,7 @@ Variant variant(int id)
     case 1: return {(const void *)sdp_bwd_kernel, SDP_K_BWD, SDP_MAXW_BWD, 1};
     case 2: return {(const void *)sdp_adj_fwd_kernel, SDP_K_AFWD, SDP_MAXW_AFWD, 2};
     case 3: return {(const void *)sdp_adj_bwd_kernel, SDP_K_ABWD, SDP_MAXW_ABWD, 3};
+    case 5: return {(const void *)sdp_fwd_x_kernel, SDP_K_FWD, SDP_MAXW_FWD, 5};
     default: return {(const void *)sdp_bwd_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 4};
     }
 }
@@ -72,7 +73,7 @@ int check_shape(int B, int N, int M, int variant)
     return 0;
 }
 
-int launch(int pass, sdp::Params &p, int device, void *stream)
+int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state = false)
 {
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
@@ -86,7 +87,7 @@ int launch(int pass, sdp::Params &p, int device, void *stream)
     // wave per SIMD; a smaller batch is bound by the length of the strip pipeline of a single pair, which
     // more waves (and the shorter-chunk build of the backward sweep) shorten.
     const bool full = p.B * 4 >= num_cus(device) * 3;
-    Variant v = variant(pass);
+    Variant v = variant(pass == sdp::PASS_FWD && exact_state ? 5 : pass);
     int W = g_waves[pass];
     if (W <= 0) W = (pass == sdp::PASS_FWD || pass == sdp::PASS_BWD) ? (full ? 4 : 8) : SDP_DEFAULT_WAVES;
     if (pass == sdp::PASS_BWD) {
@@ -104,7 +105,7 @@ int launch(int pass, sdp::Params &p, int device, void *stream)
     p.stage_off = (int)off;
     // raise the dynamic-LDS limit once per (thread, device, kernel) -- it is sticky, and the value is the
     // 160 KiB the hardware has, so concurrent callers cannot disagree
-    static thread_local unsigned long long lds_raised[5] = {0, 0, 0, 0, 0};  // bit d = done on device d
+    static thread_local unsigned long long lds_raised[6] = {0, 0, 0, 0, 0, 0};  // bit d = done on device d
     if (device >= 64 || !(lds_raised[v.id] >> device & 1ull)) {
         e = hipFuncSetAttribute(v.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -129,6 +130,12 @@ int sdp_max_cols(void) { return sdp::MAX_COLS; }
 size_t sdp_state_bytes(int B, int N, int M)
 {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
+    return (size_t)B * sdp::state_nstrips(N) * sdp::state_tpad(M) * 64 * 6;  // 2 x 23 bits per cell, 3 dwords per 2 cells
+}
+
+size_t sdp_state_d_bytes(int B, int N, int M)
+{
+    if (B <= 0 || N <= 0 || M <= 0) return 0;
     return (size_t)B * sdp::state_nstrips(N) * sdp::state_tpad(M) * 64 * sizeof(float2);
 }
 
@@ -149,15 +156,17 @@ int sdp_forward_f32(const float *theta, const float *A, float *state, float *Vt,
                     const int32_t *lens, int variant, int device, void *stream)
 {
     if (!theta || !A || !state || !Vt) return fail(SDP_E_NULLPTR, "sdp_forward_f32: null pointer");
+    const bool exact = (variant & SDP_EXACT_STATE) != 0;
+    variant &= ~SDP_EXACT_STATE;
     if (int rc = check_shape(B, N, M, variant)) return rc;
     sdp::Params p = {};
     p.sin0 = theta;
     p.sin1 = A;
-    p.dout = reinterpret_cast<float2 *>(state);
+    p.dout = state;
     p.vout = Vt;
     p.lens = lens;
     p.B = B, p.N = N, p.M = M, p.variant = variant;
-    return launch(sdp::PASS_FWD, p, device, stream);
+    return launch(sdp::PASS_FWD, p, device, stream, exact);
 }
 
 int sdp_backward_f32(const float *Et, const float *state, float *E, int B, int N, int M, const int32_t *lens,
@@ -172,7 +181,7 @@ int sdp_backward_f32(const float *Et, const float *state, float *E, int B, int N
     }
     sdp::Params p = {};
     p.vin = Et;
-    p.din0 = reinterpret_cast<const float2 *>(state);
+    p.qin = reinterpret_cast<const uint32_t *>(state);
     p.sout = E;
     p.lens = lens;
     p.B = B, p.N = N, p.M = M, p.variant = variant;
@@ -185,10 +194,10 @@ int sdp_adjoint_forward_f32(const float *state, const float *Ztheta, const float
     if (!state || !Ztheta || !Vtd || !state_d) return fail(SDP_E_NULLPTR, "sdp_adjoint_forward_f32: null pointer");
     if (int rc = check_shape(B, N, M, variant)) return rc;
     sdp::Params p = {};
-    p.din0 = reinterpret_cast<const float2 *>(state);
+    p.qin = reinterpret_cast<const uint32_t *>(state);
     p.sin0 = Ztheta;
     p.sin1 = ZA;
-    p.dout = reinterpret_cast<float2 *>(state_d);
+    p.dout = state_d;
     p.vout = Vtd;
     p.lens = lens;
     p.B = B, p.N = N, p.M = M, p.variant = variant;
@@ -207,8 +216,8 @@ int sdp_adjoint_backward_f32(const float *E, const float *state, const float *st
     }
     sdp::Params p = {};
     p.sin0 = E;
-    p.din0 = reinterpret_cast<const float2 *>(state);
-    p.din1 = reinterpret_cast<const float2 *>(state_d);
+    p.qin = reinterpret_cast<const uint32_t *>(state);
+    p.din = reinterpret_cast<const float2 *>(state_d);
     p.sout = Ed;
     p.lens = lens;
     p.B = B, p.N = N, p.M = M, p.variant = variant;

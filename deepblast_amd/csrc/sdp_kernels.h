@@ -66,9 +66,9 @@ struct Params {
     const float *sin0;   // staged (row-major) input plane 0: theta | Ztheta | E
     const float *sin1;   // staged input plane 1: A | ZA (may be null = zeros)
     float *sout;         // staged (row-major) output: E | Ed
-    const float2 *din0;  // skewed state in: Q
-    const float2 *din1;  // skewed state in: Qd
-    float2 *dout;        // skewed state out: Q | Qd
+    const uint32_t *qin; // skewed state in: Q, packed (backward sweep) or float2 (adjoint sweeps)
+    const float2 *din;   // skewed state in: Qd
+    void *dout;          // skewed state out: Q (packed | float2) | Qd (float2)
     const float *vin;    // Et
     float *vout;         // Vt | Vtd
     const int32_t *lens; // (B,2) or null
@@ -98,6 +98,7 @@ __host__ __device__ inline int state_tpad(int M) { return (M + 63 + 63) / 64 * 6
 
 extern "C" {
 __global__ void sdp_fwd_kernel(const sdp::Params p);
+__global__ void sdp_fwd_x_kernel(const sdp::Params p);
 __global__ void sdp_bwd_kernel(const sdp::Params p);
 __global__ void sdp_bwd_lat_kernel(const sdp::Params p);
 __global__ void sdp_adj_fwd_kernel(const sdp::Params p);

@@ -128,28 +128,72 @@ __device__ __forceinline__ void keep(X &x)
 // ----------------------------------------------------------------------------------
 // pass descriptions
 // ----------------------------------------------------------------------------------
-template <int PASS>
+// Q formats: the forward sweep writes the weights either compact (Q_PACKED, read by the backward sweep) or as
+// float2 (Q_EXACT, read by the two adjoint sweeps, whose products with the -- possibly large -- directional
+// derivatives need the relative precision of fp32 for small weights as well).
+enum { Q_NONE = 0, Q_PACKED = 1, Q_EXACT = 2 };
+
+template <int PASS, bool QX>
 struct Traits;
-template <>
-struct Traits<PASS_FWD> {  // nw.py:46-62
-    static constexpr int SIN = 2, SOUT = 0, DIN = 0, DOUT = 1;
+template <bool QX>
+struct Traits<PASS_FWD, QX> {  // nw.py:46-62
+    static constexpr int SIN = 2, SOUT = 0;
+    static constexpr int QIN = Q_NONE, QOUT = QX ? Q_EXACT : Q_PACKED;
+    static constexpr bool DIN = false, DOUT = false;
     static constexpr bool REV = false;
 };
-template <>
-struct Traits<PASS_BWD> {  // nw.py:120-135
-    static constexpr int SIN = 0, SOUT = 1, DIN = 1, DOUT = 0;
+template <bool QX>
+struct Traits<PASS_BWD, QX> {  // nw.py:120-135
+    static constexpr int SIN = 0, SOUT = 1;
+    static constexpr int QIN = Q_PACKED, QOUT = Q_NONE;
+    static constexpr bool DIN = false, DOUT = false;
     static constexpr bool REV = true;
 };
-template <>
-struct Traits<PASS_AFWD> {  // nw.py:178-199
-    static constexpr int SIN = 2, SOUT = 0, DIN = 1, DOUT = 1;
+template <bool QX>
+struct Traits<PASS_AFWD, QX> {  // nw.py:178-199
+    static constexpr int SIN = 2, SOUT = 0;
+    static constexpr int QIN = Q_EXACT, QOUT = Q_NONE;
+    static constexpr bool DIN = false, DOUT = true;
     static constexpr bool REV = false;
 };
-template <>
-struct Traits<PASS_ABWD> {  // nw.py:251-267
-    static constexpr int SIN = 1, SOUT = 1, DIN = 2, DOUT = 0;
+template <bool QX>
+struct Traits<PASS_ABWD, QX> {  // nw.py:251-267
+    static constexpr int SIN = 1, SOUT = 1;
+    static constexpr int QIN = Q_EXACT, QOUT = Q_NONE;
+    static constexpr bool DIN = true, DOUT = false;
     static constexpr bool REV = true;
 };
+
+// The saved softmax weights Q (qx, qy; qm = 1 - qx - qy) are kept as two 24-bit fields per cell: the low three
+// bytes of the float f = 1 + q*(1 - 2^-20), i.e. q on a grid of 2^-23 (absolute error <= 2^-24, the precision
+// fp32 itself has for weights in [0.5, 1)); the factor keeps f below 2 for any q <= 1 + 9e-7 -- a weight computed
+// as c/sum*u can exceed 1 by a few ulp -- so no clamp is needed, and the reader undoes it (Q_UNSCALE).  Two cells -- four fields -- fill three dwords: the state costs
+// 6 bytes per cell instead of 8, one dwordx3 access per lane moves two steps, and byte permutes do the packing.
+// (Two unorm16 per cell would halve the state, but their rounding error accumulates along an alignment path like
+// a random walk and passes 1e-4 on E for peaked inputs and for sequences beyond ~1000 residues.)  This format
+// feeds the backward sweep only; see Q_EXACT above.  The derivative state Qd is signed and unbounded and stays
+// float2.
+constexpr float Q_SCALE = 0.99999904632568359375f;   // 1 - 2^-20
+constexpr float Q_UNSCALE = 1.00000095367522590f;     // 1 / (1 - 2^-20)
+// group w[0..2] = bytes x0.0 x0.1 x0.2 y0.0 | y0.1 y0.2 x1.0 x1.1 | x1.2 y1.0 y1.1 y1.2
+__device__ __forceinline__ void q_pack2(float2 a, float2 b, unsigned *w)
+{
+    const unsigned x0 = __float_as_uint(__builtin_fmaf(a.x, Q_SCALE, 1.0f)), y0 = __float_as_uint(__builtin_fmaf(a.y, Q_SCALE, 1.0f));
+    const unsigned x1 = __float_as_uint(__builtin_fmaf(b.x, Q_SCALE, 1.0f)), y1 = __float_as_uint(__builtin_fmaf(b.y, Q_SCALE, 1.0f));
+    w[0] = __builtin_amdgcn_perm(y0, x0, 0x04020100u);
+    w[1] = __builtin_amdgcn_perm(x1, y0, 0x05040201u);
+    w[2] = __builtin_amdgcn_perm(y1, x1, 0x06050402u);
+}
+__device__ __forceinline__ float q_field(unsigned u)  // field in the low 23 bits of u, anything above -> f - 1
+{
+    return __uint_as_float((u & 0x7fffffu) | 0x3f800000u) - 1.0f;
+}
+// (f - 1) of both weights of a cell; the caller multiplies by Q_UNSCALE (or folds it into another factor)
+__device__ __forceinline__ float2 q_unpack(const unsigned *w, int second)
+{
+    if (second) return make_float2(q_field(__builtin_amdgcn_perm(w[2], w[1], 0x0c040302u)), q_field(w[2] >> 8));
+    return make_float2(q_field(w[0]), q_field(__builtin_amdgcn_perm(w[1], w[0], 0x0c050403u)));
+}
 
 // ----------------------------------------------------------------------------------
 // carries
@@ -232,10 +276,10 @@ struct Carry {
 // ----------------------------------------------------------------------------------
 // the sweep
 // ----------------------------------------------------------------------------------
-template <int PASS, int K>
+template <int PASS, int K, bool QX = false>
 __device__ __forceinline__ void sweep(const Params &p)
 {
-    using T = Traits<PASS>;
+    using T = Traits<PASS, QX>;
     constexpr bool REV = T::REV;
     constexpr int KIND = Kind<PASS>::value;
     constexpr int RPI = 64 / K;    // tensor rows covered by one staged (dword) store instruction
@@ -248,7 +292,6 @@ __device__ __forceinline__ void sweep(const Params &p)
     constexpr int QMAX = (63 + K - 1) / K;  // largest ceil(r/K) over the 64 rows of a strip
     constexpr int PO = stage_out_pitch(K);  // LDS pitch of the staged output ring: two chunks per row + 1
     constexpr int NSTAGE = T::SIN + T::SOUT;
-    constexpr int ND = T::DIN > 0 ? T::DIN : 1;
     constexpr int NS = T::SIN > 0 ? T::SIN : 1;
     constexpr int PUB_LANE = REV ? 0 : 63;    // lane that produces this strip's boundary row
     constexpr int DPP_IN = REV ? DPP_WAVE_SHL1 : DPP_WAVE_SHR1;  // pull from the lane that owns the previous row
@@ -338,29 +381,71 @@ __device__ __forceinline__ void sweep(const Params &p)
         // skewed state addressing: one buffer descriptor per (pair, strip); a row (one step) is 64 x float2
         // = 512 B, so step t, lane l lives at byte t*512 + l*8.  Step offsets go through the scalar
         // offset operand, the lane offset is a per-lane constant.
+        // element offset of this (pair, strip) in a state buffer; one step is a row of 64 lanes
         const size_t st_base = (b_st * p.nstrips_max + s) * p.tpad * 64;
+        // Q: 6 bytes per cell, two steps per lane and access: steps 2j, 2j+1 of lane l are the 12 bytes at
+        // j*768 + l*12, so one dwordx3 per lane moves two steps (768 B per wave access).
+        const unsigned q_bytes = (unsigned)p.tpad * 384u, q_lane = lane * 12;
+        __amdgpu_buffer_rsrc_t rs_q = make_rsrc(T::QIN == Q_PACKED ? (const void *)(p.qin + st_base * 3 / 2)
+                                                : (T::QOUT == Q_PACKED ? (const void *)(static_cast<uint32_t *>(p.dout) + st_base * 3 / 2) : (const void *)p.vout),
+                                                (T::QIN == Q_PACKED || T::QOUT == Q_PACKED) ? q_bytes : 0u);
+        typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+        auto load_q = [&](int t_base, int g, unsigned *dst) {  // steps t_base + 2g, + 1
+            const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs_q, q_lane + (g & 3) * 768, (t_base / 2 + (g & ~3)) * 768, AUX_ST_LOAD);
+            const unsigned v0 = v[0], v1 = v[1], v2 = v[2];
+            dst[0] = v0, dst[1] = v1, dst[2] = v2;
+        };
+        auto store_q = [&](int t_base, int g, const unsigned *src) {
+            u32x3 v;
+            v[0] = src[0], v[1] = src[1], v[2] = src[2];
+            __builtin_amdgcn_raw_buffer_store_b96(v, rs_q, q_lane + (g & 3) * 768, (t_base / 2 + (g & ~3)) * 768, AUX_ST_STORE);
+            // A VALU instruction that overwrites a data register of a store wider than 64 bits in the very next
+            // issue slot corrupts the stored value for part of the wave on gfx950 (seen: lanes 12-15 of every
+            // 16).  The compiler only inserts the wait state for stores without a scalar offset register, so it
+            // is forced here: the no-op "reads" the data registers (nothing that overwrites them can move above
+            // it) and is ordered after the store as a memory operation.
+            asm volatile("s_nop 1" : : "v"(v) : "memory");
+        };
+        // float2 states (Qd, and Q in its exact form): one step is a 512-byte row: step t, lane l lives at byte
+        // t*512 + l*8.  Step offsets go through the scalar offset operand, the lane offset is a per-lane constant.
         const unsigned st_bytes = (unsigned)p.tpad * 512u;
         const unsigned st_lane = lane * 8;
-        __amdgpu_buffer_rsrc_t rs_din[ND];
-        if constexpr (T::DIN > 0) {
-            rs_din[0] = make_rsrc(p.din0 + st_base, st_bytes);
-            if constexpr (T::DIN > 1) rs_din[1] = make_rsrc(p.din1 + st_base, st_bytes);
-        }
-        __amdgpu_buffer_rsrc_t rs_dout = make_rsrc(T::DOUT ? (const void *)(p.dout + st_base) : (const void *)p.vout,
-                                                   T::DOUT ? st_bytes : 0u);
-        auto load_state = [&](int q, int t_base, int k) {  // row t_base + k
-            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_din[q], st_lane + (k & 7) * 512, (t_base + (k & ~7)) * 512, AUX_ST_LOAD);
+        __amdgpu_buffer_rsrc_t rs_d = make_rsrc(T::DIN ? (const void *)(p.din + st_base)
+                                                       : (T::DOUT ? (const void *)(static_cast<float2 *>(p.dout) + st_base) : (const void *)p.vout),
+                                                (T::DIN || T::DOUT) ? st_bytes : 0u);
+        __amdgpu_buffer_rsrc_t rs_qx = make_rsrc(T::QIN == Q_EXACT ? (const void *)(reinterpret_cast<const float2 *>(p.qin) + st_base)
+                                                 : (T::QOUT == Q_EXACT ? (const void *)(static_cast<float2 *>(p.dout) + st_base) : (const void *)p.vout),
+                                                 (T::QIN == Q_EXACT || T::QOUT == Q_EXACT) ? st_bytes : 0u);
+        auto load_f2 = [&](__amdgpu_buffer_rsrc_t rs, int t_base, int k) {  // row t_base + k
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, st_lane + (k & 7) * 512, (t_base + (k & ~7)) * 512, AUX_ST_LOAD);
             // NB: copy the elements to scalars first -- __builtin_bit_cast applied directly to a vector
             // element lvalue (v[1]) reads element 0 with this compiler.
             const unsigned lo = v[0], hi = v[1];
             return make_float2(__uint_as_float(lo), __uint_as_float(hi));
         };
-        auto store_state = [&](int t_base, int k, float2 qq) {
+        auto store_f2 = [&](__amdgpu_buffer_rsrc_t rs, int t_base, int k, float2 qq) {
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             u32x2 v;
             v[0] = __float_as_uint(qq.x);
             v[1] = __float_as_uint(qq.y);
-            __builtin_amdgcn_raw_buffer_store_b64(v, rs_dout, st_lane + (k & 7) * 512, (t_base + (k & ~7)) * 512, AUX_ST_STORE);
+            __builtin_amdgcn_raw_buffer_store_b64(v, rs, st_lane + (k & 7) * 512, (t_base + (k & ~7)) * 512, AUX_ST_STORE);
+        };
+        auto load_d = [&](int t_base, int k) { return load_f2(rs_d, t_base, k); };
+        float2 qhold;  // forward: weights of the even step of the current pair of steps
+        auto store_state = [&](int t_base, int k, float2 qq) {  // the state this pass produces, step t_base + k
+            if constexpr (T::QOUT == Q_PACKED) {
+                if ((k & 1) == 0) {
+                    qhold = qq;
+                } else {
+                    unsigned w[3];
+                    q_pack2(qhold, qq, w);
+                    store_q(t_base, k >> 1, w);
+                }
+            } else if constexpr (T::QOUT == Q_EXACT) {
+                store_f2(rs_qx, t_base, k, qq);
+            } else {
+                store_f2(rs_d, t_base, k, qq);
+            }
         };
 
         Carry cy;
@@ -371,8 +456,10 @@ __device__ __forceinline__ void sweep(const Params &p)
         u64 vt_keep = edge_zero<KIND>();  // fwd passes: terminal cell's value, captured when this lane reaches it
 
         float rs[NS][K];   // staged inputs of the NEXT chunk (registers)
-        float2 rd[ND][K];  // skewed state rows: slot k holds step t0+k of the current chunk and is
-                           // refilled with the same slot of the next chunk right after it is consumed
+        unsigned rq[3 * K / 2];  // packed Q of the current chunk, three dwords per pair of steps; a pair is refilled
+                                 // with the same steps of the next chunk as soon as both have been consumed
+        float2 rqx[K];     // exact Q rows / Qd rows: slot k holds step t0+k and is refilled right after it is consumed
+        float2 rdd[K];
 
         // Staged INPUT geometry.  Row-major tensors enter as K-column blocks, four columns (one dwordx4) per
         // lane; row r's blocks start at columns K*j - (r mod 4).  During chunk c (steps cK .. cK+K-1) row r needs
@@ -467,14 +554,29 @@ __device__ __forceinline__ void sweep(const Params &p)
         const int dir = REV ? -1 : 1;
 
         // ---- prologue ----
-        if constexpr (T::DIN > 0) {
+        if constexpr (T::QIN == Q_EXACT) {
 #pragma unroll
-            for (int k = 0; k < K; ++k)
+            for (int k = 0; k < K; ++k) {
+                if constexpr (ABL_NOLOAD) rqx[k] = make_float2(0.25f + 1e-3f * k, 0.5f - 1e-3f * lane);
+                else rqx[k] = load_f2(rs_qx, c_first * K, k);
+            }
+        }
+        if constexpr (T::QIN == Q_PACKED) {
 #pragma unroll
-                for (int q = 0; q < T::DIN; ++q) {
-                    if constexpr (ABL_NOLOAD) rd[q][k] = make_float2(0.25f + 1e-3f * k, 0.5f - 1e-3f * lane);
-                    else rd[q][k] = load_state(q, c_first * K, k);
+            for (int g = 0; g < K / 2; ++g) {
+                if constexpr (ABL_NOLOAD) {
+                    for (int j = 0; j < 3; ++j) rq[3 * g + j] = 0x20003000u + 64 * g + lane;
+                } else {
+                    load_q(c_first * K, g, rq + 3 * g);
                 }
+            }
+        }
+        if constexpr (T::DIN) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if constexpr (ABL_NOLOAD) rdd[k] = make_float2(0.25f + 1e-3f * k, 0.5f - 1e-3f * lane);
+                else rdd[k] = load_d(c_first * K, k);
+            }
         }
         load_block(c_first);
         write_block(c_first);
@@ -595,21 +697,28 @@ __device__ __forceinline__ void sweep(const Params &p)
                     const bool rowok = !EDGE || lane < rows;
 
                     float2 q0, q1;
-                    if constexpr (T::DIN > 0) {
-                        q0 = rd[0][k];
-                        if constexpr (T::DIN > 1) q1 = rd[1][k];
-                        if constexpr (!ABL_NOLOAD) {  // refill the slot with the same step of the next chunk
-                            rd[0][k] = load_state(0, t0_next, k);
-                            if constexpr (T::DIN > 1) rd[1][k] = load_state(1, t0_next, k);
+                    if constexpr (T::QIN == Q_EXACT) {
+                        q0 = rqx[k];
+                        if constexpr (!ABL_NOLOAD) rqx[k] = load_f2(rs_qx, t0_next, k);
+                    }
+                    if constexpr (T::QIN == Q_PACKED) {
+                        q0 = q_unpack(rq + 3 * (k >> 1), k & 1);
+                        q0.x *= Q_UNSCALE, q0.y *= Q_UNSCALE;
+                        if constexpr (!ABL_NOLOAD) {
+                            if ((k & 1) == (REV ? 0 : 1)) load_q(t0_next, k >> 1, rq + 3 * (k >> 1));
                         }
+                    }
+                    if constexpr (T::DIN) {
+                        q1 = rdd[k];
+                        if constexpr (!ABL_NOLOAD) rdd[k] = load_d(t0_next, k);
                     }
 
                     if constexpr (ABL_NOMATH) {
-                        if constexpr (T::DOUT > 0) {
-                            float2 qq = make_float2(in0[k], T::DIN > 0 ? q0.x + q0.y : in1[k]);
+                        if constexpr (T::QOUT != Q_NONE || T::DOUT) {
+                            float2 qq = make_float2(in0[k], T::QIN != Q_NONE ? q0.x + q0.y : in1[k]);
                             if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
                         }
-                        if constexpr (T::SOUT > 0) lo[k] = q0.x + q0.y + (T::DIN > 1 ? q1.x + q1.y : 0.f) + (T::SIN > 0 ? in0[k] : 0.f);
+                        if constexpr (T::SOUT > 0) lo[k] = q0.x + q0.y + (T::DIN ? q1.x + q1.y : 0.f) + (T::SIN > 0 ? in0[k] : 0.f);
                         hist[k] = 0;
                     } else if constexpr (PASS == PASS_FWD && KIND == CK_EXP) {
                         // scaled exp-domain forward (see CK_EXP above)
@@ -703,7 +812,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                             e = live ? e : 0.f;
                         }
                         const float qx = live ? q0.x : 0.f, qy = live ? q0.y : 0.f;
-                        const float qm = (1.f - qx) - qy;
+                        const float qm = __builtin_fmaxf((1.f - qx) - qy, 0.f);  // the two stored weights are rounded independently
                         cy.fb = qy * e;
                         cy.fa = __builtin_fmaf(qx, e, cy.fc);  // px + pm of the previous step
                         cy.fc = qm * e;
@@ -718,7 +827,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                             e = live ? e : 0.0;
                         }
                         const double qx = live ? (double)q0.x : 0.0, qy = live ? (double)q0.y : 0.0;
-                        const double qm = (1.0 - qx) - qy;
+                        const double qm = fmax((1.0 - qx) - qy, 0.0);  // the two stored weights are rounded independently
                         cy.b = qy * e;
                         cy.a = __builtin_fma(qx, e, cy.c);  // px + pm of the previous step
                         cy.c = qm * e;
@@ -945,13 +1054,14 @@ __device__ __forceinline__ void sweep(const Params &p)
 // ----------------------------------------------------------------------------------
 // kernels (one symbol per pass so that rocprofv3 names them)
 // ----------------------------------------------------------------------------------
-#define SDP_KERNEL(NAME, PASS, K, MAXW)                                                    \
+#define SDP_KERNEL(NAME, PASS, K, MAXW, ...)                                               \
     extern "C" __global__ void __launch_bounds__((MAXW) * 64) NAME(const sdp::Params p)    \
     {                                                                                      \
-        sdp::sweep<PASS, K>(p);                                                            \
+        sdp::sweep<PASS, K, ##__VA_ARGS__>(p);                                             \
     }
 
 SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD)
+SDP_KERNEL(sdp_fwd_x_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true)
 SDP_KERNEL(sdp_bwd_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD)
 SDP_KERNEL(sdp_bwd_lat_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT)
 SDP_KERNEL(sdp_adj_fwd_kernel, sdp::PASS_AFWD, SDP_K_AFWD, SDP_MAXW_AFWD)

@@ -14,7 +14,8 @@
  *                                deepblast/nw_cuda.py:134-139,258
  *   sdp_adjoint_backward_f32  <- _adjoint_backward_pass_kernel[tpb,bpg](E, Q, Qd, Ed)
  *                                deepblast/nw_cuda.py:160-165,259
- *   sdp_state_bytes           <- torch.zeros((B, N+2, M+2, 3)) for Q / Qd
+ *   sdp_state_bytes,
+ *   sdp_state_d_bytes         <- torch.zeros((B, N+2, M+2, 3)) for Q / Qd
  *                                deepblast/nw_cuda.py:180-182,250-252
  *
  * Conventions
@@ -24,9 +25,15 @@
  *   - theta, A, ZA, Ztheta, E, Ed are (B, N, M).  E/Ed are written in full
  *     (the reference's (B,N+2,M+2) zero border is not materialised; its interior
  *     [:,1:-1,1:-1] is exactly this array).
- *   - `state` / `state_d` are opaque buffers of sdp_state_bytes(B,N,M) bytes that
- *     stand in for the reference's Q / Qd tensors.  Their layout is private
- *     (wavefront-skewed); only this library reads them.
+ *   - `state` / `state_d` are opaque buffers of sdp_state_bytes(B,N,M) /
+ *     sdp_state_d_bytes(B,N,M) bytes that stand in for the reference's Q / Qd
+ *     tensors.  Their layout is private (wavefront-skewed); only
+ *     this library reads them.  For the backward sweep Q is kept as two 23-bit
+ *     fixed-point weights per cell (absolute error <= 2^-24 per weight, 6 bytes
+ *     per cell).  The adjoint sweeps (second order) multiply the weights with
+ *     directional derivatives of any size and need them at full fp32 precision:
+ *     run sdp_forward_f32 with SDP_EXACT_STATE for them (float2 per cell, the
+ *     size of Qd).
  *   - `lens` is NULL (reference semantics: every pair uses the full padded N x M)
  *     or a DEVICE pointer to B x 2 int32 (n_b, m_b): pair b is aligned over its
  *     top-left n_b x m_b block, terminal cell (n_b, m_b); E/Ed outside the block
@@ -53,6 +60,10 @@ extern "C" {
 
 #define SDP_NW 0
 #define SDP_SW 1
+/* or-ed into `variant` of sdp_forward_f32: `state` (then sdp_state_d_bytes large) receives Q at full fp32
+ * precision.  The two adjoint entry points require a state produced this way; sdp_backward_f32 requires the
+ * default (compact) one. */
+#define SDP_EXACT_STATE 0x100
 
 #define SDP_E_NULLPTR (-1)  /* a required pointer is NULL */
 #define SDP_E_SHAPE (-2)    /* B, N or M non-positive */
@@ -69,8 +80,9 @@ const char *sdp_last_error_string(void);
 /* Largest M accepted (the reference's GPU path stops at 2047 columns). */
 int sdp_max_cols(void);
 
-/* Bytes of one opaque state buffer (Q or Qd) for a (B,N,M) problem; 0 on bad shape. */
+/* Bytes of the opaque buffers that hold Q (`state`) and Qd (`state_d`) for a (B,N,M) problem; 0 on bad shape. */
 size_t sdp_state_bytes(int B, int N, int M);
+size_t sdp_state_d_bytes(int B, int N, int M);
 
 /* Vt[b] = V[n_b, m_b]; state <- softmax weights of every cell. */
 int sdp_forward_f32(const float *theta, const float *A, float *state, float *Vt, int B, int N,
@@ -80,12 +92,14 @@ int sdp_forward_f32(const float *theta, const float *A, float *state, float *Vt,
 int sdp_backward_f32(const float *Et, const float *state, float *E, int B, int N, int M,
                      const int32_t *lens, int variant, int device, void *stream);
 
-/* Directional derivative through the DP: Vtd (B,), state_d <- Qd.  ZA may be NULL (= zeros). */
+/* Directional derivative through the DP: Vtd (B,), state_d <- Qd.  ZA may be NULL (= zeros).
+ * `state` must come from sdp_forward_f32(..., variant | SDP_EXACT_STATE, ...). */
 int sdp_adjoint_forward_f32(const float *state, const float *Ztheta, const float *ZA, float *Vtd,
                             float *state_d, int B, int N, int M, const int32_t *lens, int variant,
                             int device, void *stream);
 
-/* Ed = reverse sweep of the derivative (Hessian-vector product w.r.t. theta). */
+/* Ed = reverse sweep of the derivative (Hessian-vector product w.r.t. theta); `state` as for the adjoint
+ * forward sweep (exact). */
 int sdp_adjoint_backward_f32(const float *E, const float *state, const float *state_d, float *Ed,
                              int B, int N, int M, const int32_t *lens, int variant, int device,
                              void *stream);

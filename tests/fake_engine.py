@@ -26,7 +26,7 @@ class OracleEngine:
         lens = np.asarray(lens.cpu() if isinstance(lens, torch.Tensor) else lens)
         return [(int(lens[b, 0]), int(lens[b, 1])) for b in range(B)]
 
-    def forward(self, theta, A, variant, lens=None):
+    def forward(self, theta, A, variant, lens=None, exact_state=False):
         th, a = self._np(theta), self._np(A)
         B, N, M = th.shape
         Vt = np.zeros(B, np.float32)
@@ -73,8 +73,11 @@ class OracleEngine:
     def adjoint_backward(self, E, state, state_d, variant, lens=None):
         B, N, M = E.shape
         Ed = np.zeros((B, N, M), np.float32)
-        for b, (q, qd, e) in enumerate(zip(state._oracle_Q, state_d._oracle_Qd, state._oracle_E)):
+        En = self._np(E)
+        for b, (q, qd) in enumerate(zip(state._oracle_Q, state_d._oracle_Qd)):
             n, m = q.shape[1] - 2, q.shape[2] - 2
+            e = np.zeros((1, n + 2, m + 2), np.float32)   # the reference's E carries a zero border
+            e[0, 1:-1, 1:-1] = En[b, :n, :m]
             ed = oracle.adjoint_backward(e, q, qd)
             Ed[b, :n, :m] = ed[0, 1:-1, 1:-1]
         return torch.from_numpy(Ed)

@@ -163,9 +163,10 @@ def main():
 
             tf = timeit(lambda: eng.forward(t, a, 0))
             tb = timeit(lambda: eng.backward(et, Q, (B, N, M), 0))
-            Vtd, Qd = eng.adjoint_forward(Q, z, None, 0)
-            taf = timeit(lambda: eng.adjoint_forward(Q, z, None, 0))
-            tab = timeit(lambda: eng.adjoint_backward(E, Q, Qd, 0))
+            _, Qx = eng.forward(t, a, 0, exact_state=True)
+            Vtd, Qd = eng.adjoint_forward(Qx, z, None, 0)
+            taf = timeit(lambda: eng.adjoint_forward(Qx, z, None, 0))
+            tab = timeit(lambda: eng.adjoint_backward(E, Qx, Qd, 0))
             cells = B * N * M
             print(f"timing B={B} N={N} M={M}: fwd {tf:.3f} ms  bwd {tb:.3f} ms  adj_fwd {taf:.3f} ms  adj_bwd {tab:.3f} ms")
             print(f"  fwd+bwd {tf + tb:.3f} ms -> {2 * cells / ((tf + tb) * 1e-3):.3e} cell-updates/s ; "

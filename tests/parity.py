@@ -79,8 +79,9 @@ def engine_all(theta, A, Et, Z, variant, lens=None, ZA=None, device="cuda"):
     if Z is not None:
         z = torch.from_numpy(np.ascontiguousarray(Z)).to(device)
         za = None if ZA is None else torch.from_numpy(np.ascontiguousarray(ZA)).to(device)
-        Vtd, Qd = eng.adjoint_forward(Q, z, za, variant, ln)
-        Ed = eng.adjoint_backward(E, Q, Qd, variant, ln)
+        _, Qx = eng.forward(t, a, variant, ln, exact_state=True)  # the adjoint sweeps read the exact state
+        Vtd, Qd = eng.adjoint_forward(Qx, z, za, variant, ln)
+        Ed = eng.adjoint_backward(E, Qx, Qd, variant, ln)
         out["Ed"], out["Vtd"] = Ed.cpu().numpy(), Vtd.cpu().numpy()
     torch.cuda.synchronize()
     return out

@@ -37,10 +37,12 @@ def test_version_and_limits(lib):
 
 
 def test_state_bytes(lib):
-    # strips of 64 rows x roundup(M+63, 64) steps x 64 lanes x float2
-    assert lib.sdp_state_bytes(256, 512, 512) == 256 * 8 * 576 * 64 * 8
-    assert lib.sdp_state_bytes(1, 1, 1) == 1 * 1 * 64 * 64 * 8
-    assert lib.sdp_state_bytes(3, 65, 2) == 3 * 2 * 128 * 64 * 8
+    # Q: 6 B (two 23-bit weights) per cell of the skewed layout; Qd: float2 per cell
+    assert lib.sdp_state_bytes(256, 512, 512) == 256 * 8 * 576 * 64 * 6
+    assert lib.sdp_state_bytes(1, 1, 1) == 1 * 1 * 64 * 64 * 6
+    assert lib.sdp_state_bytes(3, 65, 2) == 3 * 2 * 128 * 64 * 6
+    assert lib.sdp_state_d_bytes(256, 512, 512) == 256 * 8 * 576 * 64 * 8
+    assert lib.sdp_state_d_bytes(0, 5, 5) == 0
     assert lib.sdp_state_bytes(0, 5, 5) == 0
 
 

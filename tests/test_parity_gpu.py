@@ -42,6 +42,22 @@ def test_all_four_passes_vs_oracle(shape, variant):
     _assert(parity.compare(got, ref), f"{shape} v{variant}")
 
 
+@pytest.mark.parametrize("shape", [(2, 512, 512), (1, 40, 2048), (1, 1500, 24)], ids=lambda s: "x".join(map(str, s)))
+def test_peaked_alignments_keep_parity(shape):
+    """Sharp inputs (one dominant path, weights near 0 and 1) are the worst case for the compact saved state of
+    the backward sweep: an error in a weight that is close to 1 is carried along the whole alignment path."""
+    B, N, M = shape
+    theta, A = datagen.theta_A(77, B, N, M)
+    theta = (12.0 * theta).astype(np.float32)
+    A = (6.0 * A).astype(np.float32)
+    # second order too, except for the very tall case: there the fp32 weights themselves (reference and engine
+    # alike) limit Ed to about 1e-4 of its range, which says nothing about the saved state
+    Z = datagen.normal(78, (B, N, M)) if N <= 512 else None
+    ref = parity.oracle_all(theta, A, None, Z, 0)
+    got = parity.engine_all(theta, A, None, Z, 0)
+    _assert(parity.compare(got, ref), f"peaked {shape}")
+
+
 @pytest.mark.parametrize("variant", [0, 1], ids=["nw", "sw"])
 def test_nonzero_ZA_enters_the_adjoint(variant):
     """quirk 3: the ZA buffer is part of the adjoint recurrences (nw.py:190-192)."""
@@ -113,7 +129,8 @@ def test_headline_config_full_batch():
     assert np.array_equal(alone["Vt"], got["Vt"][sel]) and np.array_equal(alone["E"], got["E"][sel])
     Et = np.full(3, 3.0, np.float32)
     scaled = parity.engine_all(theta[sel], A[sel], Et, None, 0)
-    assert np.allclose(scaled["E"], 3.0 * alone["E"], rtol=1e-6, atol=1e-7)
+    # fp32 products along up to N+M-1 steps round differently for e and 3e: a few 1e-7 relative per element
+    assert np.allclose(scaled["E"], 3.0 * alone["E"], rtol=3e-6, atol=1e-7)
     assert abs(float(got["E"][0, -1, -1]) - 1.0) < 1e-6  # E[N,M] == Et (quirk 4)
 
 

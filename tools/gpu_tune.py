@@ -19,7 +19,10 @@ from deepblast_amd import _lib  # noqa: E402
 def load(path):
     lib = ctypes.CDLL(path)
     for name, (res, args) in _lib.SIGNATURES.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:  # an older build kept for comparison
+            continue
         fn.restype, fn.argtypes = res, args
     return lib
 
@@ -43,7 +46,8 @@ def run(lib, B, N, M, waves=(0, 0, 0, 0), passes="fb"):
     t = torch.from_numpy(np.tile(th, (reps, 1, 1))[:B]).cuda()
     a = torch.from_numpy(np.tile(A, (reps, 1, 1))[:B]).cuda()
     st = torch.empty(lib.sdp_state_bytes(B, N, M) // 4, device="cuda")
-    std = torch.empty_like(st) if "a" in passes else None
+    dbytes = lib.sdp_state_d_bytes(B, N, M) if hasattr(lib, "sdp_state_d_bytes") else lib.sdp_state_bytes(B, N, M)
+    std = torch.empty(dbytes // 4, device="cuda") if "a" in passes else None
     vt = torch.empty(B, device="cuda")
     et = torch.ones(B, device="cuda")
     E = torch.empty(B, N, M, device="cuda")
@@ -60,8 +64,14 @@ def run(lib, B, N, M, waves=(0, 0, 0, 0), passes="fb"):
     out["bwd"] = timeit(b)
     out["fwd;bwd"] = timeit(lambda: (f(), b()))
     if "a" in passes:
-        af = lambda: lib.sdp_adjoint_forward_f32(st.data_ptr(), z.data_ptr(), None, vt.data_ptr(), std.data_ptr(), B, N, M, None, 0, 0, stream)
-        ab = lambda: lib.sdp_adjoint_backward_f32(E.data_ptr(), st.data_ptr(), std.data_ptr(), Ed.data_ptr(), B, N, M, None, 0, 0, stream)
+        stx = torch.empty(dbytes // 4, device="cuda")  # exact state for the adjoint sweeps
+        if hasattr(lib, "sdp_state_d_bytes"):
+            assert lib.sdp_forward_f32(t.data_ptr(), a.data_ptr(), stx.data_ptr(), vt.data_ptr(), B, N, M, None, 0x100, 0, stream) == 0
+            out["fwd_x"] = timeit(lambda: lib.sdp_forward_f32(t.data_ptr(), a.data_ptr(), stx.data_ptr(), vt.data_ptr(), B, N, M, None, 0x100, 0, stream))
+        else:
+            stx = st
+        af = lambda: lib.sdp_adjoint_forward_f32(stx.data_ptr(), z.data_ptr(), None, vt.data_ptr(), std.data_ptr(), B, N, M, None, 0, 0, stream)
+        ab = lambda: lib.sdp_adjoint_backward_f32(E.data_ptr(), stx.data_ptr(), std.data_ptr(), Ed.data_ptr(), B, N, M, None, 0, 0, stream)
         out["afwd"] = timeit(af)
         out["abwd"] = timeit(ab)
     return out
