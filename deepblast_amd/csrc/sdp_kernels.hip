@@ -870,7 +870,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                     }
                 }
             };
-            // ---- windowed exp-domain forward for interior chunks ----
+            // ---- windowed exp-domain forward ----
             // For the K steps of the chunk every lane keeps its values as plain floats relative to one exponent R
             // (its "frame": the exponent of its own last value), the neighbour's values arrive scaled by the exact
             // power of two 2^(R_neighbour - R), and the renormalisation happens once per chunk instead of once per
@@ -878,29 +878,49 @@ __device__ __forceinline__ void sweep(const Params &p)
             // All scalings are exact powers of two, so the results are those of the per-step-normalised form up to
             // how 2^theta is split.  The strip above hands over its K values in one frame too (frame word); lane 0
             // adopts that frame, so its boundary values need no conversion.
+            // EDGE chunks (the ramps of a strip, the Smith-Waterman border): a cell that is not live yet -- its
+            // column is still left of the matrix -- holds V = 0, i.e. 2^(1-R) * 0.5 in its lane's frame, and lanes
+            // that have not started take the frame of the last lane that has.  Cells right of the matrix or below
+            // it compute values nobody reads, exactly as in the normalised form.
             // Returns 1 = done, 0 = not applicable here, -1 = a value left the safe range (nothing was committed).
-            auto steps_wf = [&](int &frame) -> int {
+            auto steps_wf = [&](auto edge_tag, int &frame) -> int {
+                constexpr bool EDGE = decltype(edge_tag)::value;
+                const bool use_pred = has_pred && t0 < m;          // lane 0 meets real boundary values in this chunk
                 int fa = 0, fb = 0;
-                if (has_pred) {
-                    fa = __builtin_amdgcn_readfirstlane(frm_in[(t0 + 63) / K]);  // chunk that produced column t0
-                    fb = __builtin_amdgcn_readfirstlane(frm_in[(t0 + 64) / K]);  // ... columns t0+1 .. t0+K-1
+                if (use_pred) {
+                    fa = __builtin_amdgcn_readfirstlane(frm_in[(t0 + 63) / K]);                   // chunk that produced column t0
+                    fb = t0 + 1 < m ? __builtin_amdgcn_readfirstlane(frm_in[(t0 + 64) / K]) : fa;  // ... columns t0+1 .. t0+K-1
                     if (fa == FRAME_NONE || fb == FRAME_NONE) return 0;
                 }
-                const int R = (has_pred && lane == 0) ? fb : cy.xe;
+                int R = cy.xe;
+                int thr = 0;  // EDGE: the lane's cell is live at step t iff t >= thr
+                if constexpr (EDGE) {
+                    thr = lane + (sw ? 1 : 0);
+                    if (sw && i0 + lane == 0) thr = 0x7fffffff;  // padded row 1 of Smith-Waterman never is
+                }
+                if (use_pred && lane == 0) R = fb;
+                if constexpr (EDGE) {
+                    const int nstarted = t0 - (sw ? 1 : 0);  // lanes below this were live at step t0 - 1
+                    if (nstarted < 64) {  // the others take the frame of the last started lane (or of the boundary)
+                        const int rref = nstarted > 0 ? __builtin_amdgcn_readlane(R, nstarted - 1) : (use_pred ? fb : EXP_ONE_E);
+                        R = lane < nstarted ? R : rref;
+                    }
+                }
                 float x = __builtin_amdgcn_ldexpf(cy.xa, cy.xe - R);
                 float d = __builtin_amdgcn_ldexpf(cy.da, cy.de - R);
+                const float xz = __builtin_amdgcn_ldexpf(EXP_ONE_A, EXP_ONE_E - R);  // V = 0 in this frame
                 const int Rn = dpp_i32<DPP_IN>(R, R);
                 const float sc = __builtin_amdgcn_ldexpf(1.f, Rn - R);
-                unsigned mx = max(__float_as_uint(x), __float_as_uint(d)), mn = __float_as_uint(x), mc = 0;
+                unsigned mx = max(__float_as_uint(x), __float_as_uint(d)), mn = 0x3f800000u, mc = 0;
+                if (!EDGE || t0 > thr) mn = __float_as_uint(x);  // a value that is not live yet may be arbitrarily small
                 float bf[K];  // lane 0's `up` values in its frame
-                if (has_pred) {
+                if (use_pred) {
                     bf[0] = __builtin_amdgcn_ldexpf(__uint_as_float(lo32(bcv[0])), fa - R);
 #pragma unroll
                     for (int k = 1; k < K; ++k) bf[k] = __uint_as_float(lo32(bcv[k]));
                 } else {
-                    const float z = __builtin_amdgcn_ldexpf(EXP_ONE_A, EXP_ONE_E - R);
 #pragma unroll
-                    for (int k = 0; k < K; ++k) bf[k] = z;
+                    for (int k = 0; k < K; ++k) bf[k] = xz;
                 }
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
@@ -916,8 +936,14 @@ __device__ __forceinline__ void sweep(const Params &p)
                     }
                     d = u;
                     x = ct * ssum;
+                    if constexpr (EDGE) {
+                        const bool live = t0 + k >= thr;
+                        x = live ? x : xz;
+                        mn = min(mn, live ? __float_as_uint(x) : 0x3f800000u);
+                    } else {
+                        mn = min(mn, __float_as_uint(x));
+                    }
                     mx = max(max(mx, __float_as_uint(u)), __float_as_uint(x));
-                    mn = min(mn, __float_as_uint(x));
                     mc = max(max(mc, __float_as_uint(ct)), __float_as_uint(ca));
                     hist[k] = pack2(__float_as_uint(x), (unsigned)R);
                 }
@@ -926,6 +952,15 @@ __device__ __forceinline__ void sweep(const Params &p)
                 cy.xe = R + __builtin_amdgcn_frexp_expf(x);
                 cy.da = __builtin_amdgcn_frexp_mantf(d);
                 cy.de = R + __builtin_amdgcn_frexp_expf(d);
+                if constexpr (EDGE) {
+                    if (t0 + K - 1 < thr) cy.xa = EXP_ONE_A, cy.xe = EXP_ONE_E;  // still waiting: exactly V = 0
+                    const int tf = m - 1 + rows - 1;  // step at which the last strip meets the terminal cell
+                    if (s == nstrips - 1 && tf >= t0 && tf < t0 + K) {
+                        const int ktf = t_final - t0;  // only that lane has t_final >= 0
+#pragma unroll
+                        for (int k = 0; k < K; ++k) vt_keep = (k == ktf) ? hist[k] : vt_keep;
+                    }
+                }
                 frame = R;
                 return 1;
             };
@@ -933,8 +968,8 @@ __device__ __forceinline__ void sweep(const Params &p)
             bool wf_done = false;
             int wf_frame = FRAME_NONE;
             if constexpr (PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_WF) {
-                if (interior && wf_skip == 0) {
-                    const int rc = steps_wf(wf_frame);
+                if (wf_skip == 0) {
+                    const int rc = interior ? steps_wf(std::false_type{}, wf_frame) : steps_wf(std::true_type{}, wf_frame);
                     wf_done = rc > 0;
                     if (rc < 0) wf_skip = 2;  // values move too fast for one frame per chunk here: try again later
                 } else if (wf_skip > 0) {
