@@ -31,8 +31,9 @@ struct Variant {
     int K, maxw, id;
 };
 
-// kernel builds: [0] fwd, [1] bwd (throughput: K=32, <= 4 waves), [2] adj-fwd, [3] adj-bwd,
-// [4] bwd (latency: K=16, <= 8 waves), [5] fwd writing the exact (float2) state for the adjoint sweeps
+// kernel builds: [0] fwd (throughput: K=32, <= 4 waves), [1] bwd (throughput: K=32, <= 4 waves), [2] adj-fwd,
+// [3] adj-bwd, [4] bwd (latency: K=16, <= 8 waves), [5] fwd writing the exact (float2) state for the adjoint
+// sweeps, [6] fwd (latency: K=16, <= 8 waves)
 Variant variant(int id)
 {
     switch (id) {
@@ -40,7 +41,8 @@ Variant variant(int id)
     case 1: return {(const void *)sdp_bwd_kernel, SDP_K_BWD, SDP_MAXW_BWD, 1};
     case 2: return {(const void *)sdp_adj_fwd_kernel, SDP_K_AFWD, SDP_MAXW_AFWD, 2};
     case 3: return {(const void *)sdp_adj_bwd_kernel, SDP_K_ABWD, SDP_MAXW_ABWD, 3};
-    case 5: return {(const void *)sdp_fwd_x_kernel, SDP_K_FWD, SDP_MAXW_FWD, 5};
+    case 5: return {(const void *)sdp_fwd_x_kernel, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, 5};
+    case 6: return {(const void *)sdp_fwd_lat_kernel, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, 6};
     default: return {(const void *)sdp_bwd_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 4};
     }
 }
@@ -87,14 +89,16 @@ int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state 
     // wave per SIMD; a smaller batch is bound by the length of the strip pipeline of a single pair, which
     // more waves (and the shorter-chunk build of the backward sweep) shorten.
     const bool full = p.B * 4 >= num_cus(device) * 3;
-    Variant v = variant(pass == sdp::PASS_FWD && exact_state ? 5 : pass);
+    Variant v = variant(pass);
     int W = g_waves[pass];
     if (W <= 0) W = (pass == sdp::PASS_FWD || pass == sdp::PASS_BWD) ? (full ? 4 : 8) : SDP_DEFAULT_WAVES;
-    if (pass == sdp::PASS_BWD) {
-        // the throughput build needs 4 waves' worth of LDS; fall back to the latency build when it does not fit
+    if (pass == sdp::PASS_FWD || pass == sdp::PASS_BWD) {
+        // the throughput builds need 4 waves' worth of LDS for their longer chunks; fall back to the latency
+        // builds when that does not fit (long M) or when more waves are wanted
         const int w4 = nstrips < 4 ? nstrips : 4;
-        if (W > SDP_MAXW_BWD || lds_bytes(pass, SDP_K_BWD, w4, p.mcap, nullptr) > 160 * 1024) v = variant(4);
+        if (W > v.maxw || lds_bytes(pass, v.K, w4, p.mcap, nullptr) > 160 * 1024) v = variant(pass == sdp::PASS_FWD ? 6 : 4);
     }
+    if (pass == sdp::PASS_FWD && exact_state) v = variant(5);
     if (W > v.maxw) W = v.maxw;
     if (W > nstrips) W = nstrips;
     size_t off = 0, lds = 0;
@@ -105,7 +109,7 @@ int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state 
     p.stage_off = (int)off;
     // raise the dynamic-LDS limit once per (thread, device, kernel) -- it is sticky, and the value is the
     // 160 KiB the hardware has, so concurrent callers cannot disagree
-    static thread_local unsigned long long lds_raised[6] = {0, 0, 0, 0, 0, 0};  // bit d = done on device d
+    static thread_local unsigned long long lds_raised[7] = {0, 0, 0, 0, 0, 0, 0};  // bit d = done on device d
     if (device >= 64 || !(lds_raised[v.id] >> device & 1ull)) {
         e = hipFuncSetAttribute(v.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");

@@ -11,7 +11,7 @@
 // chunk length K per pass (steps per staged chunk; must divide 64).  K is also the prefetch
 // distance of the skewed state rows, in steps.
 #ifndef SDP_K_FWD
-#define SDP_K_FWD 16
+#define SDP_K_FWD 32
 #endif
 #ifndef SDP_K_BWD
 #define SDP_K_BWD 32
@@ -26,7 +26,15 @@
 // Largest workgroup (in waves) each kernel is compiled for; the VGPR budget per wave is
 // 512 / (waves per SIMD), so 8 waves leave 256 registers, 4 waves the full 512.
 #ifndef SDP_MAXW_FWD
-#define SDP_MAXW_FWD 8
+#define SDP_MAXW_FWD 4
+#endif
+// Second build of the forward sweep (and the one that writes the exact state) for batches that do not fill
+// the GPU: shorter chunks and up to 8 waves shorten the strip pipeline of a single pair.
+#ifndef SDP_K_FWD_LAT
+#define SDP_K_FWD_LAT 16
+#endif
+#ifndef SDP_MAXW_FWD_LAT
+#define SDP_MAXW_FWD_LAT 8
 #endif
 #ifndef SDP_MAXW_BWD
 #define SDP_MAXW_BWD 4
@@ -98,6 +106,7 @@ __host__ __device__ inline int state_tpad(int M) { return (M + 63 + 63) / 64 * 6
 
 extern "C" {
 __global__ void sdp_fwd_kernel(const sdp::Params p);
+__global__ void sdp_fwd_lat_kernel(const sdp::Params p);
 __global__ void sdp_fwd_x_kernel(const sdp::Params p);
 __global__ void sdp_bwd_kernel(const sdp::Params p);
 __global__ void sdp_bwd_lat_kernel(const sdp::Params p);

@@ -659,7 +659,7 @@ __device__ __forceinline__ void sweep(const Params &p)
             // ---- exp-domain forward: everything that does not depend on the recurrence is computed for the
             // whole chunk up front (K independent instruction streams the scheduler can interleave), so that
             // the serial per-step chain below carries only the alignment, one fma and the renormalisation.
-            // theta = (kt + ft) ln2, A = (ka + fa) ln2 with integer kt, ka and ft, fa in [0,1): c* = 2^f* in [1,2)
+            // theta = (kt + ft) ln2, A = (ka + fa) ln2 with integer kt, ka: c* = 2^f* in [0.5,2)
             float ctv[K], cav[K];
             int ktv[K], kav[K];
             const bool interior = chunk_interior(c);
@@ -671,11 +671,17 @@ __device__ __forceinline__ void sweep(const Params &p)
                         // exp(-inf) = 0 instead of producing inf - inf
                         const float tt = __builtin_amdgcn_fmed3f(in0[k] * 1.44269504088896340736f, -1048576.f, 1048576.f);
                         const float ta = __builtin_amdgcn_fmed3f(in1[k] * 1.44269504088896340736f, -1048576.f, 1048576.f);
+                        // Moderate exponents take mantissa and exponent of the SAME 2^tt the windowed form multiplies
+                        // with, so that both forms produce identical bits and a cell's result does not depend on
+                        // which of them a chunk happened to run (the builds cut a strip into different chunks).
+                        const float et = __builtin_amdgcn_exp2f(tt), ea = __builtin_amdgcn_exp2f(ta);
                         const float kt = __builtin_floorf(tt), ka = __builtin_floorf(ta);
-                        ctv[k] = __builtin_amdgcn_exp2f(tt - kt);
-                        cav[k] = __builtin_amdgcn_exp2f(ta - ka);
-                        ktv[k] = (int)kt;
-                        kav[k] = (int)ka;
+                        const float st = __builtin_amdgcn_exp2f(tt - kt), sa = __builtin_amdgcn_exp2f(ta - ka);
+                        const bool mt = __builtin_fabsf(tt) <= 120.f, ma = __builtin_fabsf(ta) <= 120.f;
+                        ctv[k] = mt ? __builtin_amdgcn_frexp_mantf(et) : st;
+                        ktv[k] = mt ? __builtin_amdgcn_frexp_expf(et) : (int)kt;
+                        cav[k] = ma ? __builtin_amdgcn_frexp_mantf(ea) : sa;
+                        kav[k] = ma ? __builtin_amdgcn_frexp_expf(ea) : (int)ka;
                     }
                 }
             };
@@ -1096,7 +1102,8 @@ __device__ __forceinline__ void sweep(const Params &p)
     }
 
 SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD)
-SDP_KERNEL(sdp_fwd_x_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true)
+SDP_KERNEL(sdp_fwd_lat_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT)
+SDP_KERNEL(sdp_fwd_x_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, true)
 SDP_KERNEL(sdp_bwd_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD)
 SDP_KERNEL(sdp_bwd_lat_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT)
 SDP_KERNEL(sdp_adj_fwd_kernel, sdp::PASS_AFWD, SDP_K_AFWD, SDP_MAXW_AFWD)
