@@ -67,7 +67,7 @@ constexpr int max_waves(int pass)
 }
 
 constexpr int MAX_COLS = 2048;     // boundary rows live in LDS (4 x MAX_COLS x 8 B = 64 KiB)
-constexpr int FRAME_CAP = 136;     // frame words per boundary row: >= chunks of a strip at MAX_COLS with K >= 16
+constexpr int FRAME_CAP = 136;     // frame words per boundary row: >= 16-step blocks of a strip at MAX_COLS (+ a chunk)
 constexpr int PROG_STRIDE = 4096;  // > MAX_COLS: progress words are (use index)*PROG_STRIDE + columns
 
 struct Params {

@@ -238,14 +238,18 @@ __device__ __forceinline__ unsigned hi32(u64 x) { return (unsigned)(x >> 32); }
 // to a per-lane exponent ("frame").  After the K steps every value a lane produced must lie in [WF_LO, WF_HI]:
 //   * overflow anywhere in a step gives inf (or NaN), which stays in the lane's value and trips the upper test;
 //   * the factors 2^theta and 2^A of every step must not exceed WF_FMAX = 2^12 (|theta|, |A| <= 8.3; anything
-//     else, including NaN, goes to the normalised form).  Then a value >= WF_LO = 2^-60 proves that the sum it
-//     was made from was a normal float (>= 2^-72), and values <= WF_HI = 2^110 keep every sum below 2^124, so its
+//     else, including NaN, goes to the normalised form).  Then a value >= WF_LO = 2^-100 proves that the sum it
+//     was made from was a normal float (>= 2^-112), and values <= WF_HI = 2^110 keep every sum below 2^124, so its
 //     reciprocal is a normal float too.  A = -inf (2^A = 0) is fine.
 // A chunk that fails a test is redone in the per-step-normalised form; nothing was committed before the test.
 // WF_HI also leaves room for the consumers of published values (value * 2^A * 2 + ... stays below 2^128).
+// Values mostly grow along a row (fastest in the lower left corner of the matrix, ~5 bits per step), so a lane's
+// frame is placed WF_BIAS bits above the exponent of its current value: it starts the chunk at 2^-40.
 constexpr unsigned WF_HI = 0x76800000u;  // 2^110
-constexpr unsigned WF_LO = 0x21800000u;  // 2^-60
+constexpr unsigned WF_LO = 0x0d800000u;  // 2^-100
 constexpr unsigned WF_FMAX = 0x45800000u;  // 2^12
+constexpr int WF_BIAS = 40;
+constexpr int WB = 16;  // steps per frame (every chunk length is a multiple)
 constexpr int FRAME_NONE = (int)0x80000000;  // published chunk is not in one frame (per-value exponents apply)
 constexpr float EXP_ONE_A = 0.5f;
 constexpr int EXP_ONE_E = 1;
@@ -889,77 +893,92 @@ __device__ __forceinline__ void sweep(const Params &p)
             // that have not started take the frame of the last lane that has.  Cells right of the matrix or below
             // it compute values nobody reads, exactly as in the normalised form.
             // Returns 1 = done, 0 = not applicable here, -1 = a value left the safe range (nothing was committed).
-            auto steps_wf = [&](auto edge_tag, int &frame) -> int {
+            auto steps_wf = [&](auto edge_tag, int *frames) -> int {
                 constexpr bool EDGE = decltype(edge_tag)::value;
-                const bool use_pred = has_pred && t0 < m;          // lane 0 meets real boundary values in this chunk
-                int fa = 0, fb = 0;
-                if (use_pred) {
-                    fa = __builtin_amdgcn_readfirstlane(frm_in[(t0 + 63) / K]);                   // chunk that produced column t0
-                    fb = t0 + 1 < m ? __builtin_amdgcn_readfirstlane(frm_in[(t0 + 64) / K]) : fa;  // ... columns t0+1 .. t0+K-1
-                    if (fa == FRAME_NONE || fb == FRAME_NONE) return 0;
-                }
-                int R = cy.xe;
-                int thr = 0;  // EDGE: the lane's cell is live at step t iff t >= thr
+                const Carry saved = cy;  // a later block of the chunk may fail after earlier ones were committed
+                int thr = 0;             // EDGE: the lane's cell is live at step t iff t >= thr
                 if constexpr (EDGE) {
                     thr = lane + (sw ? 1 : 0);
                     if (sw && i0 + lane == 0) thr = 0x7fffffff;  // padded row 1 of Smith-Waterman never is
                 }
-                if (use_pred && lane == 0) R = fb;
-                if constexpr (EDGE) {
-                    const int nstarted = t0 - (sw ? 1 : 0);  // lanes below this were live at step t0 - 1
-                    if (nstarted < 64) {  // the others take the frame of the last started lane (or of the boundary)
-                        const int rref = nstarted > 0 ? __builtin_amdgcn_readlane(R, nstarted - 1) : (use_pred ? fb : EXP_ONE_E);
-                        R = lane < nstarted ? R : rref;
+#pragma unroll
+                for (int sb = 0; sb < K / WB; ++sb) {  // one frame per block of WB steps, whatever the chunk length
+                    const int tb = t0 + sb * WB;
+                    const bool use_pred = has_pred && tb < m;  // lane 0 meets real boundary values in this block
+                    int fa = 0, fb = 0;
+                    if (use_pred) {
+                        fa = __builtin_amdgcn_readfirstlane(frm_in[(tb + 63) / WB]);                   // block that produced column tb
+                        fb = tb + 1 < m ? __builtin_amdgcn_readfirstlane(frm_in[(tb + 64) / WB]) : fa;  // ... columns tb+1 .. tb+WB-1
+                        if (fa == FRAME_NONE || fb == FRAME_NONE) {
+                            cy = saved;
+                            return 0;
+                        }
                     }
-                }
-                float x = __builtin_amdgcn_ldexpf(cy.xa, cy.xe - R);
-                float d = __builtin_amdgcn_ldexpf(cy.da, cy.de - R);
-                const float xz = __builtin_amdgcn_ldexpf(EXP_ONE_A, EXP_ONE_E - R);  // V = 0 in this frame
-                const int Rn = dpp_i32<DPP_IN>(R, R);
-                const float sc = __builtin_amdgcn_ldexpf(1.f, Rn - R);
-                unsigned mx = max(__float_as_uint(x), __float_as_uint(d)), mn = 0x3f800000u, mc = 0;
-                if (!EDGE || t0 > thr) mn = __float_as_uint(x);  // a value that is not live yet may be arbitrarily small
-                float bf[K];  // lane 0's `up` values in its frame
-                if (use_pred) {
-                    bf[0] = __builtin_amdgcn_ldexpf(__uint_as_float(lo32(bcv[0])), fa - R);
-#pragma unroll
-                    for (int k = 1; k < K; ++k) bf[k] = __uint_as_float(lo32(bcv[k]));
-                } else {
-#pragma unroll
-                    for (int k = 0; k < K; ++k) bf[k] = xz;
-                }
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const float ct = __builtin_amdgcn_exp2f(in0[k] * 1.44269504088896340736f);
-                    const float ca = __builtin_amdgcn_exp2f(in1[k] * 1.44269504088896340736f);
-                    const float ua = __uint_as_float(dpp_i32<DPP_IN>(__float_as_int(bf[k]), __float_as_int(x)));
-                    const float u = ua * sc;
-                    const float ssum = __builtin_fmaf(ca, u + x, d);
-                    const float tq = ca * __builtin_amdgcn_rcpf(ssum);
-                    {
-                        float2 qq = make_float2(tq * u, tq * x);
-                        if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
-                    }
-                    d = u;
-                    x = ct * ssum;
+                    int R = cy.xe + WF_BIAS;
+                    if (use_pred && lane == 0) R = fb;
                     if constexpr (EDGE) {
-                        const bool live = t0 + k >= thr;
-                        x = live ? x : xz;
-                        mn = min(mn, live ? __float_as_uint(x) : 0x3f800000u);
-                    } else {
-                        mn = min(mn, __float_as_uint(x));
+                        const int nstarted = tb - (sw ? 1 : 0);  // lanes below this were live at step tb - 1
+                        if (nstarted < 64) {  // the others take the frame of the last started lane (or of the boundary)
+                            const int rref = nstarted > 0 ? __builtin_amdgcn_readlane(R, nstarted - 1) : (use_pred ? fb : EXP_ONE_E + WF_BIAS);
+                            R = lane < nstarted ? R : rref;
+                        }
                     }
-                    mx = max(max(mx, __float_as_uint(u)), __float_as_uint(x));
-                    mc = max(max(mc, __float_as_uint(ct)), __float_as_uint(ca));
-                    hist[k] = pack2(__float_as_uint(x), (unsigned)R);
+                    float x = __builtin_amdgcn_ldexpf(cy.xa, cy.xe - R);
+                    float d = __builtin_amdgcn_ldexpf(cy.da, cy.de - R);
+                    const float xz = __builtin_amdgcn_ldexpf(EXP_ONE_A, EXP_ONE_E - R);  // V = 0 in this frame
+                    const int Rn = dpp_i32<DPP_IN>(R, R);
+                    const float sc = __builtin_amdgcn_ldexpf(1.f, Rn - R);
+                    unsigned mx = max(__float_as_uint(x), __float_as_uint(d)), mn = 0x3f800000u, mc = 0;
+                    if (!EDGE || tb > thr) mn = __float_as_uint(x);  // a value that is not live yet may be arbitrarily small
+                    float bf[WB];  // lane 0's `up` values in its frame
+                    if (use_pred) {
+                        bf[0] = __builtin_amdgcn_ldexpf(__uint_as_float(lo32(bcv[sb * WB])), fa - R);
+#pragma unroll
+                        for (int j = 1; j < WB; ++j) bf[j] = __uint_as_float(lo32(bcv[sb * WB + j]));
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < WB; ++j) bf[j] = xz;
+                    }
+#pragma unroll
+                    for (int j = 0; j < WB; ++j) {
+                        const int k = sb * WB + j;
+                        const float ct = __builtin_amdgcn_exp2f(in0[k] * 1.44269504088896340736f);
+                        const float ca = __builtin_amdgcn_exp2f(in1[k] * 1.44269504088896340736f);
+                        const float ua = __uint_as_float(dpp_i32<DPP_IN>(__float_as_int(bf[j]), __float_as_int(x)));
+                        const float u = ua * sc;
+                        const float ssum = __builtin_fmaf(ca, u + x, d);
+                        const float tq = ca * __builtin_amdgcn_rcpf(ssum);
+                        {
+                            float2 qq = make_float2(tq * u, tq * x);
+                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
+                        }
+                        d = u;
+                        x = ct * ssum;
+                        if constexpr (EDGE) {
+                            const bool live = t0 + k >= thr;
+                            x = live ? x : xz;
+                            mn = min(mn, live ? __float_as_uint(x) : 0x3f800000u);
+                        } else {
+                            mn = min(mn, __float_as_uint(x));
+                        }
+                        mx = max(max(mx, __float_as_uint(u)), __float_as_uint(x));
+                        mc = max(max(mc, __float_as_uint(ct)), __float_as_uint(ca));
+                        hist[k] = pack2(__float_as_uint(x), (unsigned)R);
+                    }
+                    if (__builtin_amdgcn_ballot_w64(mx > WF_HI || mn < WF_LO || mc > WF_FMAX) != 0) {
+                        cy = saved;
+                        return -1;
+                    }
+                    cy.xa = __builtin_amdgcn_frexp_mantf(x);
+                    cy.xe = R + __builtin_amdgcn_frexp_expf(x);
+                    cy.da = __builtin_amdgcn_frexp_mantf(d);
+                    cy.de = R + __builtin_amdgcn_frexp_expf(d);
+                    if constexpr (EDGE) {
+                        if (tb + WB - 1 < thr) cy.xa = EXP_ONE_A, cy.xe = EXP_ONE_E;  // still waiting: exactly V = 0
+                    }
+                    frames[sb] = R;
                 }
-                if (__builtin_amdgcn_ballot_w64(mx > WF_HI || mn < WF_LO || mc > WF_FMAX) != 0) return -1;
-                cy.xa = __builtin_amdgcn_frexp_mantf(x);
-                cy.xe = R + __builtin_amdgcn_frexp_expf(x);
-                cy.da = __builtin_amdgcn_frexp_mantf(d);
-                cy.de = R + __builtin_amdgcn_frexp_expf(d);
                 if constexpr (EDGE) {
-                    if (t0 + K - 1 < thr) cy.xa = EXP_ONE_A, cy.xe = EXP_ONE_E;  // still waiting: exactly V = 0
                     const int tf = m - 1 + rows - 1;  // step at which the last strip meets the terminal cell
                     if (s == nstrips - 1 && tf >= t0 && tf < t0 + K) {
                         const int ktf = t_final - t0;  // only that lane has t_final >= 0
@@ -967,47 +986,53 @@ __device__ __forceinline__ void sweep(const Params &p)
                         for (int k = 0; k < K; ++k) vt_keep = (k == ktf) ? hist[k] : vt_keep;
                     }
                 }
-                frame = R;
                 return 1;
             };
 
             bool wf_done = false;
-            int wf_frame = FRAME_NONE;
+            int wf_frames[K / WB];
+#pragma unroll
+            for (int sb = 0; sb < K / WB; ++sb) wf_frames[sb] = FRAME_NONE;
             if constexpr (PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_WF) {
                 if (wf_skip == 0) {
-                    const int rc = interior ? steps_wf(std::false_type{}, wf_frame) : steps_wf(std::true_type{}, wf_frame);
+                    const int rc = interior ? steps_wf(std::false_type{}, wf_frames) : steps_wf(std::true_type{}, wf_frames);
                     wf_done = rc > 0;
-                    if (rc < 0) wf_skip = 2;  // values move too fast for one frame per chunk here: try again later
+                    if (rc < 0) wf_skip = 1;  // values move too fast for one frame per block here: try again later
                 } else if (wf_skip > 0) {
                     --wf_skip;
                 }
             }
             if (!wf_done) {
-                wf_frame = FRAME_NONE;
+#pragma unroll
+                for (int sb = 0; sb < K / WB; ++sb) wf_frames[sb] = FRAME_NONE;
                 prepass();
                 if (interior) steps(std::false_type{});
                 else steps(std::true_type{});
             }
 
-            // The normalised form publishes its K values in one frame as well whenever they fit (exact rescaling
-            // to the exponent of the last one), so that the strip below can use the windowed form regardless of
-            // how this chunk was computed.  Only the publishing lane's values matter.
+            // The normalised form publishes its values in one frame per block as well whenever they fit (exact
+            // rescaling to the exponent of the block's last value), so that the strip below can use the windowed
+            // form regardless of how this chunk was computed.  Only the publishing lane's values matter.
             if constexpr (PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_WF) {
                 if (!wf_done && has_succ) {
-                    const int R = (int)hi32(hist[K - 1]);
-                    float av[K];
-                    unsigned mx = 0, mn = ~0u;
 #pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        av[k] = __builtin_amdgcn_ldexpf(__uint_as_float(lo32(hist[k])), (int)hi32(hist[k]) - R);
-                        mx = max(mx, __float_as_uint(av[k]));
-                        mn = min(mn, __float_as_uint(av[k]));
-                    }
-                    const bool fits = mx <= WF_HI && mn >= WF_LO;
-                    if ((__builtin_amdgcn_ballot_w64(fits) >> PUB_LANE) & 1ull) {
+                    for (int sb = 0; sb < K / WB; ++sb) {
+                        const int R = (int)hi32(hist[sb * WB + WB - 1]);
+                        float av[WB];
+                        unsigned mx = 0, mn = ~0u;
 #pragma unroll
-                        for (int k = 0; k < K; ++k) hist[k] = pack2(__float_as_uint(av[k]), (unsigned)R);
-                        wf_frame = R;
+                        for (int j = 0; j < WB; ++j) {
+                            const int k = sb * WB + j;
+                            av[j] = __builtin_amdgcn_ldexpf(__uint_as_float(lo32(hist[k])), (int)hi32(hist[k]) - R);
+                            mx = max(mx, __float_as_uint(av[j]));
+                            mn = min(mn, __float_as_uint(av[j]));
+                        }
+                        const bool fits = mx <= WF_HI && mn >= WF_LO;
+                        if ((__builtin_amdgcn_ballot_w64(fits) >> PUB_LANE) & 1ull) {
+#pragma unroll
+                            for (int j = 0; j < WB; ++j) hist[sb * WB + j] = pack2(__float_as_uint(av[j]), (unsigned)R);
+                            wf_frames[sb] = R;
+                        }
                     }
                 }
             }
@@ -1038,7 +1063,10 @@ __device__ __forceinline__ void sweep(const Params &p)
                 // LDS executes a wave's DS instructions in order, so the data written above is visible to
                 // any wave that observes this word (the asm statements also stop compiler reordering)
                 if constexpr (PASS == PASS_FWD && KIND == CK_EXP) {
-                    if (lane == PUB_LANE) frm_out[c] = wf_frame;
+                    if (lane == PUB_LANE) {
+#pragma unroll
+                        for (int sb = 0; sb < K / WB; ++sb) frm_out[c * (K / WB) + sb] = wf_frames[sb];
+                    }
                 }
                 if (lane == PUB_LANE) lds_store_i32(prog + 4 * oword, obase + done);
             }
