@@ -379,6 +379,10 @@ __device__ __forceinline__ void sweep(const Params &p)
         // (the terminal cell of the last strip is met at t >= m-1, which interior chunks never contain)
         const bool plain_strip = rows == 64 && !(sw && s == 0);
 
+        // reverse sweeps: this lane's cell is live (inside the matrix, not on the Smith-Waterman border) at step t
+        // iff live_lo <= t < live_lo + live_span
+        const int live_lo = lane + (sw ? 1 : 0);
+        const unsigned live_span = (lane < rows && !(sw && i0 + lane == 0)) ? (unsigned)(m - (sw ? 1 : 0)) : 0u;
         // step at which this lane meets the terminal cell (n-1, m-1) of the pair; -1 if never
         const int t_final = (s == nstrips - 1 && lane == rows - 1) ? (m - 1 + lane) : -1;
 
@@ -815,13 +819,17 @@ __device__ __forceinline__ void sweep(const Params &p)
                         if constexpr (EDGE) vt_keep = (t == t_final) ? hist[k] : vt_keep;
                     } else if constexpr (PASS == PASS_BWD && KIND == CK_F32) {
                         const float in = __uint_as_float(dpp_i32<DPP_IN>((int)lo32(bcv[k]), __float_as_int(cy.fa)));
-                        const bool live = inside && rowok && !dead;
                         float e = in + cy.fb;
                         if constexpr (EDGE) {
+                            // one unsigned compare per step: the lane's cell is real and not a Smith-Waterman
+                            // border cell iff live_lo <= t < live_lo + live_span (see the strip setup)
+                            const bool live = (unsigned)(t - live_lo) < live_span;
                             e = (t == t_final) ? et : e;
                             e = live ? e : 0.f;
                         }
-                        const float qx = live ? q0.x : 0.f, qy = live ? q0.y : 0.f;
+                        // the weights need no masking: the packed fields decode to finite numbers, and a cell that
+                        // is not live hands on e = 0
+                        const float qx = q0.x, qy = q0.y;
                         const float qm = __builtin_fmaxf((1.f - qx) - qy, 0.f);  // the two stored weights are rounded independently
                         cy.fb = qy * e;
                         cy.fa = __builtin_fmaf(qx, e, cy.fc);  // px + pm of the previous step
@@ -1073,19 +1081,22 @@ __device__ __forceinline__ void sweep(const Params &p)
 
             // ---- flush: one K-column aligned block per row (see fo_* above) ----
             if constexpr (T::SOUT > 0) {
-                float vals[K];
-#pragma unroll
-                for (int k = 0; k < K; ++k) vals[k] = lds_out[fo_off0[k] + par * fo_dk[k]];
                 const int ubase = (i0 * ld + t0) * 4;
                 // all K*64 elements are real cells: rows of a full strip, columns t0-K*(64/K-1) .. t0+K-1
                 const bool flush_plain = rows == 64 && t0 >= K * (64 / K - 1) && t0 + K <= m;
                 if (flush_plain) {
+                    float vals[K];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) vals[k] = lds_out[fo_off0[k] + par * fo_dk[k]];
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         if constexpr (ABL_NOSTORE) keep(vals[k]);
                         else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vals[k]), rs_out, fo_voff[k], ubase, AUX_OUT_STORE);
                     }
                 } else {
+                    float vals[K];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) vals[k] = lds_out[fo_off0[k] + par * fo_dk[k]];
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         const int row = k * RPI + r_l;

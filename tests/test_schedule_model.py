@@ -124,3 +124,4 @@ def test_aligned_flush_covers_every_cell_once(N, M, K):
                     assert ring[r, idx] == col, (c, r, e)
                     seen[r, col] += 1
     assert (seen == 1).all()
+
