@@ -68,6 +68,7 @@ class ShardedAligner:
         self.decoder = decoder
         self.group = group
         self.gather = gather
+        self._ones = None
 
     def align(self, theta, A, lengths=None):
         """theta, A: this rank's (B_local, N, M) shard.  Every rank must hold the same B_local
@@ -76,7 +77,11 @@ class ShardedAligner:
         -> dict(Vt_local, E_local, Vt (world*B_local,) or None, E (world*B_local,N,M) or None)."""
         theta = theta.detach().requires_grad_(True)
         Vt = self.decoder(theta, A, lengths) if lengths is not None else self.decoder(theta, A)
-        (E,) = torch.autograd.grad(Vt.sum(), theta)
+        # dVt.sum()/dtheta with the cotangent handed over directly: no reduction kernel and no expand/copy of
+        # its gradient on the way to the backward sweep
+        if self._ones is None or self._ones.shape != Vt.shape or self._ones.device != Vt.device:
+            self._ones = torch.ones_like(Vt)
+        (E,) = torch.autograd.grad(Vt, theta, grad_outputs=self._ones)
         out = {"Vt_local": Vt.detach(), "E_local": E, "Vt": None, "E": None}
         if self.gather != "none" and dist.is_available() and dist.is_initialized():
             out["Vt"] = _all_gather_cat(Vt.detach(), self.group)
