@@ -87,6 +87,12 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #ifndef SDP_PREPASS
 #define SDP_PREPASS 1
 #endif
+#ifndef SDP_LINES
+#define SDP_LINES 1  // throughput forward build: line-aligned input blocks (see "Staged INPUT geometry")
+#endif
+#ifndef SDP_LINES_NT
+#define SDP_LINES_NT 1  // line-aligned input blocks are touched once: stream them past the caches
+#endif
 #ifndef SDP_WF
 #define SDP_WF 1  // forward sweep: try the windowed form on interior chunks
 #endif
@@ -280,7 +286,7 @@ struct Carry {
 // ----------------------------------------------------------------------------------
 // the sweep
 // ----------------------------------------------------------------------------------
-template <int PASS, int K, bool QX = false>
+template <int PASS, int K, bool QX = false, bool LINES = false>
 __device__ __forceinline__ void sweep(const Params &p)
 {
     using T = Traits<PASS, QX>;
@@ -481,15 +487,27 @@ __device__ __forceinline__ void sweep(const Params &p)
         // pi = (0,4,1,5,2,6,3,7) spreads both access patterns over the banks.
         //   li_voff : global byte offset of this lane's 4 columns of block set 0 (row i0)
         //   li_w    : LDS index they are written to when bb is even (odd: the other half, ^K)
+        // LINES = true (throughput builds): the blocks start at multiples of K instead, so that every load moves
+        // whole 128-byte lines (a shifted block straddles two lines, and at one pair per CU the second touch of a
+        // line, one chunk later, no longer hits in L2: fabric reads were 1.8x the tensors' size); the (r mod 4)
+        // rotation then happens on the way into LDS, as four dword writes per loaded dwordx4.
         unsigned li_voff[NLD];
-        int li_w[NLD];
+        int li_w[NLD][LINES ? 4 : 1];
         if constexpr (T::SIN > 0) {
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int r = i * RPL + r4_l;
-                const int q = ((r & ~3) + K - 1) / K;
-                li_voff[i] = (unsigned)((r * ld - K * q - (r & 3) + 4 * cg_l) * 4);
-                li_w[i] = r * PITCH + ((4 * cg_l + K * (q & 1) + (r & ~3) + 4 * ring_pi(r & 7)) & (RING - 1));
+                if constexpr (LINES) {
+                    const int q = (r + K - 1) / K;
+                    li_voff[i] = (unsigned)((r * ld - K * q + 4 * cg_l) * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        li_w[i][j] = r * PITCH + ((4 * cg_l + j + K * (q & 1) + r + 4 * ring_pi(r & 7)) & (RING - 1));
+                } else {
+                    const int q = ((r & ~3) + K - 1) / K;
+                    li_voff[i] = (unsigned)((r * ld - K * q - (r & 3) + 4 * cg_l) * 4);
+                    li_w[i][0] = r * PITCH + ((4 * cg_l + K * (q & 1) + (r & ~3) + 4 * ring_pi(r & 7)) & (RING - 1));
+                }
             }
         }
 
@@ -531,7 +549,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                     } else {
                         // each dword is range-checked on its own (tools/ubench/bufx4.hip), and only dword
                         // alignment is needed, so M need not be a multiple of 4
-                        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_in[q], off, plain ? ubase : 0, AUX_IN_LOAD);
+                        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_in[q], off, plain ? ubase : 0, (LINES && SDP_LINES_NT) ? 2 : AUX_IN_LOAD);
                         const unsigned v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
                         rs[q][4 * i] = __uint_as_float(v0);
                         rs[q][4 * i + 1] = __uint_as_float(v1);
@@ -552,9 +570,15 @@ __device__ __forceinline__ void sweep(const Params &p)
 #pragma unroll
                 for (int i = 0; i < NLD; ++i)
 #pragma unroll
-                    for (int q = 0; q < T::SIN; ++q)
-                        *reinterpret_cast<float4 *>(lds_in + q * PLANE + (li_w[i] ^ flip)) =
-                            make_float4(rs[q][4 * i], rs[q][4 * i + 1], rs[q][4 * i + 2], rs[q][4 * i + 3]);
+                    for (int q = 0; q < T::SIN; ++q) {
+                        if constexpr (LINES) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) lds_in[q * PLANE + (li_w[i][j] ^ flip)] = rs[q][4 * i + j];
+                        } else {
+                            *reinterpret_cast<float4 *>(lds_in + q * PLANE + (li_w[i][0] ^ flip)) =
+                                make_float4(rs[q][4 * i], rs[q][4 * i + 1], rs[q][4 * i + 2], rs[q][4 * i + 3]);
+                        }
+                    }
             }
         };
 
@@ -1140,7 +1164,7 @@ __device__ __forceinline__ void sweep(const Params &p)
         sdp::sweep<PASS, K, ##__VA_ARGS__>(p);                                             \
     }
 
-SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD)
+SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LINES != 0)
 SDP_KERNEL(sdp_fwd_lat_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT)
 SDP_KERNEL(sdp_fwd_x_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, true)
 SDP_KERNEL(sdp_bwd_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD)
