@@ -51,9 +51,11 @@ def ring_pi(x):
 @pytest.mark.parametrize("K", [16, 32])
 @pytest.mark.parametrize("M", [1, 31, 64, 100, 257, 512])
 @pytest.mark.parametrize("rev", [False, True])
-def test_input_ring_holds_exactly_the_needed_blocks(M, K, rev):
+@pytest.mark.parametrize("lines", [False, True])
+def test_input_ring_holds_exactly_the_needed_blocks(M, K, rev, lines):
     """Model the staged-input ring literally: lanes load dwordx4 groups of row r's blocks (which start at
-    columns K*j - (r mod 4)), write each group to one aligned 16-byte slot, and lane l reads the K values of a
+    columns K*j - (r mod 4), or at K*j in the line-aligned variant), write each group to one aligned 16-byte slot
+    (four dword writes in the line-aligned variant), and lane l reads the K values of a
     chunk as K/4 aligned 16-byte groups at position (t + 4*pi(l mod 8)) mod 2K.  Check that every value read
     for a real column is that column, that writes only overwrite dead data, and that all slots are aligned."""
     nchunks = ceil_div(M + 63, K)
@@ -69,6 +71,14 @@ def test_input_ring_holds_exactly_the_needed_blocks(M, K, rev):
             for lane in range(64):
                 r4, cg = lane // LPR, lane % LPR
                 r = i * RPL + r4
+                if lines:   # blocks start at multiples of K (whole lines); four dword writes per group
+                    q = ceil_div(r, K)
+                    col0 = K * (bb - q) + 4 * cg
+                    for j in range(4):
+                        w = ((4 * cg + j + K * (q & 1) + r + 4 * ring_pi(r & 7)) & (RING - 1)) ^ flip
+                        assert w == (col0 + j + r + 4 * ring_pi(r & 7)) % RING
+                        ring[r, w] = col0 + j
+                    continue
                 q = ceil_div(r & ~3, K)
                 col0 = K * (bb - q) - (r & 3) + 4 * cg          # li_voff without the row term
                 w = ((4 * cg + K * (q & 1) + (r & ~3) + 4 * ring_pi(r & 7)) & (RING - 1)) ^ flip
