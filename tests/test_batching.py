@@ -1,0 +1,39 @@
+"""CPU: the lengths side-channel of padded batches (reference collate_f, dataset/utils.py:255-281)."""
+import numpy as np
+import pytest
+import torch
+
+from deepblast_amd.batching import collate_with_lengths, lengths_from_unpacked
+
+
+def _item(rng, n, m):
+    gene = torch.from_numpy(rng.integers(0, 21, n))
+    other = torch.from_numpy(rng.integers(0, 21, m))
+    states = torch.from_numpy(rng.integers(0, 3, n + m))
+    aln = torch.from_numpy(rng.random((n, m)).astype(np.float32))
+    path = torch.from_numpy(rng.random((n, m)).astype(np.float32))
+    mask = torch.from_numpy(rng.integers(0, 2, (n, m)))
+    return gene, other, states, aln, path, mask, torch.ones(n), torch.ones(m)
+
+
+def test_collate_pads_like_the_reference_and_reports_sizes():
+    rng = np.random.default_rng(0)
+    sizes = [(5, 9), (12, 3), (1, 1), (7, 7)]
+    batch = [_item(rng, n, m) for n, m in sizes]
+    genes, others, states, dm, p, G, gM, oM, lengths = collate_with_lengths(batch)
+    assert lengths.dtype == torch.int32 and lengths.tolist() == [list(s) for s in sizes]
+    assert dm.shape == p.shape == G.shape == (4, 12, 9) and G.dtype == torch.bool
+    for b, (n, m) in enumerate(sizes):
+        assert torch.equal(dm[b, :n, :m], batch[b][3]) and torch.equal(p[b, :n, :m], batch[b][4])
+        assert torch.equal(G[b, :n, :m], batch[b][5].bool())
+        # padding is zero / False, exactly as collate_f leaves it
+        assert not dm[b, n:, :].any() and not dm[b, :, m:].any() and not G[b, n:, :].any() and not G[b, :, m:].any()
+        assert gM[b].sum() == n and oM[b].sum() == m
+    assert genes[1] is batch[1][0] and others[2] is batch[2][1] and states[3] is batch[3][2]
+
+
+def test_lengths_from_unpacked():
+    out = lengths_from_unpacked(torch.tensor([3, 5]), torch.tensor([4, 2]))
+    assert out.dtype == torch.int32 and out.tolist() == [[3, 4], [5, 2]]
+    with pytest.raises(ValueError):
+        lengths_from_unpacked(torch.tensor([3, 5]), torch.tensor([4]))
