@@ -174,13 +174,14 @@ def test_config3_variable_length_padded_batch():
         assert abs(float(aware["E"][b, n - 1, m - 1]) - 1.0) < 1e-6  # terminal cell of the true block
 
 
-@pytest.mark.parametrize("waves", [1, 2, 3, 4])
+@pytest.mark.parametrize("waves", [1, 2, 3, 4, 5, 7, 8])
 def test_every_wave_count_gives_identical_results(waves):
-    """The strip hand-off (LDS row buffer + progress words) must not depend on how many wavefronts share a
-    pair: results with W = 1, 2, 3, 4 waves are bit-identical (same arithmetic, different schedule)."""
+    """The strip hand-off (two shared LDS boundary rows, per-wave progress words, frame words) must not depend on
+    how many wavefronts share a pair, nor on the build (more than 4 waves selects the latency builds with their
+    shorter chunks): results are bit-identical -- same arithmetic, different schedule."""
     from deepblast_amd._engine import get_engine
     lib = get_engine().lib
-    B, N, M = 3, 400, 333   # 7 strips: every wave owns several, W = 3 does not divide them evenly
+    B, N, M = 3, 720, 333   # 12 strips: waves own several each, W = 5, 7 do not divide them evenly
     theta, A = datagen.theta_A(61, B, N, M)
     Z = datagen.normal(62, (B, N, M))
     ref = parity.oracle_all(theta, A, None, Z, 0)
@@ -205,6 +206,27 @@ def test_repeated_calls_are_deterministic():
     b = parity.engine_all(theta, A, None, Z, 1)
     for k in a:
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_many_strips_eight_waves_repeatable():
+    """Timing-dependent faults (a missed hand-off, the wide-store data hazard that once corrupted lanes 12-15 of the
+    saved state with 8 waves) show up as run-to-run differences: 10 strips on 8 waves, repeated."""
+    from deepblast_amd._engine import get_engine
+    lib = get_engine().lib
+    B, N, M = 24, 640, 96
+    theta, A = datagen.theta_A(65, B, N, M)
+    first = parity.engine_all(theta, A, None, None, 0)
+    _assert(parity.compare(first, parity.oracle_all(theta, A, None, None, 0)))
+    try:
+        for p in range(4):
+            lib.sdp_set_waves(p, 8)
+        for rep in range(6):
+            again = parity.engine_all(theta, A, None, None, 0)
+            for k in first:
+                assert np.array_equal(first[k], again[k]), (rep, k)
+    finally:
+        for p in range(4):
+            lib.sdp_set_waves(p, 0)
 
 
 @pytest.mark.parametrize("variant", [0, 1], ids=["nw", "sw"])
