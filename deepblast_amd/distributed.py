@@ -40,16 +40,19 @@ def balanced_assignment(work, world):
     return order, counts, inverse
 
 
-def _all_gather_cat(x, group):
-    """All-gather equally shaped tensors along dim 0 with one collective."""
+def _all_gather_cat(x, group, async_op=False):
+    """All-gather equally shaped tensors along dim 0 with one collective.
+
+    async_op=True returns (out, work): the collective is enqueued on the backend's own stream and `work.wait()`
+    makes the current stream wait for it, so that it can overlap with kernels launched in between."""
     world = dist.get_world_size(group)
     out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     try:
-        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+        work = dist.all_gather_into_tensor(out, x.contiguous(), group=group, async_op=async_op)
     except (RuntimeError, NotImplementedError):  # backends without the flat variant
         parts = list(out.chunk(world, dim=0))
-        dist.all_gather(parts, x.contiguous(), group=group)
-    return out
+        work = dist.all_gather(parts, x.contiguous(), group=group, async_op=async_op)
+    return (out, work) if async_op else out
 
 
 class ShardedAligner:
@@ -81,10 +84,19 @@ class ShardedAligner:
         # its gradient on the way to the backward sweep
         if self._ones is None or self._ones.shape != Vt.shape or self._ones.device != Vt.device:
             self._ones = torch.ones_like(Vt)
+        gathering = self.gather != "none" and dist.is_available() and dist.is_initialized()
+        pending = None
+        if gathering:
+            # the scores are final after the forward sweep: their all-gather (RCCL's own stream) runs while the
+            # backward sweep computes E
+            pending = _all_gather_cat(Vt.detach(), self.group, async_op=True)
         (E,) = torch.autograd.grad(Vt, theta, grad_outputs=self._ones)
         out = {"Vt_local": Vt.detach(), "E_local": E, "Vt": None, "E": None}
-        if self.gather != "none" and dist.is_available() and dist.is_initialized():
-            out["Vt"] = _all_gather_cat(Vt.detach(), self.group)
+        if gathering:
+            vt_all, work = pending
+            if work is not None:
+                work.wait()
+            out["Vt"] = vt_all
             if self.gather == "e":
                 out["E"] = _all_gather_cat(E, self.group)
         return out
