@@ -91,7 +91,7 @@ int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state 
     // With per-pair lengths the longest pairs set the time of a batch that does not queue up on the CUs, so such
     // a batch is treated like a small one (measured, 256 pairs with n, m ~ U[64,1024]: 1.27 ms vs 1.41 ms).
     const int cus = num_cus(device);
-    const bool full = p.B * 4 >= cus * 3 && !(p.lens && p.B <= 2 * cus);
+    const bool full = p.B * 2 >= cus && !(p.lens && p.B <= 2 * cus);  // measured crossover: ~100 pairs on 256 CUs
     Variant v = variant(pass);
     int W = g_waves[pass];
     if (W <= 0) W = (pass == sdp::PASS_FWD || pass == sdp::PASS_BWD) ? (full ? 4 : 8) : SDP_DEFAULT_WAVES;
