@@ -94,7 +94,13 @@ int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state 
     const bool full = p.B * 2 >= cus && !(p.lens && p.B <= 2 * cus);  // measured crossover: ~100 pairs on 256 CUs
     Variant v = variant(pass);
     int W = g_waves[pass];
-    if (W <= 0) W = (pass == sdp::PASS_FWD || pass == sdp::PASS_BWD) ? (full ? 4 : 8) : SDP_DEFAULT_WAVES;
+    if (W <= 0) {
+        W = (pass == sdp::PASS_FWD || pass == sdp::PASS_BWD) ? (full ? 4 : 8) : SDP_DEFAULT_WAVES;
+        // More pairs than CUs: with 2 waves two workgroups share a CU (their LDS fits twice) and overlap each
+        // other's ramps -- a round of 2*CUs pairs then takes 1.8x a 4-wave round of CUs pairs.  Pick the cheaper.
+        const int r4 = (p.B + cus - 1) / cus, r2 = (p.B + 2 * cus - 1) / (2 * cus);
+        if (full && (pass == sdp::PASS_FWD || pass == sdp::PASS_BWD) && p.B > cus && 181 * r2 < 100 * r4) W = 2;
+    }
     if (pass == sdp::PASS_FWD || pass == sdp::PASS_BWD) {
         // the throughput builds need 4 waves' worth of LDS for their longer chunks; fall back to the latency
         // builds when that does not fit (long M) or when more waves are wanted
