@@ -75,46 +75,63 @@ int check_shape(int B, int N, int M, int variant)
     return 0;
 }
 
-int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state = false)
-{
-    hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
-    const int nstrips = sdp::state_nstrips(p.N);
-    p.nstrips_max = nstrips;
-    p.tpad = sdp::state_tpad(p.M);
-    p.mcap = (p.M + 63) / 64 * 64;
-    p.dbg = g_dbg;
+// What a launch will use: which kernel build, how many waves per pair, how much LDS.  Pure function of the
+// problem and the CU count (no device access), so that the policy can be tested without a GPU (sdp_plan).
+struct Plan {
+    Variant v;
+    int W;
+    size_t lds, stage_off;
+};
 
-    // Waves per pair.  A batch that fills the GPU (one pair per CU) is bound by HBM and runs best with one
-    // wave per SIMD; a smaller batch is bound by the length of the strip pipeline of a single pair, which
-    // more waves (and the shorter-chunk build of the backward sweep) shorten.
+Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cus, int forced_waves)
+{
+    const int nstrips = sdp::state_nstrips(N);
+    const int mcap = (M + 63) / 64 * 64;
+    // Waves per pair.  A batch that occupies the GPU is bound by HBM/fabric traffic and runs best with one wave
+    // per SIMD and long chunks; a smaller batch is bound by the length of the strip pipeline of a single pair,
+    // which more waves (and the shorter-chunk latency builds) shorten.
     // With per-pair lengths the longest pairs set the time of a batch that does not queue up on the CUs, so such
     // a batch is treated like a small one (measured, 256 pairs with n, m ~ U[64,1024]: 1.27 ms vs 1.41 ms).
-    const int cus = num_cus(device);
-    const bool full = p.B * 2 >= cus && !(p.lens && p.B <= 2 * cus);  // measured crossover: ~100 pairs on 256 CUs
+    const bool sweep12 = pass == sdp::PASS_FWD || pass == sdp::PASS_BWD;
+    const bool full = B * 2 >= cus && !(has_lens && B <= 2 * cus);  // measured crossover: ~100 pairs on 256 CUs
     Variant v = variant(pass);
-    int W = g_waves[pass];
+    int W = forced_waves;
     if (W <= 0) {
-        W = (pass == sdp::PASS_FWD || pass == sdp::PASS_BWD) ? (full ? 4 : 8) : SDP_DEFAULT_WAVES;
+        W = sweep12 ? (full ? 4 : 8) : SDP_DEFAULT_WAVES;
         // More pairs than CUs: with 2 waves two workgroups share a CU (their LDS fits twice) and overlap each
         // other's ramps -- a round of 2*CUs pairs then takes 1.8x a 4-wave round of CUs pairs.  Pick the cheaper.
-        const int r4 = (p.B + cus - 1) / cus, r2 = (p.B + 2 * cus - 1) / (2 * cus);
-        if (full && (pass == sdp::PASS_FWD || pass == sdp::PASS_BWD) && p.B > cus && 181 * r2 < 100 * r4) W = 2;
+        const int r4 = (B + cus - 1) / cus, r2 = (B + 2 * cus - 1) / (2 * cus);
+        if (full && sweep12 && B > cus && 181 * r2 < 100 * r4) W = 2;
     }
-    if (pass == sdp::PASS_FWD || pass == sdp::PASS_BWD) {
+    if (sweep12) {
         // the throughput builds need 4 waves' worth of LDS for their longer chunks; fall back to the latency
         // builds when that does not fit (long M) or when more waves are wanted
         const int w4 = nstrips < 4 ? nstrips : 4;
-        if (W > v.maxw || lds_bytes(pass, v.K, w4, p.mcap, nullptr) > 160 * 1024) v = variant(pass == sdp::PASS_FWD ? 6 : 4);
+        if (W > v.maxw || lds_bytes(pass, v.K, w4, mcap, nullptr) > 160 * 1024) v = variant(pass == sdp::PASS_FWD ? 6 : 4);
     }
     if (pass == sdp::PASS_FWD && exact_state) v = variant(5);
     if (W > v.maxw) W = v.maxw;
     if (W > nstrips) W = nstrips;
     size_t off = 0, lds = 0;
     for (;; --W) {  // fewer waves if the boundary rows (long M) plus staging exceed the 160 KiB of LDS
-        lds = lds_bytes(pass, v.K, W, p.mcap, &off);
+        lds = lds_bytes(pass, v.K, W, mcap, &off);
         if (lds <= 160 * 1024 || W == 1) break;
     }
+    return {v, W, lds, off};
+}
+
+int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state = false)
+{
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    p.nstrips_max = sdp::state_nstrips(p.N);
+    p.tpad = sdp::state_tpad(p.M);
+    p.mcap = (p.M + 63) / 64 * 64;
+    p.dbg = g_dbg;
+    const Plan pl = plan(pass, p.B, p.N, p.M, p.lens != nullptr, exact_state, num_cus(device), g_waves[pass]);
+    const Variant v = pl.v;
+    const int W = pl.W;
+    const size_t lds = pl.lds, off = pl.stage_off;
     p.stage_off = (int)off;
     // raise the dynamic-LDS limit once per (thread, device, kernel) -- it is sticky, and the value is the
     // 160 KiB the hardware has, so concurrent callers cannot disagree
@@ -150,6 +167,20 @@ size_t sdp_state_d_bytes(int B, int N, int M)
 {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
     return (size_t)B * sdp::state_nstrips(N) * sdp::state_tpad(M) * 64 * sizeof(float2);
+}
+
+int sdp_plan(int pass, int B, int N, int M, int has_lens, int exact_state, int cus, int *kernel_id, int *chunk,
+             int *waves, size_t *lds)
+{
+    if (pass < 0 || pass > 3) return fail(SDP_E_VARIANT, "sdp_plan: pass must be 0..3");
+    if (int rc = check_shape(B, N, M, SDP_NW)) return rc;
+    if (cus <= 0) return fail(SDP_E_SHAPE, "sdp_plan: cus must be positive");
+    const Plan pl = plan(pass, B, N, M, has_lens != 0, exact_state != 0, cus, 0);
+    if (kernel_id) *kernel_id = pl.v.id;
+    if (chunk) *chunk = pl.v.K;
+    if (waves) *waves = pl.W;
+    if (lds) *lds = pl.lds;
+    return 0;
 }
 
 int sdp_set_waves(int pass, int waves)

@@ -57,3 +57,36 @@ def test_argument_errors_need_no_gpu(lib):
     assert lib.sdp_adjoint_forward_f32(one, None, None, one, one, 1, 1, 1, None, 0, 0, None) == -1
     assert lib.sdp_adjoint_backward_f32(one, one, one, one, 1, 1, 1 << 20, None, 0, 0, None) == -3
     assert lib.sdp_set_waves(9, 1) == -1
+
+
+def _plan(lib, pass_, B, N, M, lens=0, exact=0, cus=256):
+    import ctypes
+    kid, chunk, waves, lds = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
+    assert lib.sdp_plan(pass_, B, N, M, lens, exact, cus, ctypes.byref(kid), ctypes.byref(chunk), ctypes.byref(waves),
+                        ctypes.byref(lds)) == 0
+    return kid.value, chunk.value, waves.value, lds.value
+
+
+def test_launch_plan_policy(lib):
+    """Which build / how many waves a launch uses, checked without a device."""
+    LDS = 160 * 1024
+    # headline: one pair per CU -> throughput builds, 4 waves, long chunks
+    assert _plan(lib, 0, 256, 512, 512)[:3] == (0, 32, 4)
+    assert _plan(lib, 1, 256, 512, 512)[:3] == (1, 32, 4)
+    # small batch -> latency builds, 8 waves, short chunks
+    assert _plan(lib, 0, 16, 512, 512)[:3] == (6, 16, 8)
+    assert _plan(lib, 1, 16, 512, 512)[:3] == (4, 16, 8)
+    # more pairs than CUs: two waves when that needs fewer rounds
+    assert _plan(lib, 0, 512, 512, 512)[2] == 2 and _plan(lib, 0, 768, 512, 512)[2] == 4
+    # per-pair lengths on a batch that does not queue up: treated like a small batch
+    assert _plan(lib, 0, 256, 1024, 1024, lens=1)[:3] == (6, 16, 8)
+    # exact state for the adjoint sweeps: its own build
+    assert _plan(lib, 0, 256, 512, 512, exact=1)[0] == 5
+    # never more waves than strips; LDS always fits, also at the column limit
+    assert _plan(lib, 0, 4, 100, 100)[2] == 2
+    for pass_ in range(4):
+        for (B, N, M) in [(256, 512, 512), (4, 64, 2048), (300, 2000, 2048), (1, 1, 1)]:
+            kid, chunk, waves, lds = _plan(lib, pass_, B, N, M)
+            assert 1 <= waves <= 8 and lds <= LDS, (pass_, B, N, M, kid, waves, lds)
+    # the long-M fallback: throughput builds do not fit with 2048 columns
+    assert _plan(lib, 0, 256, 512, 2048)[0] == 6 and _plan(lib, 1, 256, 512, 2048)[0] in (1, 4)
