@@ -7,7 +7,8 @@
 // <= 1e-4; see "carries" below for the arithmetic each pass uses.
 //
 // Mapping:
-//   * one workgroup per pair, W <= 4 wavefronts (one per SIMD);
+//   * one workgroup per pair, W <= 8 wavefronts (throughput builds: K = 32, <= 4 waves; latency builds:
+//     K = 16, <= 8 waves; the host picks per launch, sdp_api.hip::plan);
 //   * the N rows are cut into strips of 64; wave w owns strips w, w+W, ...;
 //   * inside a strip lane l owns row i0+l and at step t sits on column t-l, so the
 //     64 lanes of a wave always lie on one anti-diagonal.  The two predecessors from
@@ -15,15 +16,20 @@
 //     LDS, no barrier); the row-i predecessor is the lane's own register;
 //   * strip-to-strip hand-off (bottom row of strip s -> lane 0 of strip s+1) goes
 //     through an 8-byte-slot row buffer in LDS, published K columns at a time with a
-//     monotonic progress word (no s_barrier anywhere in the sweep);
-//   * row-major tensors (theta, A, Ztheta, ZA, E, Ed) cross the skew through LDS in
-//     K-column blocks aligned to K columns (full 128-byte lines for K = 32): inputs
-//     live in a per-row ring of two blocks, prefetched through registers one chunk
-//     ahead; outputs are written to LDS by step and leave as aligned blocks;
+//     monotonic progress word per wave (no s_barrier anywhere in the sweep);
+//   * row-major tensors (theta, A, Ztheta, ZA, E, Ed) cross the skew through LDS:
+//     inputs as K-column blocks loaded four columns per lane into a rotated per-row
+//     ring that the lanes read back with aligned 16-byte reads, prefetched through
+//     registers one chunk ahead; outputs are written to LDS by step and leave as
+//     aligned blocks;
 //   * the saved state (reference: Q, (B,N+2,M+2,3) fp32) is private to this library,
-//     so it is stored ALREADY SKEWED: state[pair][strip][t][lane] = (qx, qy) as
-//     float2 (qm = 1 - qx - qy).  Forward writes and backward reads are then single
-//     512-byte fully coalesced wave accesses with no transposition.
+//     so it is stored ALREADY SKEWED, [pair][strip][t][lane]: packed to 6 bytes per
+//     cell for the backward sweep (two steps per dwordx3), or float2 for the adjoint
+//     sweeps (qm = 1 - qx - qy is never stored).  Forward writes and backward reads
+//     are then fully coalesced wave accesses with no transposition;
+//   * the forward recurrence runs in a scaled exp domain; normally in its windowed
+//     form (one exponent per lane and 16-step block, see steps_wf), with the
+//     per-step-normalised form as the verified fallback;
 //   * the reverse passes run the same (t, lane) -> cell schedule backwards in "push"
 //     form: each cell scales its E by its own three weights and hands the products to
 //     its predecessors, so every cell's weights are read exactly once, by its owner.
