@@ -1029,6 +1029,9 @@ __device__ __forceinline__ void sweep(const Params &p)
                         const int ktf = t_final - t0;  // only that lane has t_final >= 0
 #pragma unroll
                         for (int k = 0; k < K; ++k) vt_keep = (k == ktf) ? hist[k] : vt_keep;
+                        // a terminal cell on the Smith-Waterman border is not live: V = 0 exactly (its value in the
+                        // frame may have underflowed to 0, which would read as -inf)
+                        if (t_final >= 0 && t_final < thr) vt_keep = edge_zero<KIND>();
                     }
                 }
                 return 1;

@@ -230,6 +230,29 @@ def test_many_strips_eight_waves_repeatable():
 
 
 @pytest.mark.parametrize("variant", [0, 1], ids=["nw", "sw"])
+def test_terminal_cell_on_the_border(variant):
+    """Single-column / single-row problems and per-pair lengths of 1: for Smith-Waterman the terminal cell then
+    lies on the padded border (V = 0 exactly, Vt = 0, E = 0); found by fuzzing when the windowed forward form
+    captured an underflowed 0 (-> -inf) for it."""
+    for (B, N, M) in [(1, 232, 1), (2, 1, 300), (3, 127, 1), (2, 485, 2)]:
+        theta, A = datagen.theta_A(90 + N, B, N, M)
+        Z = datagen.normal(91 + N, (B, N, M))
+        ref = parity.oracle_all(theta, A, None, Z, variant)
+        got = parity.engine_all(theta, A, None, Z, variant)
+        assert np.all(np.isfinite(got["Vt"])), (B, N, M)
+        _assert(parity.compare(got, ref), f"{(B, N, M)} v{variant}")
+    B, N, M = 4, 135, 40
+    theta, A = datagen.theta_A(95, B, N, M)
+    theta = (5.0 * theta).astype(np.float32)
+    Z = datagen.normal(96, (B, N, M))
+    lens = np.array([[135, 1], [1, 40], [60, 2], [135, 40]], dtype=np.int32)
+    ref = parity.oracle_lens(theta, A, None, Z, variant, lens)
+    got = parity.engine_all(theta, A, None, Z, variant, lens=lens)
+    assert np.all(np.isfinite(got["Vt"]))
+    _assert(parity.compare(got, ref), f"lens v{variant}")
+
+
+@pytest.mark.parametrize("variant", [0, 1], ids=["nw", "sw"])
 def test_forbidden_gaps_minus_infinity(variant):
     """A = -inf (a forbidden gap) is legal in the reference: exp(-inf) = 0 removes the x/y terms (nw.py:10-27).
     The exp-domain forward clamps the exponent instead of forming inf - inf."""
