@@ -1,0 +1,42 @@
+"""Wider fuzz than tests/gpu_check.py --fuzz: steep and flat scores, forbidden gaps, long rows, tiny shapes, many
+pairs, per-pair lengths; first-order results must meet 1e-4, second-order ones are reported."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, datagen, parity
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 777
+rng = np.random.default_rng(seed)
+worst1 = worst2 = 0.0
+nf1 = nf2 = 0
+for it in range(n):
+    kind = rng.integers(0, 5)
+    if kind == 0: B, N, M = int(rng.integers(1, 4)), int(rng.integers(1, 8)), int(rng.integers(1, 2049))
+    elif kind == 1: B, N, M = int(rng.integers(1, 4)), int(rng.integers(1, 1500)), int(rng.integers(1, 8))
+    elif kind == 2: B, N, M = int(rng.integers(1, 300)), int(rng.integers(1, 90)), int(rng.integers(1, 90))
+    else: B, N, M = int(rng.integers(1, 4)), int(rng.integers(1, 700)), int(rng.integers(1, 900))
+    variant = int(rng.integers(0, 2))
+    theta, A = datagen.theta_A(50000 + it, B, N, M)
+    ts = float(rng.choice([0.01, 1.0, 8.0, 30.0])); as_ = float(rng.choice([0.0, 1.0, 10.0, 40.0])); ao = float(rng.choice([0.0, 0.5, -3.0]))
+    theta = (theta * ts - float(rng.choice([0.0, 0.0, 2.0]))).astype(np.float32)
+    A = (A * as_ + ao).astype(np.float32)
+    if rng.integers(0, 6) == 0:
+        A[rng.random(A.shape) < 0.2] = -np.inf
+    Z = datagen.normal(60000 + it, (B, N, M))
+    use_lens = bool(rng.integers(0, 2))
+    try:
+        if use_lens:
+            lens = np.stack([rng.integers(1, N + 1, B), rng.integers(1, M + 1, B)], axis=1).astype(np.int32)
+            ref = parity.oracle_lens(theta, A, None, Z, variant, lens); got = parity.engine_all(theta, A, None, Z, variant, lens=lens)
+        else:
+            ref = parity.oracle_all(theta, A, None, Z, variant); got = parity.engine_all(theta, A, None, Z, variant)
+        e = parity.compare(got, ref)
+    except Exception as ex:
+        print("EXCEPTION", it, (B, N, M, variant, use_lens), ex, flush=True); nf1 += 1; continue
+    e1 = max(e["Vt"], e["E"]); e2 = max(e["Ed"], e["Vtd"])
+    e1 = e1 if np.isfinite(e1) else 9e9; e2 = e2 if np.isfinite(e2) else 9e9
+    worst1, worst2 = max(worst1, e1), max(worst2, e2)
+    if e1 > parity.TOL or e2 > parity.TOL:
+        nf1 += e1 > parity.TOL; nf2 += e2 > parity.TOL
+        print(f"it={it} {(B, N, M, variant, use_lens)} theta*{ts} A*{as_}+{ao}: " + " ".join(f"{k}={v:.2e}" for k, v in e.items()), flush=True)
+print(f"{n} cases: first-order worst {worst1:.3e} ({nf1} over 1e-4), second-order worst {worst2:.3e} ({nf2} over 1e-4)")
