@@ -229,6 +229,22 @@ def test_many_strips_eight_waves_repeatable():
             lib.sdp_set_waves(p, 0)
 
 
+@pytest.mark.parametrize("case", [(130, 64, 2048, 0, False), (600, 130, 70, 1, False), (520, 200, 64, 0, True),
+                                  (300, 70, 2000, 1, True), (128, 512, 512, 0, False)],
+                         ids=["full-longM-latency-fallback", "two-waves-per-pair", "two-waves-lengths", "lengths-longM",
+                              "half-the-CUs-throughput"])
+def test_every_launch_policy_branch_keeps_parity(case):
+    """Batches that make sdp_api.hip::plan pick each of its branches on a 256-CU device (throughput builds, their
+    long-M fallback, two waves per pair for more pairs than CUs, the lengths rule): first-order parity."""
+    B, N, M, variant, use_lens = case
+    theta, A = datagen.theta_A(19, B, N, M)
+    lens = datagen.lengths(21, B, 1, min(N, M)) if use_lens else None
+    ref = (parity.oracle_lens(theta, A, None, None, variant, lens) if use_lens
+           else parity.oracle_all(theta, A, None, None, variant, omp=True))
+    got = parity.engine_all(theta, A, None, None, variant, lens=lens)
+    _assert(parity.compare(got, ref), str(case))
+
+
 @pytest.mark.parametrize("variant", [0, 1], ids=["nw", "sw"])
 def test_terminal_cell_on_the_border(variant):
     """Single-column / single-row problems and per-pair lengths of 1: for Smith-Waterman the terminal cell then
