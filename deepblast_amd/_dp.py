@@ -4,7 +4,7 @@ Mirrors the reference's Function pair (deepblast/nw_cuda.py:168-262, nw.py:315-3
 
     Function.forward(theta, A, operator)            -> Vt            saves (theta, A, state)
     Function.backward(Et)                           -> (E, A, None)  via FunctionBackward.apply
-    FunctionBackward.forward(theta, A, Et, Q, op)   -> (E, A)        saves (theta, A, E)
+    FunctionBackward.forward(theta, A, Et, Q, op)   -> (E, A)        saves (Q, E) or (theta, A, E)
     FunctionBackward.backward(Ztheta, ZA)           -> (Ed, None, Vtd, None, None)
 
 and keeps its gradient-flow quirks: the first-order "gradient" returned
@@ -12,8 +12,8 @@ for A is A itself (nw.py:337-339,355); the second-order gradient w.r.t. A is Non
 (nw.py:386); Et may be non-uniform.
 
 Differences that are part of the design, not of the maths: `Q` is an opaque state tensor
-(library-private layout, 6 bytes per cell; the second-order path recomputes it at full fp32
-precision) instead of (B,N+2,M+2,3), and E is produced directly
+(library-private layout; 6 bytes per cell on the inference path, float2 when decode() announces
+that the second-order sweeps will follow) instead of (B,N+2,M+2,3), and E is produced directly
 as (B,N,M) -- the reference's E[:,1:-1,1:-1] -- without materialising the zero border.
 """
 import numpy as np
@@ -39,11 +39,15 @@ def make_functions(variant, prefix, allow_none_operator=False):
     class FunctionBackward(torch.autograd.Function):
 
         @staticmethod
-        def forward(ctx, theta, A, Et, Q, operator, lens=None):
+        def forward(ctx, theta, A, Et, Q, operator, lens=None, exact_state=False):
             eng = _engine.get_engine()
-            E = eng.backward(Et.detach(), Q, tuple(theta.shape), variant, lens)
-            ctx.save_for_backward(theta, A, E)
-            ctx.others = (operator, lens)
+            E = eng.backward(Et.detach(), Q, tuple(theta.shape), variant, lens, exact_state=exact_state)
+            # exact state: the adjoint sweeps can use Q as it is; compact state: they need theta and A to get it
+            if exact_state:
+                ctx.save_for_backward(Q, E)
+            else:
+                ctx.save_for_backward(theta, A, E)
+            ctx.others = (operator, lens, exact_state)
             # The cotangent of the pass-through A output is all zeros whenever nothing consumes it (the
             # reference materialises it, nw.py:357-383, and feeds the zeros to the adjoint sweep).  Asking
             # autograd not to materialise lets the kernel skip reading a (B,N,M) tensor of zeros.
@@ -52,37 +56,41 @@ def make_functions(variant, prefix, allow_none_operator=False):
 
         @staticmethod
         def backward(ctx, Ztheta, ZA):
-            theta, A, E = ctx.saved_tensors
-            _, lens = ctx.others
+            _, lens, exact_state = ctx.others
             eng = _engine.get_engine()
+            if exact_state:
+                Q, E = ctx.saved_tensors
+            else:
+                # The saved state is the compact one (6 B/cell) the backward sweep reads fastest.  The adjoint
+                # sweeps multiply the weights with directional derivatives of any magnitude and need them at
+                # full fp32 precision: re-run the forward sweep in its exact-state form.  Callers that know
+                # the second-order sweeps will follow (Decoder.decode, i.e. training) ask for the exact state
+                # up front and never get here.
+                theta, A, E = ctx.saved_tensors
+                _, Q = eng.forward(theta.detach(), A.detach(), variant, lens, exact_state=True)
             if Ztheta is None:
                 Ztheta = torch.zeros_like(E)
-            # The saved state is the compact one (6 B/cell) the backward sweep reads.  The adjoint sweeps
-            # multiply the weights with directional derivatives of any magnitude and need them at full
-            # fp32 precision, so the second-order path -- rare next to the first-order one -- re-runs
-            # the forward sweep in its exact-state form instead of making every forward pay for it.
-            _, Q = eng.forward(theta.detach(), A.detach(), variant, lens, exact_state=True)
             Vtd, Qd = eng.adjoint_forward(Q, Ztheta, ZA, variant, lens)
             Ed = eng.adjoint_backward(E, Q, Qd, variant, lens)
-            return Ed, None, Vtd, None, None, None
+            return Ed, None, Vtd, None, None, None, None
 
     class Function(torch.autograd.Function):
 
         @staticmethod
-        def forward(ctx, theta, A, operator, lens=None):
+        def forward(ctx, theta, A, operator, lens=None, exact_state=False):
             _validate(theta, A, operator, allow_none_operator)
             eng = _engine.get_engine()
-            Vt, Q = eng.forward(theta.detach(), A.detach(), variant, lens)
+            Vt, Q = eng.forward(theta.detach(), A.detach(), variant, lens, exact_state=exact_state)
             ctx.save_for_backward(theta, A, Q)
-            ctx.others = (operator, lens)
+            ctx.others = (operator, lens, exact_state)
             return Vt
 
         @staticmethod
         def backward(ctx, Et):
             theta, A, Q = ctx.saved_tensors
-            operator, lens = ctx.others
-            E, A = FunctionBackward.apply(theta, A, Et, Q, operator, lens)
-            return E, A, None, None
+            operator, lens, exact_state = ctx.others
+            E, A = FunctionBackward.apply(theta, A, Et, Q, operator, lens, exact_state)
+            return E, A, None, None, None
 
     Function.__name__ = Function.__qualname__ = prefix + "Function"
     FunctionBackward.__name__ = FunctionBackward.__qualname__ = prefix + "FunctionBackward"
@@ -147,6 +155,11 @@ class _Decoder(nn.Module):
             return self._function.apply(theta, A, self.operator)
         return self._function.apply(theta, A, self.operator, lengths)
 
+    def _forward_for_decode(self, theta, A, lengths):
+        # decode() is differentiated again by its callers (training: loss on the alignment matrix): save the
+        # state in the exact form all four sweeps can share
+        return self._function.apply(theta, A, self.operator, lengths, True)
+
     def traceback(self, grad):
         return traceback(grad)
 
@@ -163,7 +176,7 @@ class _Decoder(nn.Module):
     def decode(self, theta, A, lengths=None):
         """Expected alignment matrix dVt/dtheta, differentiable (nw_cuda.py:319-325)."""
         with torch.enable_grad():
-            nll = self.forward(theta, A, lengths)
+            nll = self._forward_for_decode(theta, A, lengths)
             v = torch.sum(nll)
             v_grad, _ = torch.autograd.grad(v, (theta, A), create_graph=True)
         return v_grad

@@ -94,16 +94,18 @@ class HipEngine:
         _lib.check(rc, "sdp_forward_f32")
         return Vt, state
 
-    def backward(self, Et, state, shape, variant, lens=None):
-        """-> E (B,N,M).  Replaces _backward_pass_kernel (nw_cuda.py:98-102)."""
+    def backward(self, Et, state, shape, variant, lens=None, exact_state=False):
+        """-> E (B,N,M).  Replaces _backward_pass_kernel (nw_cuda.py:98-102).
+
+        exact_state: `state` came from forward(..., exact_state=True)."""
         dev = self._dev(state)
         B, N, M = shape
         Et = Et.to(torch.float32).expand(B).contiguous()
         lens = self._lens(lens, B, state.device)
         E = torch.empty((B, N, M), dtype=torch.float32, device=state.device)
         with torch.cuda.device(dev), self._bracket("sdp_bwd_kernel"):
-            rc = self.lib.sdp_backward_f32(_ptr(Et), _ptr(state), _ptr(E), B, N, M, _ptr(lens), variant, dev,
-                                           self._stream(dev))
+            rc = self.lib.sdp_backward_f32(_ptr(Et), _ptr(state), _ptr(E), B, N, M, _ptr(lens),
+                                           variant | (EXACT_STATE if exact_state else 0), dev, self._stream(dev))
         _lib.check(rc, "sdp_backward_f32")
         return E
 

@@ -33,7 +33,7 @@ struct Variant {
 
 // kernel builds: [0] fwd (throughput: K=32, <= 4 waves), [1] bwd (throughput: K=32, <= 4 waves), [2] adj-fwd,
 // [3] adj-bwd, [4] bwd (latency: K=16, <= 8 waves), [5] fwd writing the exact (float2) state for the adjoint
-// sweeps, [6] fwd (latency: K=16, <= 8 waves)
+// sweeps, [6] fwd (latency: K=16, <= 8 waves), [7] / [8] bwd reading the exact state (throughput / latency)
 Variant variant(int id)
 {
     switch (id) {
@@ -43,6 +43,8 @@ Variant variant(int id)
     case 3: return {(const void *)sdp_adj_bwd_kernel, SDP_K_ABWD, SDP_MAXW_ABWD, 3};
     case 5: return {(const void *)sdp_fwd_x_kernel, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, 5};
     case 6: return {(const void *)sdp_fwd_lat_kernel, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, 6};
+    case 7: return {(const void *)sdp_bwd_x_kernel, SDP_K_BWD, SDP_MAXW_BWD, 7};
+    case 8: return {(const void *)sdp_bwd_x_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 8};
     default: return {(const void *)sdp_bwd_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 4};
     }
 }
@@ -110,6 +112,7 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
         if (W > v.maxw || lds_bytes(pass, v.K, w4, mcap, nullptr) > 160 * 1024) v = variant(pass == sdp::PASS_FWD ? 6 : 4);
     }
     if (pass == sdp::PASS_FWD && exact_state) v = variant(5);
+    if (pass == sdp::PASS_BWD && exact_state) v = variant(v.id == 1 ? 7 : 8);
     if (W > v.maxw) W = v.maxw;
     if (W > nstrips) W = nstrips;
     size_t off = 0, lds = 0;
@@ -135,7 +138,7 @@ int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state 
     p.stage_off = (int)off;
     // raise the dynamic-LDS limit once per (thread, device, kernel) -- it is sticky, and the value is the
     // 160 KiB the hardware has, so concurrent callers cannot disagree
-    static thread_local unsigned long long lds_raised[7] = {0, 0, 0, 0, 0, 0, 0};  // bit d = done on device d
+    static thread_local unsigned long long lds_raised[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // bit d = done on device d
     if (device >= 64 || !(lds_raised[v.id] >> device & 1ull)) {
         e = hipFuncSetAttribute(v.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -217,6 +220,8 @@ int sdp_backward_f32(const float *Et, const float *state, float *E, int B, int N
                      int variant, int device, void *stream)
 {
     if (!Et || !state || !E) return fail(SDP_E_NULLPTR, "sdp_backward_f32: null pointer");
+    const bool exact = (variant & SDP_EXACT_STATE) != 0;
+    variant &= ~SDP_EXACT_STATE;
     if (int rc = check_shape(B, N, M, variant)) return rc;
     if (lens) {
         hipError_t e = hipSetDevice(device);
@@ -229,7 +234,7 @@ int sdp_backward_f32(const float *Et, const float *state, float *E, int B, int N
     p.sout = E;
     p.lens = lens;
     p.B = B, p.N = N, p.M = M, p.variant = variant;
-    return launch(sdp::PASS_BWD, p, device, stream);
+    return launch(sdp::PASS_BWD, p, device, stream, exact);
 }
 
 int sdp_adjoint_forward_f32(const float *state, const float *Ztheta, const float *ZA, float *Vtd, float *state_d,

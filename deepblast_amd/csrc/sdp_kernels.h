@@ -110,6 +110,8 @@ __global__ void sdp_fwd_lat_kernel(const sdp::Params p);
 __global__ void sdp_fwd_x_kernel(const sdp::Params p);
 __global__ void sdp_bwd_kernel(const sdp::Params p);
 __global__ void sdp_bwd_lat_kernel(const sdp::Params p);
+__global__ void sdp_bwd_x_kernel(const sdp::Params p);
+__global__ void sdp_bwd_x_lat_kernel(const sdp::Params p);
 __global__ void sdp_adj_fwd_kernel(const sdp::Params p);
 __global__ void sdp_adj_bwd_kernel(const sdp::Params p);
 __global__ void sdp_selftest_kernel(int *out);

@@ -157,7 +157,7 @@ struct Traits<PASS_FWD, QX> {  // nw.py:46-62
 template <bool QX>
 struct Traits<PASS_BWD, QX> {  // nw.py:120-135
     static constexpr int SIN = 0, SOUT = 1;
-    static constexpr int QIN = Q_PACKED, QOUT = Q_NONE;
+    static constexpr int QIN = QX ? Q_EXACT : Q_PACKED, QOUT = Q_NONE;  // QX: the training path's float2 state
     static constexpr bool DIN = false, DOUT = false;
     static constexpr bool REV = true;
 };
@@ -864,9 +864,13 @@ __device__ __forceinline__ void sweep(const Params &p)
                             e = (t == t_final) ? et : e;
                             e = live ? e : 0.f;
                         }
-                        // the weights need no masking: the packed fields decode to finite numbers, and a cell that
-                        // is not live hands on e = 0
-                        const float qx = q0.x, qy = q0.y;
+                        // the packed weights need no masking: the fields decode to finite numbers, and a cell that
+                        // is not live hands on e = 0; float2 records of dead cells may hold anything (NaN included)
+                        float qx = q0.x, qy = q0.y;
+                        if constexpr (EDGE && T::QIN == Q_EXACT) {
+                            const bool live = (unsigned)(t - live_lo) < live_span;
+                            qx = live ? qx : 0.f, qy = live ? qy : 0.f;
+                        }
                         const float qm = __builtin_fmaxf((1.f - qx) - qy, 0.f);  // the two stored weights are rounded independently
                         cy.fb = qy * e;
                         cy.fa = __builtin_fmaf(qx, e, cy.fc);  // px + pm of the previous step
@@ -1185,6 +1189,8 @@ SDP_KERNEL(sdp_fwd_lat_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT)
 SDP_KERNEL(sdp_fwd_x_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, true)
 SDP_KERNEL(sdp_bwd_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD)
 SDP_KERNEL(sdp_bwd_lat_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT)
+SDP_KERNEL(sdp_bwd_x_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, true)
+SDP_KERNEL(sdp_bwd_x_lat_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, true)
 SDP_KERNEL(sdp_adj_fwd_kernel, sdp::PASS_AFWD, SDP_K_AFWD, SDP_MAXW_AFWD)
 SDP_KERNEL(sdp_adj_bwd_kernel, sdp::PASS_ABWD, SDP_K_ABWD, SDP_MAXW_ABWD)
 

@@ -33,7 +33,7 @@
  *     per cell).  The adjoint sweeps (second order) multiply the weights with
  *     directional derivatives of any size and need them at full fp32 precision:
  *     run sdp_forward_f32 with SDP_EXACT_STATE for them (float2 per cell, the
- *     size of Qd).
+ *     size of Qd); sdp_backward_f32 reads that format too when given the flag.
  *   - `lens` is NULL (reference semantics: every pair uses the full padded N x M)
  *     or a DEVICE pointer to B x 2 int32 (n_b, m_b): pair b is aligned over its
  *     top-left n_b x m_b block, terminal cell (n_b, m_b); E/Ed outside the block
@@ -61,8 +61,10 @@ extern "C" {
 #define SDP_NW 0
 #define SDP_SW 1
 /* or-ed into `variant` of sdp_forward_f32: `state` (then sdp_state_d_bytes large) receives Q at full fp32
- * precision.  The two adjoint entry points require a state produced this way; sdp_backward_f32 requires the
- * default (compact) one. */
+ * precision; or-ed into `variant` of sdp_backward_f32: `state` is such a buffer.  The two adjoint entry points
+ * always require a state produced this way.  A caller that knows the second-order sweeps will follow (training:
+ * decode() + loss.backward()) runs forward and backward with the flag and shares the one state; a caller that
+ * only needs E (inference) uses the default compact state, which the backward sweep reads faster. */
 #define SDP_EXACT_STATE 0x100
 
 #define SDP_E_NULLPTR (-1)  /* a required pointer is NULL */
@@ -138,7 +140,8 @@ int sdp_probe(int device);
 
 /* Diagnostic: what a launch of pass (0 fwd, 1 bwd, 2 adj-fwd, 3 adj-bwd) would use on a device with `cus` compute
  * units -- kernel build (0 fwd throughput, 1 bwd throughput, 2 adj-fwd, 3 adj-bwd, 4 bwd latency, 5 fwd exact
- * state, 6 fwd latency), chunk length, waves per pair, dynamic LDS bytes.  Pure function, needs no device. */
+ * state, 6 fwd latency, 7 / 8 bwd reading the exact state, throughput / latency), chunk length, waves per pair,
+ * dynamic LDS bytes.  Pure function, needs no device. */
 int sdp_plan(int pass, int B, int N, int M, int has_lens, int exact_state, int cus, int *kernel_id, int *chunk,
              int *waves, size_t *lds);
 

@@ -79,10 +79,13 @@ def engine_all(theta, A, Et, Z, variant, lens=None, ZA=None, device="cuda"):
     if Z is not None:
         z = torch.from_numpy(np.ascontiguousarray(Z)).to(device)
         za = None if ZA is None else torch.from_numpy(np.ascontiguousarray(ZA)).to(device)
-        _, Qx = eng.forward(t, a, variant, ln, exact_state=True)  # the adjoint sweeps read the exact state
+        # the training path: one exact (float2) state shared by the backward sweep and the two adjoint sweeps
+        Vtx, Qx = eng.forward(t, a, variant, ln, exact_state=True)
+        Ex = eng.backward(et, Qx, tuple(t.shape), variant, ln, exact_state=True)
         Vtd, Qd = eng.adjoint_forward(Qx, z, za, variant, ln)
-        Ed = eng.adjoint_backward(E, Qx, Qd, variant, ln)
+        Ed = eng.adjoint_backward(Ex, Qx, Qd, variant, ln)
         out["Ed"], out["Vtd"] = Ed.cpu().numpy(), Vtd.cpu().numpy()
+        out["Ex"], out["Vtx"] = Ex.cpu().numpy(), Vtx.cpu().numpy()
     torch.cuda.synchronize()
     return out
 
@@ -93,4 +96,7 @@ def compare(got, ref):
     if "Ed" in ref:
         errs["Ed"] = abs_err(got["Ed"], ref["Ed"], scale=True)
         errs["Vtd"] = rel_err(got["Vtd"], ref["Vtd"])
+    if "Ex" in got:  # backward sweep reading the exact state (training path) against the same reference E
+        errs["Ex"] = abs_err(got["Ex"], ref["E"])
+        errs["Vtx"] = rel_err(got["Vtx"], ref["Vt"])
     return errs

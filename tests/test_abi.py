@@ -82,6 +82,7 @@ def test_launch_plan_policy(lib):
     assert _plan(lib, 0, 256, 1024, 1024, lens=1)[:3] == (6, 16, 8)
     # exact state for the adjoint sweeps: its own build
     assert _plan(lib, 0, 256, 512, 512, exact=1)[0] == 5
+    assert _plan(lib, 1, 256, 512, 512, exact=1)[:3] == (7, 32, 4) and _plan(lib, 1, 16, 512, 512, exact=1)[:3] == (8, 16, 8)
     # never more waves than strips; LDS always fits, also at the column limit
     assert _plan(lib, 0, 4, 100, 100)[2] == 2
     for pass_ in range(4):
@@ -90,3 +91,4 @@ def test_launch_plan_policy(lib):
             assert 1 <= waves <= 8 and lds <= LDS, (pass_, B, N, M, kid, waves, lds)
     # the long-M fallback: throughput builds do not fit with 2048 columns
     assert _plan(lib, 0, 256, 512, 2048)[0] == 6 and _plan(lib, 1, 256, 512, 2048)[0] in (1, 4)
+    assert _plan(lib, 1, 256, 512, 2048, exact=1)[0] in (7, 8)
