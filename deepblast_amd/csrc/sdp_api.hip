@@ -33,7 +33,7 @@ struct Variant {
 
 // kernel builds: [0] fwd (throughput: K=32, <= 4 waves), [1] bwd (throughput: K=32, <= 4 waves), [2] adj-fwd,
 // [3] adj-bwd, [4] bwd (latency: K=16, <= 8 waves), [5] fwd writing the exact (float2) state for the adjoint
-// sweeps, [6] fwd (latency: K=16, <= 8 waves), [7] / [8] bwd reading the exact state (throughput / latency)
+// sweeps, [6] fwd (latency: K=16, <= 8 waves), [7] / [8] bwd reading the exact state (throughput / latency), [9] fwd writing the exact state (throughput)
 Variant variant(int id)
 {
     switch (id) {
@@ -45,6 +45,7 @@ Variant variant(int id)
     case 6: return {(const void *)sdp_fwd_lat_kernel, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, 6};
     case 7: return {(const void *)sdp_bwd_x_kernel, SDP_K_BWD, SDP_MAXW_BWD, 7};
     case 8: return {(const void *)sdp_bwd_x_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 8};
+    case 9: return {(const void *)sdp_fwd_x_tp_kernel, SDP_K_FWD, SDP_MAXW_FWD, 9};
     default: return {(const void *)sdp_bwd_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 4};
     }
 }
@@ -111,7 +112,7 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
         const int w4 = nstrips < 4 ? nstrips : 4;
         if (W > v.maxw || lds_bytes(pass, v.K, w4, mcap, nullptr) > 160 * 1024) v = variant(pass == sdp::PASS_FWD ? 6 : 4);
     }
-    if (pass == sdp::PASS_FWD && exact_state) v = variant(5);
+    if (pass == sdp::PASS_FWD && exact_state) v = variant(v.id == 0 ? 9 : 5);
     if (pass == sdp::PASS_BWD && exact_state) v = variant(v.id == 1 ? 7 : 8);
     if (W > v.maxw) W = v.maxw;
     if (W > nstrips) W = nstrips;
@@ -138,7 +139,7 @@ int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state 
     p.stage_off = (int)off;
     // raise the dynamic-LDS limit once per (thread, device, kernel) -- it is sticky, and the value is the
     // 160 KiB the hardware has, so concurrent callers cannot disagree
-    static thread_local unsigned long long lds_raised[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // bit d = done on device d
+    static thread_local unsigned long long lds_raised[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // bit d = done on device d
     if (device >= 64 || !(lds_raised[v.id] >> device & 1ull)) {
         e = hipFuncSetAttribute(v.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");

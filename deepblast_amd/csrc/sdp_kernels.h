@@ -108,6 +108,7 @@ extern "C" {
 __global__ void sdp_fwd_kernel(const sdp::Params p);
 __global__ void sdp_fwd_lat_kernel(const sdp::Params p);
 __global__ void sdp_fwd_x_kernel(const sdp::Params p);
+__global__ void sdp_fwd_x_tp_kernel(const sdp::Params p);
 __global__ void sdp_bwd_kernel(const sdp::Params p);
 __global__ void sdp_bwd_lat_kernel(const sdp::Params p);
 __global__ void sdp_bwd_x_kernel(const sdp::Params p);

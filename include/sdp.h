@@ -140,7 +140,8 @@ int sdp_probe(int device);
 
 /* Diagnostic: what a launch of pass (0 fwd, 1 bwd, 2 adj-fwd, 3 adj-bwd) would use on a device with `cus` compute
  * units -- kernel build (0 fwd throughput, 1 bwd throughput, 2 adj-fwd, 3 adj-bwd, 4 bwd latency, 5 fwd exact
- * state, 6 fwd latency, 7 / 8 bwd reading the exact state, throughput / latency), chunk length, waves per pair,
+ * state (latency), 6 fwd latency, 7 / 8 bwd reading the exact state (throughput / latency), 9 fwd exact state
+ * (throughput)), chunk length, waves per pair,
  * dynamic LDS bytes.  Pure function, needs no device. */
 int sdp_plan(int pass, int B, int N, int M, int has_lens, int exact_state, int cus, int *kernel_id, int *chunk,
              int *waves, size_t *lds);

@@ -81,7 +81,7 @@ def test_launch_plan_policy(lib):
     # per-pair lengths on a batch that does not queue up: treated like a small batch
     assert _plan(lib, 0, 256, 1024, 1024, lens=1)[:3] == (6, 16, 8)
     # exact state for the adjoint sweeps: its own build
-    assert _plan(lib, 0, 256, 512, 512, exact=1)[0] == 5
+    assert _plan(lib, 0, 256, 512, 512, exact=1)[0] == 9 and _plan(lib, 0, 16, 512, 512, exact=1)[0] == 5
     assert _plan(lib, 1, 256, 512, 512, exact=1)[:3] == (7, 32, 4) and _plan(lib, 1, 16, 512, 512, exact=1)[:3] == (8, 16, 8)
     # never more waves than strips; LDS always fits, also at the column limit
     assert _plan(lib, 0, 4, 100, 100)[2] == 2
