@@ -100,7 +100,7 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
     Variant v = variant(pass);
     int W = forced_waves;
     if (W <= 0) {
-        W = sweep12 ? (full ? 4 : 8) : SDP_DEFAULT_WAVES;
+        W = (sweep12 || pass == sdp::PASS_AFWD) ? (full ? 4 : 8) : SDP_DEFAULT_WAVES;  // (adj-bwd is compiled for <= 4)
         // More pairs than CUs: with 2 waves two workgroups share a CU (their LDS fits twice) and overlap each
         // other's ramps -- a round of 2*CUs pairs then takes 1.8x a 4-wave round of CUs pairs.  Pick the cheaper.
         const int r4 = (B + cus - 1) / cus, r2 = (B + 2 * cus - 1) / (2 * cus);

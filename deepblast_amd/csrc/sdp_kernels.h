@@ -48,7 +48,7 @@
 #define SDP_MAXW_BWD_LAT 8
 #endif
 #ifndef SDP_MAXW_AFWD
-#define SDP_MAXW_AFWD 4
+#define SDP_MAXW_AFWD 8
 #endif
 #ifndef SDP_MAXW_ABWD
 #define SDP_MAXW_ABWD 4
