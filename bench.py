@@ -115,14 +115,38 @@ def cpu_baseline(args):
     return out
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-run this script under torch.distributed.run with one
+    rank per GPU of this node (RCCL over xGMI), rendezvous on 127.0.0.1.  Fails loudly if the node has fewer
+    than N devices -- a run that silently timed fewer GPUs would be a wrong number."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"[bench] --gpus {args.gpus} requested but only {have} device(s) visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback)"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args)   # `python bench.py --gpus N`: create the N ranks ourselves
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
-    assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback)"
+    if world != args.gpus:
+        raise SystemExit(f"[bench] WORLD_SIZE={world} does not match --gpus {args.gpus}: refusing to time a "
+                         f"different job than the one asked for")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"[bench] rank {rank}: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} device(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -164,17 +188,35 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    def timed(nsteps):
+        """EXACTLY nsteps steps between two fences; -> (wall seconds, max over ranks; per-step ms from events)."""
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(nsteps + 1)]
+        fence()
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(nsteps):
+            step()
+            marks[i + 1].record()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, [marks[i].elapsed_time(marks[i + 1]) for i in range(nsteps)]
+
     timer.enabled = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed, per_step_ms = timed(args.steps)
     timer.enabled = False
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    # N > 1: the same job with the expected-alignment matrices gathered as well (SURVEY 8e: report scaling with
+    # and without the E gather); a secondary figure, never `value`
+    e_gather = None
+    if world > 1 and args.mode == "fwdbwd" and args.gather != "e":
+        aligner.gather = "e"
+        step()
+        dt_e, _ = timed(min(args.steps, 5))
+        aligner.gather = args.gather
+        e_gather = dt_e / min(args.steps, 5)
 
     cells = B * N * M if args.variant == "nw" else B * (N - 1) * (M - 1)
     per_step_updates = (2 if args.mode == "fwdbwd" else 4) * cells
@@ -195,10 +237,13 @@ def main():
         line = {
             "metric": "DP cell-updates/sec (fwd+bwd)" if args.mode == "fwdbwd" else "DP cell-updates/sec (train: fwd+bwd+adjoint pair)",
             "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": float(np.median(per_step_ms)),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.variant.upper()} soft-DP {'fwd+bwd' if args.mode == 'fwdbwd' else 'decode+loss.backward'}"
-                                   f", B={B} per GPU, N={N}, M={M}, random theta/A (BASELINE.json configs[1])",
+                                   f", B={B} per GPU, N={N}, M={M}, random theta/A "
+                                   + ("(BASELINE.json configs[1])" if world == 1 else
+                                      f"(BASELINE.json configs[4] sharding: {B * world} pairs over {world} GPUs)"),
                        "global_batch": B * world, "N": N, "M": M, "variant": args.variant,
                        "parallelism": f"batch-sharded x{world}", "gather": args.gather if world > 1 else "none",
                        "arith": "fwd: scaled exp-domain f32 (exact power-of-two rescaling); bwd: f32; adjoint pair: f64 carries; f32 storage"},
@@ -209,6 +254,9 @@ def main():
                          "launch_ms": dom_ms,
                          "whole_step_frac": (per_step_updates * ALGO_BYTES_PER_CELL_UPDATE * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9)},
         }
+        if e_gather is not None:
+            line["with_e_gather"] = {"ms_per_step": e_gather * 1e3, "value": world * per_step_updates / e_gather,
+                                     "bytes_into_each_gpu": (world - 1) * B * N * M * 4}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
             line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

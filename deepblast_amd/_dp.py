@@ -27,10 +27,24 @@ def _validate(theta, A, operator, allow_none_operator):
     # error behaviour of the reference GPU variant (nw_cuda.py:171-175)
     if operator != 'softmax' and not (allow_none_operator and operator is None):
         raise NotImplementedError("HIP variant only supports 'softmax' operator")
-    if theta.dtype != torch.float32:
+    if theta.dtype != torch.float32 or A.dtype != torch.float32:
         raise TypeError("HIP variant only supports torch.float32 type")
     if theta.dim() != 3 or A.shape != theta.shape:
         raise ValueError(f"theta and A must both be (B, N, M); got {tuple(theta.shape)} and {tuple(A.shape)}")
+    if A.device != theta.device:
+        # the kernels receive raw pointers: a tensor on another device would be a foreign address
+        raise ValueError(f"theta and A must live on the same device; got {theta.device} and {A.device}")
+
+
+def _same_device(ref, **others):
+    """Raw pointers cross the C ABI: every tensor of a call must be fp32 on the device the kernel runs on."""
+    for name, t in others.items():
+        if t is None:
+            continue
+        if t.device != ref.device:
+            raise ValueError(f"{name} is on {t.device}, expected {ref.device}")
+        if t.dtype != torch.float32:
+            raise TypeError(f"{name} must be torch.float32, got {t.dtype}")
 
 
 def make_functions(variant, prefix, allow_none_operator=False):
@@ -41,6 +55,8 @@ def make_functions(variant, prefix, allow_none_operator=False):
         @staticmethod
         def forward(ctx, theta, A, Et, Q, operator, lens=None, exact_state=False):
             eng = _engine.get_engine()
+            if Et.device != theta.device:
+                raise ValueError(f"Et is on {Et.device}, expected {theta.device}")
             E = eng.backward(Et.detach(), Q, tuple(theta.shape), variant, lens, exact_state=exact_state)
             # exact state: the adjoint sweeps can use Q as it is; compact state: they need theta and A to get it
             if exact_state:
@@ -70,6 +86,7 @@ def make_functions(variant, prefix, allow_none_operator=False):
                 _, Q = eng.forward(theta.detach(), A.detach(), variant, lens, exact_state=True)
             if Ztheta is None:
                 Ztheta = torch.zeros_like(E)
+            _same_device(E, Ztheta=Ztheta, ZA=ZA)
             Vtd, Qd = eng.adjoint_forward(Q, Ztheta, ZA, variant, lens)
             Ed = eng.adjoint_backward(E, Q, Qd, variant, lens)
             return Ed, None, Vtd, None, None, None, None

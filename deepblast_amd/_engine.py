@@ -54,6 +54,17 @@ class HipEngine:
         return t.device.index if t.device.index is not None else torch.cuda.current_device()
 
     @staticmethod
+    def _check(ref, **tensors):
+        """The C ABI takes raw addresses: refuse anything that is not fp32 on the launch device."""
+        for name, t in tensors.items():
+            if t is None:
+                continue
+            if t.dtype != torch.float32:
+                raise TypeError(f"{name} must be torch.float32, got {t.dtype}")
+            if t.device != ref.device:
+                raise ValueError(f"{name} is on {t.device}, expected {ref.device}")
+
+    @staticmethod
     def _stream(dev):
         return torch.cuda.current_stream(dev).cuda_stream
 
@@ -81,6 +92,7 @@ class HipEngine:
         exact_state=False: the compact state the backward sweep reads; True: Q as float2, which the two
         adjoint sweeps need (include/sdp.h, SDP_EXACT_STATE)."""
         dev = self._dev(theta)
+        self._check(theta, theta=theta, A=A)
         theta, A = theta.contiguous(), A.contiguous()
         B, N, M = theta.shape
         lens = self._lens(lens, B, theta.device)
@@ -100,6 +112,8 @@ class HipEngine:
         exact_state: `state` came from forward(..., exact_state=True)."""
         dev = self._dev(state)
         B, N, M = shape
+        if Et.device != state.device:
+            raise ValueError(f"Et is on {Et.device}, expected {state.device}")
         Et = Et.to(torch.float32).expand(B).contiguous()
         lens = self._lens(lens, B, state.device)
         E = torch.empty((B, N, M), dtype=torch.float32, device=state.device)
@@ -112,6 +126,9 @@ class HipEngine:
     def adjoint_forward(self, state, Ztheta, ZA, variant, lens=None):
         """-> (Vtd (B,), state_d).  Replaces _adjoint_forward_pass_kernel (nw_cuda.py:134-139)."""
         dev = self._dev(state)
+        for name, t in (("Ztheta", Ztheta), ("ZA", ZA)):
+            if t is not None and t.device != state.device:
+                raise ValueError(f"{name} is on {t.device}, expected {state.device}")
         Ztheta = Ztheta.to(torch.float32).contiguous()
         B, N, M = Ztheta.shape
         if ZA is not None:
@@ -128,6 +145,7 @@ class HipEngine:
     def adjoint_backward(self, E, state, state_d, variant, lens=None):
         """-> Ed (B,N,M).  Replaces _adjoint_backward_pass_kernel (nw_cuda.py:160-165)."""
         dev = self._dev(state)
+        self._check(state, E=E, state_d=state_d)
         E = E.contiguous()
         B, N, M = E.shape
         lens = self._lens(lens, B, state.device)

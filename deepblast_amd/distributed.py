@@ -5,6 +5,12 @@ deepblast/nw.py:110), so the data path needs NO collective: every rank aligns it
 The only exchange is collecting results afterwards -- one all-gather of Vt (B floats) and,
 on request, of the expected-alignment matrices E.  `torch.distributed` backend "nccl" is RCCL
 on ROCm; on CPU test boxes the same code runs over "gloo".
+
+Two ways to cut a batch:
+  * `shard_bounds`  -- contiguous B/G slices (equal shapes: BASELINE.json configs[4]);
+  * `BalancedPlan`  -- for padded batches with per-pair lengths: pairs are dealt to ranks by work
+    n_b*m_b (longest first, snake order) so that every rank gets the same number of pairs and
+    nearly the same number of DP cells, and the gathered results are put back into batch order.
 """
 import numpy as np
 import torch
@@ -23,8 +29,8 @@ def balanced_assignment(work, world):
 
     Pairs are sorted by work (n_b * m_b) descending and dealt in a snake (0..G-1, G-1..0, ...),
     which keeps per-rank counts within one of each other and per-rank work within one pair of the
-    mean.  Returns (order, inverse): rank r takes order[r::world]-style slices via `take(r)`;
-    `inverse` restores the original batch order after a gather.
+    mean.  Returns (order, counts, inverse): rank r owns order[sum(counts[:r]) : sum(counts[:r+1])];
+    `inverse` restores the original batch order after a gather of the per-rank results.
     """
     work = np.asarray(work, dtype=np.int64)
     B = work.shape[0]
@@ -38,6 +44,41 @@ def balanced_assignment(work, world):
     inverse = np.empty(B, dtype=np.int64)
     inverse[order] = np.arange(B)
     return order, counts, inverse
+
+
+class BalancedPlan:
+    """Which pairs of a variable-length batch each rank aligns, and how to restore batch order.
+
+    Built from the global (B, 2) lengths, which every rank knows (it is the collate side-channel,
+    deepblast_amd/batching.py); deterministic, so every rank computes the same plan without talking.
+    Every rank aligns `per_rank` pairs: ranks that were dealt one pair fewer (B not a multiple of the
+    world size) pad with a 1x1 dummy pair, so the gather stays one fixed-size collective.
+    """
+
+    def __init__(self, lengths, world):
+        lengths = np.asarray(lengths.cpu() if isinstance(lengths, torch.Tensor) else lengths, dtype=np.int64)
+        if lengths.ndim != 2 or lengths.shape[1] != 2:
+            raise ValueError(f"lengths must be (B, 2), got {lengths.shape}")
+        self.B, self.world = int(lengths.shape[0]), int(world)
+        self.order, self.counts, _ = balanced_assignment(lengths[:, 0] * lengths[:, 1], world)
+        self.per_rank = int(self.counts.max()) if self.B else 0
+        self.offsets = np.concatenate([[0], np.cumsum(self.counts)])
+        # position of pair b in the gathered (world * per_rank) result
+        self.gathered_pos = np.empty(self.B, dtype=np.int64)
+        for r in range(world):
+            mine = self.order[self.offsets[r]:self.offsets[r + 1]]
+            self.gathered_pos[mine] = r * self.per_rank + np.arange(len(mine))
+        self.work_per_rank = np.array([int((lengths[self.indices(r), 0] * lengths[self.indices(r), 1]).sum())
+                                       for r in range(world)], dtype=np.int64)
+
+    def indices(self, rank):
+        """Global batch indices of the pairs `rank` aligns (longest first)."""
+        return self.order[self.offsets[rank]:self.offsets[rank + 1]]
+
+    def restore(self, gathered):
+        """(world * per_rank, ...) gathered results -> (B, ...) in the original batch order."""
+        idx = torch.as_tensor(self.gathered_pos, device=gathered.device)
+        return gathered.index_select(0, idx)
 
 
 def _all_gather_cat(x, group, async_op=False):
@@ -55,6 +96,20 @@ def _all_gather_cat(x, group, async_op=False):
     return (out, work) if async_op else out
 
 
+class PendingGather:
+    """Result of an asynchronous gather: `.wait()` makes the current stream wait for the collective and returns
+    the gathered tensor (in batch order when a plan was given)."""
+
+    def __init__(self, out, work, plan=None):
+        self._out, self._work, self._plan = out, work, plan
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self._plan.restore(self._out) if self._plan is not None else self._out
+
+
 class ShardedAligner:
     """Align this rank's shard and collect results from all ranks.
 
@@ -63,21 +118,37 @@ class ShardedAligner:
               Gathering E moves (G-1) x B/G x N x M x 4 bytes INTO every GPU over xGMI -- at
               B/G=256, N=M=512 that is 1.9 GB per rank and takes several times longer than
               computing it, so it is opt-in.
+    async_e : with gather="e", return `out["E"]` as a PendingGather instead of waiting: the collective runs on
+              RCCL's stream while the caller launches the next batch's sweeps (the gather is several times
+              longer than the compute, so the compute disappears under it).
     """
 
-    def __init__(self, decoder, group=None, gather="vt"):
+    def __init__(self, decoder, group=None, gather="vt", async_e=False):
         if gather not in ("vt", "e", "none"):
             raise ValueError("gather must be 'vt', 'e' or 'none'")
         self.decoder = decoder
         self.group = group
         self.gather = gather
+        self.async_e = async_e
         self._ones = None
 
-    def align(self, theta, A, lengths=None):
-        """theta, A: this rank's (B_local, N, M) shard.  Every rank must hold the same B_local
-        (pad the last shard) -- the all-gather is a single fixed-size collective.
+    def _world(self):
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
-        -> dict(Vt_local, E_local, Vt (world*B_local,) or None, E (world*B_local,N,M) or None)."""
+    def align(self, theta, A, lengths=None, plan=None):
+        """theta, A: this rank's (B_local, N, M) shard.  Every rank must hold the same B_local -- the all-gather
+        is a single fixed-size collective (use `pad_shard` or a BalancedPlan, which pads by itself).
+
+        lengths : (B_local, 2) per-pair sizes of a padded shard (lengths-aware decode), or None.
+        plan    : a BalancedPlan; theta/A/lengths are then this rank's `plan.indices(rank)` pairs (in that order),
+                  and the gathered results come back in the ORIGINAL batch order.
+
+        -> dict(Vt_local, E_local, Vt (B,) or None, E (B,N,M) | PendingGather | None)."""
+        n_real = theta.shape[0]
+        if plan is not None:
+            if lengths is None:
+                raise ValueError("a BalancedPlan needs the per-pair lengths of this rank's pairs")
+            theta, A, lengths = pad_shard(theta, A, lengths, plan.per_rank)
         theta = theta.detach().requires_grad_(True)
         Vt = self.decoder(theta, A, lengths) if lengths is not None else self.decoder(theta, A)
         # dVt.sum()/dtheta with the cotangent handed over directly: no reduction kernel and no expand/copy of
@@ -91,12 +162,25 @@ class ShardedAligner:
             # backward sweep computes E
             pending = _all_gather_cat(Vt.detach(), self.group, async_op=True)
         (E,) = torch.autograd.grad(Vt, theta, grad_outputs=self._ones)
-        out = {"Vt_local": Vt.detach(), "E_local": E, "Vt": None, "E": None}
+        out = {"Vt_local": Vt.detach()[:n_real], "E_local": E[:n_real], "Vt": None, "E": None}
         if gathering:
-            vt_all, work = pending
-            if work is not None:
-                work.wait()
-            out["Vt"] = vt_all
+            out["Vt"] = PendingGather(*pending, plan=plan).wait()
             if self.gather == "e":
-                out["E"] = _all_gather_cat(E, self.group)
+                e_pending = PendingGather(*_all_gather_cat(E, self.group, async_op=True), plan=plan)
+                out["E"] = e_pending if self.async_e else e_pending.wait()
         return out
+
+
+def pad_shard(theta, A, lengths, count):
+    """Pad a shard to `count` pairs with 1x1 dummy pairs (zeros, lengths (1,1)) so that every rank launches and
+    gathers the same shapes.  -> (theta, A, lengths as an int32 tensor on theta's device)."""
+    B = theta.shape[0]
+    lengths = torch.as_tensor(lengths, dtype=torch.int32, device=theta.device)
+    if B > count:
+        raise ValueError(f"shard has {B} pairs, more than the {count} it is padded to")
+    if B == count:
+        return theta, A, lengths
+    extra = count - B
+    zeros = theta.new_zeros((extra,) + tuple(theta.shape[1:]))
+    ones = torch.ones((extra, 2), dtype=torch.int32, device=theta.device)
+    return torch.cat([theta, zeros]), torch.cat([A, zeros]), torch.cat([lengths, ones])

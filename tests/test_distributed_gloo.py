@@ -63,6 +63,62 @@ def test_sharded_align_world2(tmp_path, gather):
             assert np.array_equal(d["E"], ref["E"])
 
 
+def _worker_balanced(rank, world, port, outdir):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deepblast_amd import _engine, NeedlemanWunschDecoder
+    from deepblast_amd.distributed import BalancedPlan, ShardedAligner
+    from fake_engine import OracleEngine
+    _engine._ENGINE = OracleEngine()
+    B, N, M = 7, 30, 26   # 7 pairs on 2 ranks: one rank pads with a dummy pair
+    theta, A = datagen.theta_A(43, B, N, M)
+    lens = datagen.lengths(44, B, 3, 26)
+    plan = BalancedPlan(lens, world)
+    mine = plan.indices(rank)
+    al = ShardedAligner(NeedlemanWunschDecoder("softmax"), gather="e")
+    out = al.align(torch.from_numpy(theta[mine]), torch.from_numpy(A[mine]), torch.from_numpy(lens[mine]), plan=plan)
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), Vt=out["Vt"].numpy(), E=out["E"].numpy(),
+             Vt_local=out["Vt_local"].numpy(), mine=mine)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_balanced_plan_world2_restores_batch_order(tmp_path):
+    """Variable-length batch: pairs dealt to ranks by work (LPT snake), uneven count padded with a dummy pair,
+    gathered Vt and E come back in the ORIGINAL batch order."""
+    import parity
+    world = 2
+    mp.spawn(_worker_balanced, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    theta, A = datagen.theta_A(43, 7, 30, 26)
+    lens = datagen.lengths(44, 7, 3, 26)
+    ref = parity.oracle_lens(theta, A, None, None, 0, lens)
+    seen = []
+    for r in range(world):
+        d = np.load(tmp_path / f"r{r}.npz")
+        assert d["Vt"].shape == (7,) and d["E"].shape == (7, 30, 26)
+        assert np.array_equal(d["Vt"], ref["Vt"]) and np.array_equal(d["E"], ref["E"])
+        assert np.array_equal(d["Vt_local"], ref["Vt"][d["mine"]])
+        seen += d["mine"].tolist()
+    assert sorted(seen) == list(range(7))
+
+
+def test_balanced_plan_balances_work():
+    from deepblast_amd.distributed import BalancedPlan
+    lens = datagen.lengths(2, 2048, 64, 1024)
+    plan = BalancedPlan(lens, 8)
+    assert plan.per_rank == 256 and sorted(np.concatenate([plan.indices(r) for r in range(8)]).tolist()) == list(range(2048))
+    assert plan.work_per_rank.max() / plan.work_per_rank.min() < 1.01
+    g = torch.arange(8 * 256)   # a "gathered" tensor holding its own position
+    back = plan.restore(g).numpy()
+    for r in range(8):
+        assert np.array_equal(back[plan.indices(r)], r * 256 + np.arange(256))
+
+
 def test_shard_bounds_cover_batch():
     for B in (1, 7, 8, 256, 2048):
         for world in (1, 2, 3, 8):

@@ -1,0 +1,94 @@
+"""GPU, needs >= 2 devices (skipped on the 1-GPU box): the N>1 path on RCCL -- two ranks, one per GPU, each
+aligning its shard with the HIP engine; gathered Vt / E against the CPU oracle, contiguous and balanced shards."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import datagen
+
+pytestmark = pytest.mark.gpu
+
+
+def _ndev():
+    try:
+        return torch.cuda.device_count() if torch.cuda.is_available() else 0
+    except Exception:
+        return 0
+
+
+needs2 = pytest.mark.skipif(_ndev() < 2, reason="needs >= 2 ROCm devices")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, mode, outdir):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from deepblast_amd import NeedlemanWunschDecoder
+    from deepblast_amd.distributed import BalancedPlan, ShardedAligner, shard_bounds
+    B, N, M = 10, 150, 130
+    theta, A = datagen.theta_A(45, B, N, M)
+    al = ShardedAligner(NeedlemanWunschDecoder("softmax"), gather="e", async_e=(mode == "balanced"))
+    if mode == "contiguous":
+        lo, hi = shard_bounds(B, world, rank)
+        out = al.align(torch.from_numpy(theta[lo:hi]).to(dev), torch.from_numpy(A[lo:hi]).to(dev))
+        E = out["E"]
+    else:
+        lens = datagen.lengths(46, B, 5, 130)
+        plan = BalancedPlan(lens, world)
+        mine = plan.indices(rank)
+        out = al.align(torch.from_numpy(theta[mine]).to(dev), torch.from_numpy(A[mine]).to(dev),
+                       torch.from_numpy(lens[mine]).to(dev), plan=plan)
+        E = out["E"].wait()   # asynchronous gather handle
+    torch.cuda.synchronize()
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), Vt=out["Vt"].cpu().numpy(), E=E.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@needs2
+@pytest.mark.parametrize("mode", ["contiguous", "balanced"])
+def test_sharded_align_two_ranks_rccl(tmp_path, mode):
+    import parity
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+    theta, A = datagen.theta_A(45, 10, 150, 130)
+    if mode == "contiguous":
+        ref = parity.oracle_all(theta, A, None, None, 0, omp=False)
+    else:
+        ref = parity.oracle_lens(theta, A, None, None, 0, datagen.lengths(46, 10, 5, 130))
+    for r in range(world):
+        d = np.load(tmp_path / f"r{r}.npz")
+        assert parity.rel_err(d["Vt"], ref["Vt"]) <= parity.TOL
+        assert parity.abs_err(d["E"], ref["E"]) <= parity.TOL
+
+
+def test_bench_refuses_more_gpus_than_present():
+    """`python bench.py --gpus N` creates its own ranks and must fail loudly -- not time fewer GPUs -- when the node
+    has fewer than N devices."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = _ndev() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "device(s) visible" in (r.stderr + r.stdout)
+    assert '"n_gpus"' not in r.stdout
