@@ -40,6 +40,22 @@ class HipEngine:
         # optional profiling hook (bench.py): callable(name) -> context manager that brackets one
         # kernel launch on the current stream, e.g. with a pair of events.  None = no overhead.
         self.launch_hook = None
+        # per-pass wave-count override for experiments and tests ({0 fwd, 1 bwd, 2 adj-fwd, 3 adj-bwd} -> waves);
+        # travels with each call as SDP_WAVES(w), the library keeps no tuning state
+        self.force_waves = {}
+
+    def _v(self, pass_, variant):
+        w = self.force_waves.get(pass_, 0)
+        return variant | (_lib.SDP_WAVES(w) if w else 0)
+
+    def check_device(self, device=None):
+        """Raise HandoffTimeout if a kernel launched earlier on `device` reported a strip hand-off that timed out.
+        Host-side read: synchronise first to cover work that is still in flight."""
+        import ctypes
+        dev = torch.cuda.current_device() if device is None else device
+        info = (ctypes.c_int32 * 4)()
+        _lib.check(self.lib.sdp_device_status(dev, info), "sdp_device_status")
+        return list(info)
 
     def _bracket(self, name):
         return self.launch_hook(name) if self.launch_hook is not None else _NULL_CTX
@@ -102,7 +118,7 @@ class HipEngine:
         Vt = torch.empty(B, dtype=torch.float32, device=theta.device)
         with torch.cuda.device(dev), self._bracket("sdp_fwd_kernel"):
             rc = self.lib.sdp_forward_f32(_ptr(theta), _ptr(A), _ptr(state), _ptr(Vt), B, N, M, _ptr(lens),
-                                          variant, dev, self._stream(dev))
+                                          self._v(0, variant), dev, self._stream(dev))
         _lib.check(rc, "sdp_forward_f32")
         return Vt, state
 
@@ -119,7 +135,7 @@ class HipEngine:
         E = torch.empty((B, N, M), dtype=torch.float32, device=state.device)
         with torch.cuda.device(dev), self._bracket("sdp_bwd_kernel"):
             rc = self.lib.sdp_backward_f32(_ptr(Et), _ptr(state), _ptr(E), B, N, M, _ptr(lens),
-                                           variant | (EXACT_STATE if exact_state else 0), dev, self._stream(dev))
+                                           self._v(1, variant) | (EXACT_STATE if exact_state else 0), dev, self._stream(dev))
         _lib.check(rc, "sdp_backward_f32")
         return E
 
@@ -138,7 +154,7 @@ class HipEngine:
         Vtd = torch.empty(B, dtype=torch.float32, device=state.device)
         with torch.cuda.device(dev), self._bracket("sdp_adj_fwd_kernel"):
             rc = self.lib.sdp_adjoint_forward_f32(_ptr(state), _ptr(Ztheta), _ptr(ZA), _ptr(Vtd), _ptr(state_d),
-                                                  B, N, M, _ptr(lens), variant, dev, self._stream(dev))
+                                                  B, N, M, _ptr(lens), self._v(2, variant), dev, self._stream(dev))
         _lib.check(rc, "sdp_adjoint_forward_f32")
         return Vtd, state_d
 
@@ -152,7 +168,7 @@ class HipEngine:
         Ed = torch.empty((B, N, M), dtype=torch.float32, device=state.device)
         with torch.cuda.device(dev), self._bracket("sdp_adj_bwd_kernel"):
             rc = self.lib.sdp_adjoint_backward_f32(_ptr(E), _ptr(state), _ptr(state_d), _ptr(Ed), B, N, M,
-                                                   _ptr(lens), variant, dev, self._stream(dev))
+                                                   _ptr(lens), self._v(3, variant), dev, self._stream(dev))
         _lib.check(rc, "sdp_adjoint_backward_f32")
         return Ed
 

@@ -41,15 +41,28 @@ SIGNATURES = {
     "sdp_loss_backward_f32": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_i32p, _c_f32p, _c_f32p, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "sdp_selftest": (ctypes.c_int, [ctypes.c_int]),
-    "sdp_probe": (ctypes.c_int, [ctypes.c_int]),
-    "sdp_set_waves": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "sdp_device_status": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int32)]),
 }
+# only in -DSDP_EXPERIMENTS builds (deepblast_amd/libsdp_hip_exp.so; never the shipped library)
+EXPERIMENT_SIGNATURES = {
+    "sdp_set_debug": (ctypes.c_int, [ctypes.c_int]),
+}
+
+
+def SDP_WAVES(w):
+    """include/sdp.h: or-ed into `variant`, run with w wavefronts per pair."""
+    return (int(w) & 0xf) << 12
 
 _LIB = None
 
 
 class SdpLibraryMissing(ImportError):
     pass
+
+
+class HandoffTimeout(RuntimeError):
+    """SDP_E_HANDOFF: a kernel of an earlier launch gave up waiting for a strip hand-off; that launch's results
+    are invalid (include/sdp.h)."""
 
 
 def load():
@@ -61,13 +74,22 @@ def load():
                 f"{LIB_PATH} not found: the HIP engine is not built. Run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (or deepblast_amd/build.py). "
                 "deepblast_amd has no CPU fallback.")
-        lib = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)
-            fn.restype = res
-            fn.argtypes = args
-        _LIB = lib
+        _LIB = load_path(LIB_PATH)
     return _LIB
+
+
+def load_path(path):
+    """A fresh, bound handle of the library at `path` (tests load the -DSDP_EXPERIMENTS build next to the shipped one)."""
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    for name, (res, args) in EXPERIMENT_SIGNATURES.items():
+        if hasattr(lib, name):
+            getattr(lib, name).restype = res
+            getattr(lib, name).argtypes = args
+    return lib
 
 
 def check(rc, what):
@@ -79,4 +101,6 @@ def check(rc, what):
         raise ValueError(f"{what}: {msg}")
     if rc in (-1, -2, -4, -5):
         raise ValueError(f"{what}: {msg}")
+    if rc == -7:
+        raise HandoffTimeout(f"{what}: {msg}")
     raise RuntimeError(f"{what}: {msg} (status {rc})")

@@ -39,5 +39,17 @@ def build(force=False, extra=(), out=None):
     return OUT
 
 
+EXP_OUT = os.path.join(HERE, "libsdp_hip_exp.so")
+
+
+def build_experiments(force=False):
+    """The -DSDP_EXPERIMENTS build (sdp_set_debug: wrong-results timing switches, forced hand-off time-outs).
+    Test and tuning infrastructure; the package never loads it."""
+    newest = max(os.path.getmtime(f) for f in SRC + HDR)
+    if not force and os.path.exists(EXP_OUT) and os.path.getmtime(EXP_OUT) >= newest:
+        return EXP_OUT
+    return build(True, extra=("-DSDP_EXPERIMENTS",), out=EXP_OUT) or EXP_OUT
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))

@@ -1,18 +1,49 @@
 // sdp_api.hip -- host side of the C ABI declared in include/sdp.h.
 // Validates arguments, sizes the launch and enqueues one kernel per call on the
-// caller's stream.  No allocation, no synchronisation, no global mutable state
-// besides the experiment knob sdp_set_waves().
+// caller's stream.  No device allocation, no synchronisation.  Process-wide state: one 64-byte block of
+// host-pinned status words per device (created on the first launch there), through which a kernel reports a
+// strip hand-off that timed out; the experiment switches (sdp_set_debug) exist only in -DSDP_EXPERIMENTS builds.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+
+#include <atomic>
+#include <mutex>
 
 #include "sdp_kernels.h"
 
 namespace {
 
 thread_local char g_err[256] = "";
-int g_waves[4] = {0, 0, 0, 0};
-int g_dbg = 0;
+#ifdef SDP_EXPERIMENTS
+std::atomic<int> g_dbg{0};
+#endif
+
+// ---- per-device status words (host-pinned, device-visible) ----
+constexpr int MAX_DEV = 64;
+std::mutex g_status_mu;
+int *g_status_host[MAX_DEV] = {nullptr};
+int *g_status_dev[MAX_DEV] = {nullptr};
+std::atomic<int> g_status_seen[MAX_DEV];  // time-outs already reported to the caller
+
+int *status_words(int device)  // device pointer, or nullptr (then kernels cannot report)
+{
+    if (device < 0 || device >= MAX_DEV) return nullptr;
+    std::lock_guard<std::mutex> lk(g_status_mu);
+    if (!g_status_dev[device]) {
+        int *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return nullptr;
+        memset(h, 0, 64);
+        if (hipHostGetDevicePointer((void **)&d, h, 0) != hipSuccess) {
+            (void)hipHostFree(h);
+            return nullptr;
+        }
+        g_status_host[device] = h;
+        g_status_dev[device] = d;
+        g_status_seen[device] = 0;
+    }
+    return g_status_dev[device];
+}
 
 int fail(int code, const char *msg)
 {
@@ -124,15 +155,51 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
     return {v, W, lds, off};
 }
 
-int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state = false)
+// A kernel of an EARLIER call on this device gave up waiting for a strip hand-off: its results are wrong.  Reported
+// once, by the next call on the device (or by sdp_device_status), as SDP_E_HANDOFF.
+int pending_handoff_error(int device)
+{
+    if (device < 0 || device >= MAX_DEV || !g_status_host[device]) return 0;
+    const volatile int *h = g_status_host[device];
+    const int n = h[0];
+    if (n == g_status_seen[device].load()) return 0;
+    g_status_seen[device] = n;
+    snprintf(g_err, sizeof(g_err),
+             "a strip hand-off timed out in an earlier launch on device %d (%d so far; first: pair %d, strip %d, chunk %d, "
+             "pass %d): the results of that launch are invalid",
+             device, n, h[1], h[2], h[3] & 0xffffff, (h[3] >> 24) & 0xff);
+    return SDP_E_HANDOFF;
+}
+
+// flags or-ed into `variant` (include/sdp.h): SDP_EXACT_STATE, SDP_WAVES(w)
+struct VariantBits {
+    int variant, waves;
+    bool exact;
+};
+VariantBits split_variant(int variant)
+{
+    VariantBits v;
+    v.exact = (variant & SDP_EXACT_STATE) != 0;
+    v.waves = (variant >> 12) & 0xf;
+    v.variant = variant & ~(SDP_EXACT_STATE | (0xf << 12));
+    return v;
+}
+
+int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state = false, int forced_waves = 0)
 {
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    if (int rc = pending_handoff_error(device)) return rc;
     p.nstrips_max = sdp::state_nstrips(p.N);
     p.tpad = sdp::state_tpad(p.M);
     p.mcap = (p.M + 63) / 64 * 64;
-    p.dbg = g_dbg;
-    const Plan pl = plan(pass, p.B, p.N, p.M, p.lens != nullptr, exact_state, num_cus(device), g_waves[pass]);
+    p.status = status_words(device);
+#ifdef SDP_EXPERIMENTS
+    p.dbg = g_dbg.load();
+#else
+    p.dbg = 0;
+#endif
+    const Plan pl = plan(pass, p.B, p.N, p.M, p.lens != nullptr, exact_state, num_cus(device), forced_waves);
     const Variant v = pl.v;
     const int W = pl.W;
     const size_t lds = pl.lds, off = pl.stage_off;
@@ -187,25 +254,31 @@ int sdp_plan(int pass, int B, int N, int M, int has_lens, int exact_state, int c
     return 0;
 }
 
-int sdp_set_waves(int pass, int waves)
+int sdp_device_status(int device, int32_t info[4])
 {
-    if (pass == 100) {  // experiment switches, see Params::dbg
-        const int old = g_dbg;
-        g_dbg = waves;
-        return old;
+    if (device < 0 || device >= MAX_DEV || !g_status_host[device]) {
+        if (info) info[0] = info[1] = info[2] = info[3] = 0;
+        return 0;
     }
-    if (pass < 0 || pass > 3) return -1;
-    const int old = g_waves[pass];
-    g_waves[pass] = waves;
-    return old;
+    const volatile int *h = g_status_host[device];
+    if (info) info[0] = h[0], info[1] = h[1], info[2] = h[2], info[3] = h[3];
+    return pending_handoff_error(device);
 }
+
+#ifdef SDP_EXPERIMENTS
+int sdp_set_debug(int mask)
+{
+    return g_dbg.exchange(mask);
+}
+#endif
 
 int sdp_forward_f32(const float *theta, const float *A, float *state, float *Vt, int B, int N, int M,
                     const int32_t *lens, int variant, int device, void *stream)
 {
     if (!theta || !A || !state || !Vt) return fail(SDP_E_NULLPTR, "sdp_forward_f32: null pointer");
-    const bool exact = (variant & SDP_EXACT_STATE) != 0;
-    variant &= ~SDP_EXACT_STATE;
+    const VariantBits vb = split_variant(variant);
+    const bool exact = vb.exact;
+    variant = vb.variant;
     if (int rc = check_shape(B, N, M, variant)) return rc;
     sdp::Params p = {};
     p.sin0 = theta;
@@ -214,15 +287,16 @@ int sdp_forward_f32(const float *theta, const float *A, float *state, float *Vt,
     p.vout = Vt;
     p.lens = lens;
     p.B = B, p.N = N, p.M = M, p.variant = variant;
-    return launch(sdp::PASS_FWD, p, device, stream, exact);
+    return launch(sdp::PASS_FWD, p, device, stream, exact, vb.waves);
 }
 
 int sdp_backward_f32(const float *Et, const float *state, float *E, int B, int N, int M, const int32_t *lens,
                      int variant, int device, void *stream)
 {
     if (!Et || !state || !E) return fail(SDP_E_NULLPTR, "sdp_backward_f32: null pointer");
-    const bool exact = (variant & SDP_EXACT_STATE) != 0;
-    variant &= ~SDP_EXACT_STATE;
+    const VariantBits vb = split_variant(variant);
+    const bool exact = vb.exact;
+    variant = vb.variant;
     if (int rc = check_shape(B, N, M, variant)) return rc;
     if (lens) {
         hipError_t e = hipSetDevice(device);
@@ -235,13 +309,15 @@ int sdp_backward_f32(const float *Et, const float *state, float *E, int B, int N
     p.sout = E;
     p.lens = lens;
     p.B = B, p.N = N, p.M = M, p.variant = variant;
-    return launch(sdp::PASS_BWD, p, device, stream, exact);
+    return launch(sdp::PASS_BWD, p, device, stream, exact, vb.waves);
 }
 
 int sdp_adjoint_forward_f32(const float *state, const float *Ztheta, const float *ZA, float *Vtd, float *state_d,
                             int B, int N, int M, const int32_t *lens, int variant, int device, void *stream)
 {
     if (!state || !Ztheta || !Vtd || !state_d) return fail(SDP_E_NULLPTR, "sdp_adjoint_forward_f32: null pointer");
+    const VariantBits vb = split_variant(variant);
+    variant = vb.variant;
     if (int rc = check_shape(B, N, M, variant)) return rc;
     sdp::Params p = {};
     p.qin = reinterpret_cast<const uint32_t *>(state);
@@ -251,13 +327,15 @@ int sdp_adjoint_forward_f32(const float *state, const float *Ztheta, const float
     p.vout = Vtd;
     p.lens = lens;
     p.B = B, p.N = N, p.M = M, p.variant = variant;
-    return launch(sdp::PASS_AFWD, p, device, stream);
+    return launch(sdp::PASS_AFWD, p, device, stream, false, vb.waves);
 }
 
 int sdp_adjoint_backward_f32(const float *E, const float *state, const float *state_d, float *Ed, int B, int N,
                              int M, const int32_t *lens, int variant, int device, void *stream)
 {
     if (!E || !state || !state_d || !Ed) return fail(SDP_E_NULLPTR, "sdp_adjoint_backward_f32: null pointer");
+    const VariantBits vb = split_variant(variant);
+    variant = vb.variant;
     if (int rc = check_shape(B, N, M, variant)) return rc;
     if (lens) {
         hipError_t e = hipSetDevice(device);
@@ -271,7 +349,7 @@ int sdp_adjoint_backward_f32(const float *E, const float *state, const float *st
     p.sout = Ed;
     p.lens = lens;
     p.B = B, p.N = N, p.M = M, p.variant = variant;
-    return launch(sdp::PASS_ABWD, p, device, stream);
+    return launch(sdp::PASS_ABWD, p, device, stream, false, vb.waves);
 }
 
 int sdp_traceback_capacity(int N, int M) { return (N > 0 && M > 0) ? N + M + 2 : 0; }
@@ -323,13 +401,6 @@ int sdp_loss_backward_f32(const float *ref, const float *pred, const float *G, c
     return 0;
 }
 
-static int g_probe = -1;
-
-int sdp_probe(int device)
-{
-    if (g_probe < 0) (void)sdp_selftest(device);
-    return g_probe;
-}
 
 int sdp_selftest(int device)
 {
@@ -351,7 +422,6 @@ int sdp_selftest(int device)
         if (h[64 + i] != 1000 + i) bad |= 128;   // in-range stores must land
     for (int i = 128; i < 192; ++i)
         if (h[i] != 7777) bad |= 256;            // out-of-range stores must be dropped
-    g_probe = (h[192] == 0) ? 1 : 0;  // bit0: scalar offset takes part in the buffer range check
     if (bad) {
         snprintf(g_err, sizeof(g_err), "sdp_selftest: hardware semantics mismatch, mask 0x%x", bad);
         return SDP_E_SELFTEST;

@@ -86,7 +86,9 @@ struct Params {
     int mcap;            // doubles per boundary row in LDS
     int stage_off;       // byte offset of the per-wave staging area in LDS
     int variant;
-    int dbg;             // experiment switches (sdp_set_waves pass 100): bit0 inputs, bit1 outputs, bit2 state: all pairs alias pair 0
+    int dbg;             // experiments build only (sdp_set_debug): bit0 inputs, bit1 outputs, bit2 state: all pairs alias
+                         // pair 0; bit3: strips never publish their progress (exercises the hand-off time-out)
+    int *status;         // host-visible status words of the device: [0] hand-off time-outs, [1..3] first (pair, strip, chunk | pass << 24)
 };
 
 // per-wave LDS staging (floats): input planes are rings [64][2K], the output ring is [64][2K+1]

@@ -90,6 +90,11 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #ifndef SDP_ABL
 #define SDP_ABL 0
 #endif
+#ifdef SDP_EXPERIMENTS
+#define SDP_EXP_BUILD 1
+#else
+#define SDP_EXP_BUILD 0  // default library: Params::dbg is ignored, no wrong-results switch is reachable
+#endif
 #ifndef SDP_PREPASS
 #define SDP_PREPASS 1
 #endif
@@ -205,6 +210,23 @@ __device__ __forceinline__ float2 q_unpack(const unsigned *w, int second)
 {
     if (second) return make_float2(q_field(__builtin_amdgcn_perm(w[2], w[1], 0x0c040302u)), q_field(w[2] >> 8));
     return make_float2(q_field(w[0]), q_field(__builtin_amdgcn_perm(w[1], w[0], 0x0c050403u)));
+}
+
+// Exact-state weights: the largest of the three is formed as 1 - (the other two).  c/sum*u goes through an
+// approximate reciprocal and two products (~1.5 ulp): harmless for a weight of 0.3, but a weight that the reference
+// -- which divides in float64 and rounds once (nw.py:21-22,115) -- stores as exactly 1.0 would come out as
+// 1 +- 1e-7, and the adjoint sweeps turn such an error into (1 - q) * a, relative to a difference that should be
+// 0: on long, peaked alignments it reached 1e-3 of Ed.  The small weights carry the same relative error, so the
+// complement is accurate to 1e-7 * (1 - q).  When the match weight qm is the largest nothing has to be done: the
+// readers form qm = 1 - qx - qy anyway.
+__device__ __forceinline__ void q_sharpen(float &wx, float &wy, float wm)
+{
+    const float big = __builtin_fmaxf(wx, wy), small = __builtin_fminf(wx, wy);
+    const float o = 1.0f - (small + wm);
+    const float nb = big > 0.5f ? o : big;
+    const bool xbig = wx >= wy;
+    wx = xbig ? nb : wx;
+    wy = xbig ? wy : nb;
 }
 
 // ----------------------------------------------------------------------------------
@@ -348,13 +370,16 @@ __device__ __forceinline__ void sweep(const Params &p)
     float *lds_out = stage + T::SIN * PLANE;
 
     if (threadIdx.x < (unsigned)W) lds_store_i32(prog + 4 * threadIdx.x, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the store above is inline asm: the compiler's own counter tracking does not see it
     __syncthreads();
     if (wave >= nstrips) return;
 
     // ---- per-pair tensor descriptors ----
     const size_t plane_elems = (size_t)p.N * p.M;
     const unsigned plane_bytes = (unsigned)(plane_elems * 4);
-    const size_t b_in = (p.dbg & 1) ? 0 : b, b_out = (p.dbg & 2) ? 0 : b, b_st = (p.dbg & 4) ? 0 : b;
+    // experiments build only (sdp_set_debug): all pairs alias pair 0 -- every access is served from cache
+    const size_t b_in = (SDP_EXP_BUILD && (p.dbg & 1)) ? 0 : b, b_out = (SDP_EXP_BUILD && (p.dbg & 2)) ? 0 : b,
+                 b_st = (SDP_EXP_BUILD && (p.dbg & 4)) ? 0 : b;
     __amdgpu_buffer_rsrc_t rs_in[NS];
     if constexpr (T::SIN > 0) {
         rs_in[0] = make_rsrc(p.sin0 + b_in * plane_elems, plane_bytes);
@@ -655,11 +680,22 @@ __device__ __forceinline__ void sweep(const Params &p)
                     }
                 }
                 if (need > 0) {
-                    // bounded spin: a missed hand-off must never hang the device (results would be wrong,
-                    // which the parity tests catch); ~0.2 s at the cap
-                    for (int spin = 0; !ABL_NOSYNC && spin < (1 << 21); ++spin) {
-                        if (__builtin_amdgcn_readfirstlane(lds_load_i32(prog + 4 * pword)) >= pbase + need) break;
+                    // bounded spin: a missed hand-off must never hang the device (~0.2 s at the cap).  If it ever
+                    // gives up the results of this pair are wrong, so the wave says so in the status words the host
+                    // checks on its next call (sdp_api.hip: SDP_E_HANDOFF) -- it does not carry on silently.
+                    bool ready = ABL_NOSYNC;
+                    const int spin_cap = (SDP_EXP_BUILD && (p.dbg & 8)) ? (1 << 10) : (1 << 21);
+                    for (int spin = 0; !ABL_NOSYNC && spin < spin_cap; ++spin) {
+                        if (__builtin_amdgcn_readfirstlane(lds_load_i32(prog + 4 * pword)) >= pbase + need) {
+                            ready = true;
+                            break;
+                        }
                         __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (!ready && p.status && lane == 0) {
+                        if (__hip_atomic_fetch_add(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+                            p.status[1] = b, p.status[2] = s, p.status[3] = c | (PASS << 24);
+                        }
                     }
                     if (c_lo >= 0 && c_lo + K <= m) {
 #pragma unroll
@@ -793,9 +829,11 @@ __device__ __forceinline__ void sweep(const Params &p)
                         const float l = __builtin_amdgcn_ldexpf(cy.xa, ey - er);
                         const float d = __builtin_amdgcn_ldexpf(cy.da, ed - er);
                         const float ssum = __builtin_fmaf(ca, u + l, d);  // the operand with the largest exponent is unshifted
-                        const float tq = ca * __builtin_amdgcn_rcpf(ssum);
+                        const float rinv = __builtin_amdgcn_rcpf(ssum);
+                        const float tq = ca * rinv;
                         {
                             float2 qq = make_float2(tq * u, tq * l);
+                            if constexpr (QX) q_sharpen(qq.x, qq.y, d * rinv);
                             if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
                         }
                         const float an = ct * ssum;
@@ -996,9 +1034,11 @@ __device__ __forceinline__ void sweep(const Params &p)
                         const float ua = __uint_as_float(dpp_i32<DPP_IN>(__float_as_int(bf[j]), __float_as_int(x)));
                         const float u = ua * sc;
                         const float ssum = __builtin_fmaf(ca, u + x, d);
-                        const float tq = ca * __builtin_amdgcn_rcpf(ssum);
+                        const float rinv = __builtin_amdgcn_rcpf(ssum);
+                        const float tq = ca * rinv;
                         {
                             float2 qq = make_float2(tq * u, tq * x);
+                            if constexpr (QX) q_sharpen(qq.x, qq.y, d * rinv);
                             if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
                         }
                         d = u;
@@ -1120,7 +1160,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         for (int sb = 0; sb < K / WB; ++sb) frm_out[c * (K / WB) + sb] = wf_frames[sb];
                     }
                 }
-                if (lane == PUB_LANE) lds_store_i32(prog + 4 * oword, obase + done);
+                if (lane == PUB_LANE && !(SDP_EXP_BUILD && (p.dbg & 8))) lds_store_i32(prog + 4 * oword, obase + done);
             }
 
             // ---- flush: one K-column aligned block per row (see fo_* above) ----

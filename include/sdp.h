@@ -44,7 +44,11 @@
  *     stream).  Calls only enqueue work; they never synchronise.
  *   - Return: 0 ok; negative = SDP_E_* below; positive = hipError_t.  Nothing is
  *     thrown across the boundary.  sdp_last_error_string() is thread-local.
- *   - Re-entrant: no global mutable state besides a per-thread error string.
+ *   - Re-entrant: calls from several threads / on several streams may overlap.  Process-wide state is limited
+ *     to a per-thread error string and one 64-byte block of host-pinned status words per device (created on
+ *     the first launch there) through which a kernel reports a strip hand-off that timed out: such a launch's
+ *     results are invalid, and the NEXT call on that device (or sdp_device_status) returns SDP_E_HANDOFF once.
+ *     There is no tuning state: a wave-count override travels with the call (SDP_WAVES).
  */
 #ifndef SDP_H_
 #define SDP_H_
@@ -73,6 +77,11 @@ extern "C" {
 #define SDP_E_VARIANT (-4)  /* variant is neither SDP_NW nor SDP_SW */
 #define SDP_E_TOOBIG (-5)   /* a tensor exceeds the 4 GiB-per-plane addressing limit */
 #define SDP_E_SELFTEST (-6) /* sdp_selftest found a hardware-semantics mismatch */
+#define SDP_E_HANDOFF (-7)  /* an earlier launch on this device timed out waiting for a strip hand-off: its results are invalid */
+
+/* or-ed into `variant` of the four sweeps: run with w (1..8) wavefronts per pair instead of the automatic choice
+ * (clamped to what the kernel build and the problem allow).  Results do not depend on it (bit-identical). */
+#define SDP_WAVES(w) (((w) & 0xf) << 12)
 
 int sdp_version(void);
 
@@ -134,9 +143,10 @@ int sdp_loss_backward_f32(const float *ref, const float *pred, const float *G, c
  * behaviour the kernels rely on.  Synchronises the device.  0 = ok. */
 int sdp_selftest(int device);
 
-/* Diagnostic: bit0 = the buffer instructions' scalar offset takes part in the hardware range check
- * on this device (runs sdp_selftest on first use). */
-int sdp_probe(int device);
+/* Status words of `device`: info[0] = strip hand-offs that timed out since the library was loaded, info[1..3] =
+ * pair, strip, chunk | pass << 24 of the first one.  Returns SDP_E_HANDOFF if there are time-outs that no call has
+ * reported yet, else 0.  Host-side read, no synchronisation: synchronise the stream first to cover its launches. */
+int sdp_device_status(int device, int32_t info[4]);
 
 /* Diagnostic: what a launch of pass (0 fwd, 1 bwd, 2 adj-fwd, 3 adj-bwd) would use on a device with `cus` compute
  * units -- kernel build (0 fwd throughput, 1 bwd throughput, 2 adj-fwd, 3 adj-bwd, 4 bwd latency, 5 fwd exact
@@ -146,9 +156,12 @@ int sdp_probe(int device);
 int sdp_plan(int pass, int B, int N, int M, int has_lens, int exact_state, int cus, int *kernel_id, int *chunk,
              int *waves, size_t *lds);
 
-/* Tuning knob for experiments: waves per workgroup (0 = automatic). Returns previous value.
- * Process-wide, not part of the drop-in surface. */
-int sdp_set_waves(int pass /*0 fwd,1 bwd,2 adj-fwd,3 adj-bwd*/, int waves);
+#ifdef SDP_EXPERIMENTS
+/* Only in libraries built with -DSDP_EXPERIMENTS (never the shipped one): timing experiments that produce WRONG
+ * results.  bit0/1/2: inputs / outputs / state of every pair alias pair 0 (all traffic cache-served); bit3: strips
+ * never publish their progress, so every hand-off times out (tests the SDP_E_HANDOFF path).  Returns the old mask. */
+int sdp_set_debug(int mask);
+#endif
 
 #ifdef __cplusplus
 }

@@ -15,9 +15,14 @@ def lib():
     return _lib.load()
 
 
-def _declared():
+def _declared(experiments=False):
     src = open(os.path.join(ROOT, "include", "sdp.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    exp = re.findall(r"#ifdef SDP_EXPERIMENTS(.*?)#endif", src, flags=re.S)
+    if experiments:
+        src = "".join(exp)
+    else:
+        src = re.sub(r"#ifdef SDP_EXPERIMENTS.*?#endif", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(sdp_[a-z0-9_]+)\s*\(", src)))
 
 
@@ -29,6 +34,11 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), f"{n} declared in include/sdp.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
+    # the shipped library has no experiment switches (no wrong-results knob reachable through the ABI)
+    for n in _declared(experiments=True):
+        assert n in _lib.EXPERIMENT_SIGNATURES and not hasattr(lib, n), n
+    for gone in ("sdp_set_waves", "sdp_probe"):
+        assert not hasattr(lib, gone)
 
 
 def test_version_and_limits(lib):
@@ -56,7 +66,11 @@ def test_argument_errors_need_no_gpu(lib):
     assert lib.sdp_backward_f32(one, one, None, 1, 1, 1, None, 0, 0, None) == -1
     assert lib.sdp_adjoint_forward_f32(one, None, None, one, one, 1, 1, 1, None, 0, 0, None) == -1
     assert lib.sdp_adjoint_backward_f32(one, one, one, one, 1, 1, 1 << 20, None, 0, 0, None) == -3
-    assert lib.sdp_set_waves(9, 1) == -1
+    # flags in `variant` (SDP_EXACT_STATE, SDP_WAVES) are stripped before validation; junk above them is not
+    assert lib.sdp_forward_f32(one, one, one, one, 0, 1, 1, None, 0x100 | (8 << 12), 0, None) == -2
+    assert lib.sdp_forward_f32(one, one, one, one, 1, 1, 1, None, 1 << 20, 0, None) == -4
+    info = (ctypes.c_int32 * 4)()
+    assert lib.sdp_device_status(0, info) == 0 and list(info) == [0, 0, 0, 0]   # nothing launched: no status block
 
 
 def _plan(lib, pass_, B, N, M, lens=0, exact=0, cus=256):

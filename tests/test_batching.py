@@ -37,3 +37,28 @@ def test_lengths_from_unpacked():
     assert out.dtype == torch.int32 and out.tolist() == [[3, 4], [5, 2]]
     with pytest.raises(ValueError):
         lengths_from_unpacked(torch.tensor([3, 5]), torch.tensor([4]))
+
+
+def _fixture_batch(golden_dir):
+    import os
+    d = np.load(os.path.join(golden_dir, "g10_batching.npz"))
+    batch = []
+    for b in range(len(d["sizes"])):
+        batch.append(tuple(torch.from_numpy(d[f"i{b}_{k}"]) for k in ("gene", "other", "states", "aln", "path", "mask", "gm", "om")))
+    return d, batch
+
+
+def test_collate_reproduces_the_reference_fixture(golden_dir):
+    """tests/golden/g10_batching.npz holds what the REAL collate_f / pack_sequences / unpack_sequences
+    (deepblast/dataset/utils.py:214-281) returned for these items (oracle/gen_golden_batching.py)."""
+    d, batch = _fixture_batch(golden_dir)
+    genes, others, states, dm, p, G, gM, oM, lengths = collate_with_lengths(batch)
+    for name, got in (("dm", dm), ("p", p), ("G", G), ("gM", gM), ("oM", oM)):
+        ref = d[name]
+        assert got.numpy().dtype == ref.dtype and np.array_equal(got.numpy(), ref), name
+    assert lengths.tolist() == d["sizes"].tolist()
+    # the lengths the reference's own unpack_sequences reports for the same batch are the same side-channel
+    assert lengths_from_unpacked(d["xlen"], d["ylen"]).tolist() == d["sizes"].tolist()
+    # (unpack_sequences pads x AND y to the longest sequence of the whole batch, utils.py:245-251)
+    longest = int(d["sizes"].max())
+    assert d["x"].shape == (len(batch), longest) and d["y"].shape == (len(batch), longest)

@@ -1,0 +1,62 @@
+"""GPU: the widened path end to end (SURVEY 8 f4 -> a -> f3): reference-style collate with the lengths side-channel
+-> decode(theta, A, lengths) -> fused masked loss with the same lengths -> backward.  Expected values: the reference's
+per-item procedure (alignment.py:165-170 slices each pair; losses.py:26-46 loops over pairs) evaluated with the CPU
+oracle in float64."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import datagen
+import parity
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("variant", [0, 1], ids=["nw", "sw"])
+def test_collate_decode_loss_backward(golden_dir, variant):
+    from deepblast_amd import NeedlemanWunschDecoder, SmithWatermanDecoder
+    from deepblast_amd.batching import collate_with_lengths
+    from deepblast_amd.losses import MatrixCrossEntropy
+    d = np.load(os.path.join(golden_dir, "g10_batching.npz"))
+    batch = [tuple(torch.from_numpy(d[f"i{b}_{k}"]) for k in ("gene", "other", "states", "aln", "path", "mask", "gm", "om"))
+             for b in range(len(d["sizes"]))]
+    genes, others, states, dm, p, G, gM, oM, lengths = collate_with_lengths(batch)
+    B, N, M = dm.shape
+    theta, A = datagen.theta_A(333, B, N, M)   # stands in for the language-model scores (alignment.py:122-123)
+    Yt = (dm > 0.8).float()
+    dev = torch.device("cuda", 0)
+    t = torch.from_numpy(theta).to(dev).requires_grad_()
+    a = torch.from_numpy(A).to(dev).requires_grad_()
+    dec = (NeedlemanWunschDecoder, SmithWatermanDecoder)[variant]("softmax")
+    aln = dec.decode(t, a, lengths.to(dev))
+    xl, yl = lengths[:, 0].tolist(), lengths[:, 1].tolist()
+    loss = MatrixCrossEntropy()(Yt.to(dev), aln, xl, yl, G.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+
+    # reference procedure, pair by pair
+    ref_loss, ref_grad, ref_aln = 0.0, np.zeros((B, N, M)), np.zeros((B, N, M), np.float32)
+    eps = 3e-8
+    for b in range(B):
+        n, m = xl[b], yl[b]
+        th, ga = np.ascontiguousarray(theta[b:b + 1, :n, :m]), np.ascontiguousarray(A[b:b + 1, :n, :m])
+        _, E, Q, Ef = oracle.fwd_bwd(th, ga, None, variant)
+        ref_aln[b, :n, :m] = E[0]
+        g = G[b, :n, :m].numpy().astype(bool)
+        y = Yt[b, :n, :m].numpy().astype(np.float64)
+        pr = np.clip(E[0].astype(np.float32), np.float32(eps), np.float32(1 - eps)).astype(np.float64)
+        cnt = g.sum()
+        ref_loss += -np.sum((y * np.log(pr) + (1 - y) * np.log(1 - pr))[g]) / cnt / B
+        inside = (E[0] >= eps) & (E[0] <= 1 - eps)
+        Z = np.where(g & inside, -(y / pr - (1 - y) / (1 - pr)) / (cnt * B), 0.0).astype(np.float32)
+        Ed, _, _ = oracle.double_backward(Q, Ef, Z[None])
+        ref_grad[b, :n, :m] = Ed[0]
+    assert parity.abs_err(aln.detach().cpu().numpy(), ref_aln) <= parity.TOL
+    assert abs(float(loss) - ref_loss) <= 1e-4 * max(1.0, abs(ref_loss))
+    assert parity.abs_err(t.grad.cpu().numpy(), ref_grad, scale=True) <= parity.TOL
+    # nothing leaks outside a pair's own block
+    for b in range(B):
+        assert not t.grad[b, xl[b]:, :].any() and not t.grad[b, :, yl[b]:].any()

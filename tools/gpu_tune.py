@@ -27,6 +27,16 @@ def load(path):
     return lib
 
 
+def set_debug(lib, mask):
+    """Experiment switches exist only in -DSDP_EXPERIMENTS builds (deepblast_amd/libsdp_hip_exp.so)."""
+    if hasattr(lib, "sdp_set_debug"):
+        lib.sdp_set_debug.restype, lib.sdp_set_debug.argtypes = ctypes.c_int, [ctypes.c_int]
+        return lib.sdp_set_debug(mask)
+    if mask:
+        raise RuntimeError("this library has no sdp_set_debug: load deepblast_amd/libsdp_hip_exp.so")
+    return 0
+
+
 def timeit(fn, n=8):
     fn()
     torch.cuda.synchronize()
@@ -54,11 +64,10 @@ def run(lib, B, N, M, waves=(0, 0, 0, 0), passes="fb"):
     Ed = torch.empty(B, N, M, device="cuda") if "a" in passes else None
     z = torch.randn(B, N, M, device="cuda") if "a" in passes else None
     stream = torch.cuda.current_stream().cuda_stream
-    for p, w in enumerate(waves):
-        lib.sdp_set_waves(p, w)
+    wf = [(w & 0xf) << 12 for w in waves]   # include/sdp.h SDP_WAVES(w): travels with the call
     out = {}
-    f = lambda: lib.sdp_forward_f32(t.data_ptr(), a.data_ptr(), st.data_ptr(), vt.data_ptr(), B, N, M, None, 0, 0, stream)
-    b = lambda: lib.sdp_backward_f32(et.data_ptr(), st.data_ptr(), E.data_ptr(), B, N, M, None, 0, 0, stream)
+    f = lambda: lib.sdp_forward_f32(t.data_ptr(), a.data_ptr(), st.data_ptr(), vt.data_ptr(), B, N, M, None, wf[0], 0, stream)
+    b = lambda: lib.sdp_backward_f32(et.data_ptr(), st.data_ptr(), E.data_ptr(), B, N, M, None, wf[1], 0, stream)
     assert f() == 0
     out["fwd"] = timeit(f)
     out["bwd"] = timeit(b)
@@ -66,12 +75,12 @@ def run(lib, B, N, M, waves=(0, 0, 0, 0), passes="fb"):
     if "a" in passes:
         stx = torch.empty(dbytes // 4, device="cuda")  # exact state for the adjoint sweeps
         if hasattr(lib, "sdp_state_d_bytes"):
-            assert lib.sdp_forward_f32(t.data_ptr(), a.data_ptr(), stx.data_ptr(), vt.data_ptr(), B, N, M, None, 0x100, 0, stream) == 0
-            out["fwd_x"] = timeit(lambda: lib.sdp_forward_f32(t.data_ptr(), a.data_ptr(), stx.data_ptr(), vt.data_ptr(), B, N, M, None, 0x100, 0, stream))
+            assert lib.sdp_forward_f32(t.data_ptr(), a.data_ptr(), stx.data_ptr(), vt.data_ptr(), B, N, M, None, 0x100 | wf[0], 0, stream) == 0
+            out["fwd_x"] = timeit(lambda: lib.sdp_forward_f32(t.data_ptr(), a.data_ptr(), stx.data_ptr(), vt.data_ptr(), B, N, M, None, 0x100 | wf[0], 0, stream))
         else:
             stx = st
-        af = lambda: lib.sdp_adjoint_forward_f32(stx.data_ptr(), z.data_ptr(), None, vt.data_ptr(), std.data_ptr(), B, N, M, None, 0, 0, stream)
-        ab = lambda: lib.sdp_adjoint_backward_f32(E.data_ptr(), stx.data_ptr(), std.data_ptr(), Ed.data_ptr(), B, N, M, None, 0, 0, stream)
+        af = lambda: lib.sdp_adjoint_forward_f32(stx.data_ptr(), z.data_ptr(), None, vt.data_ptr(), std.data_ptr(), B, N, M, None, wf[2], 0, stream)
+        ab = lambda: lib.sdp_adjoint_backward_f32(E.data_ptr(), stx.data_ptr(), std.data_ptr(), Ed.data_ptr(), B, N, M, None, wf[3], 0, stream)
         out["afwd"] = timeit(af)
         out["abwd"] = timeit(ab)
     return out
@@ -91,12 +100,13 @@ def main():
                 continue
             r = run(main_lib, B, 512, 512, (W, W, W, W), "fba" if B == 256 else "fb")
             print(f"B={B:5d} W={W}: " + "  ".join(f"{k}={v:8.1f}" for k, v in r.items()), flush=True)
-    print("== aliasing experiments (main lib, B=256, W=4): dbg bit0 inputs, bit1 outputs, bit2 state alias pair 0")
+    exp_lib = load(os.path.join(ROOT, "deepblast_amd", "libsdp_hip_exp.so"))
+    print("== aliasing experiments (experiments build, B=256, W=4): dbg bit0 inputs, bit1 outputs, bit2 state alias pair 0")
     for dbg in (0, 1, 2, 4, 5, 6, 7):
-        main_lib.sdp_set_waves(100, dbg)
-        r = run(main_lib, 256, 512, 512, (0, 0, 0, 0), "fb")
+        set_debug(exp_lib, dbg)
+        r = run(exp_lib, 256, 512, 512, (0, 0, 0, 0), "fb")
         print(f"dbg={dbg}: " + "  ".join(f"{k}={v:8.1f}" for k, v in r.items()), flush=True)
-    main_lib.sdp_set_waves(100, 0)
+    set_debug(exp_lib, 0)
     print("== variants at B=256 W=4, us (3 interleaved rounds, min)")
     sel = {n: load(pth) for n, pth in libs.items()
            if not ((only and n not in only) or (not only and "--variants" not in sys.argv and n != "main"))}
