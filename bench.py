@@ -167,7 +167,7 @@ def main():
     aligner = ShardedAligner(dec, gather=args.gather if world > 1 else "none")
     eng = get_engine()
     timer = KernelTimer()
-    eng.launch_hook = timer
+    eng.launch_hook = None if os.environ.get("BENCH_NO_KERNEL_EVENTS") else timer   # (experiment: cost of the event pairs)
 
     def step():
         if args.mode == "fwdbwd":
@@ -227,12 +227,21 @@ def main():
         dom = "sdp_fwd_kernel"
         dom_ms = ms.get(dom, float("nan"))
         achieved = cells * ALGO_BYTES_PER_CELL_UPDATE / (dom_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch from the PMC passes (profiles/traffic.json, tools/gpu_round.sh): only if that file was
+        # measured on exactly these kernel sources -- a stale figure is reported as null, not as a number
+        traffic, traffic_stamp = None, None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf) and (B, N, M, args.variant) == (256, 512, 512, "nw"):
             try:
-                traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
-            except (OSError, ValueError):
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import source_stamp
+                tj = json.load(open(tf))
+                traffic_stamp = tj.get("_stamp", {}).get("source_sha256")
+                if traffic_stamp == source_stamp.source_sha():
+                    traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
+                else:
+                    print("[bench] profiles/traffic.json was measured on other kernel sources: roofline.traffic = null", file=sys.stderr)
+            except (OSError, ValueError, ImportError):
                 traffic = None
         line = {
             "metric": "DP cell-updates/sec (fwd+bwd)" if args.mode == "fwdbwd" else "DP cell-updates/sec (train: fwd+bwd+adjoint pair)",

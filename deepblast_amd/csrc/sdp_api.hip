@@ -298,11 +298,6 @@ int sdp_backward_f32(const float *Et, const float *state, float *E, int B, int N
     const bool exact = vb.exact;
     variant = vb.variant;
     if (int rc = check_shape(B, N, M, variant)) return rc;
-    if (lens) {
-        hipError_t e = hipSetDevice(device);
-        if (e == hipSuccess) e = hipMemsetAsync(E, 0, (size_t)B * N * M * sizeof(float), (hipStream_t)stream);
-        if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(E)");
-    }
     sdp::Params p = {};
     p.vin = Et;
     p.qin = reinterpret_cast<const uint32_t *>(state);
@@ -337,11 +332,6 @@ int sdp_adjoint_backward_f32(const float *E, const float *state, const float *st
     const VariantBits vb = split_variant(variant);
     variant = vb.variant;
     if (int rc = check_shape(B, N, M, variant)) return rc;
-    if (lens) {
-        hipError_t e = hipSetDevice(device);
-        if (e == hipSuccess) e = hipMemsetAsync(Ed, 0, (size_t)B * N * M * sizeof(float), (hipStream_t)stream);
-        if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(Ed)");
-    }
     sdp::Params p = {};
     p.sin0 = E;
     p.qin = reinterpret_cast<const uint32_t *>(state);

@@ -372,11 +372,48 @@ __device__ __forceinline__ void sweep(const Params &p)
     if (threadIdx.x < (unsigned)W) lds_store_i32(prog + 4 * threadIdx.x, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the store above is inline asm: the compiler's own counter tracking does not see it
     __syncthreads();
-    if (wave >= nstrips) return;
 
     // ---- per-pair tensor descriptors ----
     const size_t plane_elems = (size_t)p.N * p.M;
     const unsigned plane_bytes = (unsigned)(plane_elems * 4);
+
+    // Lengths-aware mode: E / Ed are dense (B,N,M) tensors that must be zero outside the pair's n x m block.  The
+    // sweep only writes the block; the rest is zero-filled here by the pair's own workgroup (no separate memset
+    // pass over the whole tensor): by the waves that have no strip (short pairs -- they start at once and finish
+    // long before the batch's longest pair), otherwise by every wave after its last strip.
+    auto zero_fill = [&]() {
+        if constexpr (T::SOUT > 0) {
+            if (p.lens == nullptr || (n == p.N && m == p.M)) return;
+            const int idle = W > nstrips ? W - nstrips : 0;
+            const int parts = idle > 0 ? idle : W, part = idle > 0 ? wave - nstrips : wave;
+            if (part < 0) return;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 z4 = {0u, 0u, 0u, 0u};
+            __amdgpu_buffer_rsrc_t rz = make_rsrc(p.sout + ((SDP_EXP_BUILD && (p.dbg & 2)) ? 0 : (size_t)b) * plane_elems, plane_bytes);
+            // rows [n, N): one contiguous run; stores past the end of the plane are dropped dword by dword
+            const unsigned tail1 = (unsigned)(p.N * p.M);
+            for (unsigned e = (unsigned)(n * p.M) + (unsigned)(part * 64 + lane) * 4u; e < tail1; e += (unsigned)parts * 256u)
+                __builtin_amdgcn_raw_buffer_store_b128(z4, rz, e * 4u, 0, 0);
+            // rows [0, n): columns [m, M)
+            if (m < p.M) {
+                for (int r = part; r < n; r += parts) {
+                    const unsigned row = (unsigned)(r * p.M);
+                    for (int c = m + 4 * lane; c < p.M; c += 256) {
+                        if (c + 4 <= p.M) {
+                            __builtin_amdgcn_raw_buffer_store_b128(z4, rz, (row + c) * 4u, 0, 0);
+                        } else {
+                            for (int q = 0; q < 4; ++q)
+                                if (c + q < p.M) __builtin_amdgcn_raw_buffer_store_b32(0u, rz, (row + c + q) * 4u, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    };
+    if (wave >= nstrips) {
+        zero_fill();
+        return;
+    }
     // experiments build only (sdp_set_debug): all pairs alias pair 0 -- every access is served from cache
     const size_t b_in = (SDP_EXP_BUILD && (p.dbg & 1)) ? 0 : b, b_out = (SDP_EXP_BUILD && (p.dbg & 2)) ? 0 : b,
                  b_st = (SDP_EXP_BUILD && (p.dbg & 4)) ? 0 : b;
@@ -1211,6 +1248,7 @@ __device__ __forceinline__ void sweep(const Params &p)
             }
         }
     }
+    zero_fill();  // every wave is busy (no idle ones): each clears its share once its strips are done
 }
 
 }  // namespace sdp

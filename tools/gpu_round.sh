@@ -1,17 +1,27 @@
 #!/bin/bash
-# One GPU-box visit: GPU test-suite, smoke, bench line, rocprofv3 kernel stats.
-# Usage (from the repo root on the GPU box): bash tools/gpu_round.sh <tag> [quick]
-TAG=${1:-r01}
-mkdir -p gpurun_out
+# One GPU-box visit that produces EVERY tracked profile from the same sources:
+#   bash tools/gpu_round.sh <tag> [quick]     (from the repo root on the GPU box; `quick` skips pytest/smoke)
+# writes gpurun_out/round_<tag>/ : pytest + smoke logs, bench lines (fwdbwd, train), rocprofv3 kernel stats for both
+# modes, FETCH_SIZE and WRITE_SIZE counter passes (separate runs, kernel-trace only -- gpurun refuses pmc + other
+# traces), and the source hash the numbers belong to.  Afterwards, in the build container:
+#   python tools/collect_profiles.py <tag>    -> profiles/<tag>_*.csv|json + profiles/traffic.json (stamped)
+TAG=${1:-r02}
+OUT=gpurun_out/round_$TAG
+mkdir -p $OUT
 export TMPDIR=/tmp
+python tools/source_stamp.py > $OUT/stamp.json
 if [ "$2" != "quick" ]; then
-  timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee gpurun_out/pytest_gpu_$TAG.txt
-  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke_$TAG.txt
+  timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $OUT/pytest_gpu.txt
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee $OUT/smoke.txt
 fi
-timeout 600 python bench.py --steps 20 --warmup 3 2> gpurun_out/bench_$TAG.err | tee gpurun_out/bench_$TAG.json
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o $TAG -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/bench_prof_$TAG.json 2> gpurun_out/rocprof_$TAG.err
+timeout 600 python bench.py --steps 20 --warmup 3 2> $OUT/bench.err | tee $OUT/bench.json
+timeout 600 python bench.py --steps 20 --warmup 3 --mode train --no-cpu-baseline 2>> $OUT/bench.err | tee $OUT/bench_train.json
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o fwdbwd -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/rocprof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o train -- python bench.py --steps 10 --warmup 2 --mode train --no-cpu-baseline > $OUT/bench_prof_train.json 2>> $OUT/rocprof.err
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/pmc_${C}_$TAG -o $TAG -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/pmc_${C}_$TAG.err
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o fwdbwd -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$C.err
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_train_$C -o train -- python bench.py --steps 3 --warmup 1 --mode train --no-cpu-baseline > /dev/null 2>> $OUT/pmc_$C.err
 done
-ls -R gpurun_out/prof_$TAG gpurun_out/pmc_FETCH_SIZE_$TAG | head -30
-for f in $(find gpurun_out/prof_$TAG -name "*kernel_stats.csv"); do echo "== $f"; cat $f; done
+# keep what is merged back small: the per-dispatch traces are large, the stats and counter CSVs are not
+find $OUT -name "*kernel_trace.csv" -size +4M -delete
+for f in $(find $OUT/prof $OUT/prof_train -name "*kernel_stats.csv"); do echo "== $f"; head -8 $f; done

@@ -1,5 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 300 tools/ubench/isa_cost > gpurun_out/isa_cost2.txt 2>&1
-timeout 900 python tools/abl_probe.py > gpurun_out/abl.txt 2>&1
-cat gpurun_out/abl.txt
+for i in 1 2; do
+timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('hook  ', d['ms_per_step'], d['ms_per_step_median'], d['kernel_ms'])"
+BENCH_NO_KERNEL_EVENTS=1 timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('nohook', d['ms_per_step'], d['ms_per_step_median'])"
+done
