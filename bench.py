@@ -42,8 +42,10 @@ def parse():
     ap.add_argument("--N", type=int, default=512)
     ap.add_argument("--M", type=int, default=512)
     ap.add_argument("--variant", choices=["nw", "sw"], default="nw")
-    ap.add_argument("--mode", choices=["fwdbwd", "train"], default="fwdbwd",
-                    help="fwdbwd: headline; train: decode -> loss -> backward (adds the adjoint pair)")
+    ap.add_argument("--mode", choices=["fwdbwd", "train", "scores+dp"], default="fwdbwd",
+                    help="fwdbwd: headline; train: decode -> loss -> backward (adds the adjoint pair); scores+dp: theta/A "
+                         "from (B,N,D) embeddings on the matrix cores (alignment.py:122-123), then the headline step")
+    ap.add_argument("--D", type=int, default=512, help="embedding width of --mode scores+dp (reference default n_embed)")
     ap.add_argument("--gather", choices=["vt", "e", "none"], default="vt")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs in the CPU-baseline sample")
@@ -169,7 +171,17 @@ def main():
     timer = KernelTimer()
     eng.launch_hook = None if os.environ.get("BENCH_NO_KERNEL_EVENTS") else timer   # (experiment: cost of the event pairs)
 
+    emb = None
+    if args.mode == "scores+dp":
+        from deepblast_amd.scores import alignment_scores
+        sc = 2.0 / np.sqrt(args.D)
+        emb = [torch.from_numpy((datagen.normal(20 + i, (B, n, args.D)) * sc).astype(np.float32)).to(dev)
+               for i, n in enumerate((N, M, N, M))]
+
     def step():
+        if args.mode == "scores+dp":
+            th, ga = alignment_scores(*emb)     # one MFMA launch: both GEMMs + softplus / logsigmoid
+            return aligner.align(th, ga)["E_local"]
         if args.mode == "fwdbwd":
             out = aligner.align(theta, A)      # Vt = dec(theta, A); dVt.sum()/dtheta; all-gather Vt
             return out["E_local"]
@@ -219,7 +231,7 @@ def main():
         e_gather = dt_e / min(args.steps, 5)
 
     cells = B * N * M if args.variant == "nw" else B * (N - 1) * (M - 1)
-    per_step_updates = (2 if args.mode == "fwdbwd" else 4) * cells
+    per_step_updates = (4 if args.mode == "train" else 2) * cells
     value = world * per_step_updates * args.steps / elapsed
     ms = timer.means_ms()
 
@@ -244,12 +256,14 @@ def main():
             except (OSError, ValueError, ImportError):
                 traffic = None
         line = {
-            "metric": "DP cell-updates/sec (fwd+bwd)" if args.mode == "fwdbwd" else "DP cell-updates/sec (train: fwd+bwd+adjoint pair)",
+            "metric": {"fwdbwd": "DP cell-updates/sec (fwd+bwd)", "train": "DP cell-updates/sec (train: fwd+bwd+adjoint pair)",
+                       "scores+dp": "DP cell-updates/sec (scores from embeddings + fwd+bwd)"}[args.mode],
             "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": float(np.median(per_step_ms)),
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.variant.upper()} soft-DP {'fwd+bwd' if args.mode == 'fwdbwd' else 'decode+loss.backward'}"
+            "config": {"workload": f"{args.variant.upper()} soft-DP " + {"fwdbwd": "fwd+bwd", "train": "decode+loss.backward",
+                                                                        "scores+dp": f"scores(D={args.D})+fwd+bwd"}[args.mode] +
                                    f", B={B} per GPU, N={N}, M={M}, random theta/A "
                                    + ("(BASELINE.json configs[1])" if world == 1 else
                                       f"(BASELINE.json configs[4] sharding: {B * world} pairs over {world} GPUs)"),
@@ -263,6 +277,12 @@ def main():
                          "launch_ms": dom_ms,
                          "whole_step_frac": (per_step_updates * ALGO_BYTES_PER_CELL_UPDATE * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9)},
         }
+        if args.mode == "scores+dp" and "sdp_scores_kernel" in ms:
+            flops = 2.0 * 2.0 * B * N * M * args.D          # two (N,D) x (D,M) products per pair
+            tf = flops / (ms["sdp_scores_kernel"] * 1e-3) / 1e12
+            line["scores_roofline"] = {"bound": "mfma", "kernel": "sdp_scores_kernel", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s",
+                                       "frac": tf / 157.3, "dtype": "f32 (v_mfma_f32_32x32x2_f32)", "D": args.D,
+                                       "launch_ms": ms["sdp_scores_kernel"], "flops_per_launch": flops}
         if e_gather is not None:
             line["with_e_gather"] = {"ms_per_step": e_gather * 1e3, "value": world * per_step_updates / e_gather,
                                      "bytes_into_each_gpu": (world - 1) * B * N * M * 4}

@@ -342,6 +342,31 @@ int sdp_adjoint_backward_f32(const float *E, const float *state, const float *st
     return launch(sdp::PASS_ABWD, p, device, stream, false, vb.waves);
 }
 
+int sdp_scores_f32(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
+                   int M, int D, int device, void *stream)
+{
+    if (!zx || !zy || !theta) return fail(SDP_E_NULLPTR, "sdp_scores_f32: null pointer");
+    if ((gx || gy || A) && !(gx && gy && A)) return fail(SDP_E_NULLPTR, "sdp_scores_f32: gx, gy and A go together (all or none)");
+    if (B <= 0 || N <= 0 || M <= 0 || D <= 0) return fail(SDP_E_SHAPE, "B, N, M and D must be positive");
+    if ((size_t)N * M > ((size_t)1 << 28) || (size_t)N * D > ((size_t)1 << 28) || (size_t)M * D > ((size_t)1 << 28))
+        return fail(SDP_E_TOOBIG, "a matrix of one pair exceeds 2^28 elements");
+    const long long nz = (long long)(A ? 2 : 1) * B;
+    if (nz > 65535) return fail(SDP_E_TOOBIG, "too many pairs for one launch (grid.z)");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    static thread_local unsigned long long raised = 0;
+    if (device >= 64 || !(raised >> device & 1ull)) {
+        e = hipFuncSetAttribute((const void *)sdp_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sdp::SCORES_LDS_BYTES);
+        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(sdp_scores_kernel)");
+        if (device < 64) raised |= 1ull << device;
+    }
+    hipLaunchKernelGGL(sdp_scores_kernel, dim3((M + 127) / 128, (N + 127) / 128, (unsigned)nz), dim3(256), sdp::SCORES_LDS_BYTES,
+                       (hipStream_t)stream, zx, zy, gx, gy, theta, A, B, N, M, D);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "sdp_scores_kernel");
+    return 0;
+}
+
 int sdp_traceback_capacity(int N, int M) { return (N > 0 && M > 0) ? N + M + 2 : 0; }
 
 int sdp_traceback_i32(const float *grad, int32_t *states, int32_t *counts, int B, int N, int M, const int32_t *lens,

@@ -104,6 +104,8 @@ __host__ __device__ constexpr int stage_floats(int pass, int K)
 __host__ __device__ inline int state_nstrips(int N) { return (N + 63) / 64; }
 __host__ __device__ inline int state_tpad(int M) { return (M + 63 + 63) / 64 * 64; }
 
+constexpr int SCORES_LDS_BYTES = 2 * 2 * 128 * 36 * 4;  // sdp_scores_kernel: [buffer][operand][128 rows][36 floats]
+
 }  // namespace sdp
 
 extern "C" {
@@ -120,6 +122,8 @@ __global__ void sdp_adj_bwd_kernel(const sdp::Params p);
 __global__ void sdp_selftest_kernel(int *out);
 __global__ void sdp_loss_fwd_kernel(const float *ref, const float *pred, const float *G, const int *lens, double *acc, int *cnt, int N, int M, int kind);
 __global__ void sdp_loss_bwd_kernel(const float *ref, const float *pred, const float *G, const int *lens, const float *scale, float *grad, int N, int M, int kind);
+__global__ void sdp_scores_kernel(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
+                                  int M, int D);
 __global__ void sdp_traceback_kernel(const float *grad, int *states, int *counts, const int *lens, int B, int N, int M, int cap);
 }
 

@@ -1,0 +1,183 @@
+// sdp_scores.hip -- the step in front of the DP: the score tensors
+//
+//     theta[b,i,j] = softplus  ( sum_d zx[b,i,d] * zy[b,j,d] )
+//     A    [b,i,j] = logsigmoid( sum_d gx[b,i,d] * gy[b,j,d] )
+//
+// that NeuralAligner builds with two einsums and two elementwise passes (deepblast/alignment.py:122-123,
+// :134-135) and that the DP then reads.  One launch: a batched fp32 GEMM on the matrix cores with the activation
+// applied to the accumulators, so each (B,N,M) tensor is written once, in the row-major layout the sweeps read,
+// and the pre-activation products never exist in memory.
+//
+// This is the one place on the widened path where MFMA belongs.  Arithmetic: v_mfma_f32_32x32x2_f32 -- f32 in,
+// f32 accumulate, bit-for-bit an fmaf chain (no bf16 splitting): parity with torch's fp32 einsum is then a matter
+// of summation order only (<= ~1e-7 * sum|a*b|).  It runs at the fp32 vector rate (64 FLOP/clk/SIMD, 157 TFLOP/s
+// peak), 1/16 of the bf16 matrix rate; a bf16x3 split would be ~5x faster but leaves 2^-16-relative errors per
+// product -- 3e-4 absolute on theta at D = 512 -- which does not meet the 1e-4 parity bound, so it is not used.
+//
+// Tiling: one workgroup (4 waves) per 128 x 128 tile of one (pair, tensor); a wave owns 64 x 64 = 2 x 2 MFMA
+// blocks (64 accumulator VGPRs).  Operands are staged through LDS in 32-deep K slabs (rows padded to 36 floats:
+// the 16-byte reads of 16 different rows then fall on 16 different bank quads), double-buffered, the next slab's
+// global loads (one 128-byte line per 8 lanes) in flight during the current slab's 64 MFMAs.  A lane's
+// ds_read_b128 delivers four consecutive k of one row; lanes 0-31 take k = 8s..8s+3 and lanes 32-63 k = 8s+4..8s+7,
+// so VGPR v of the read feeds the MFMA that contracts k in {8s+v, 8s+4+v} -- both operands use the same map, and
+// the order of a sum does not matter.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sdp_kernels.h"
+
+namespace sdp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SC_TILE = 128;   // rows and columns of C per workgroup
+constexpr int SC_BK = 32;      // K slab
+constexpr int SC_PITCH = 36;   // LDS row pitch in floats (padding: see above)
+
+// F.softplus(x) (beta 1, threshold 20: x itself above it) and F.logsigmoid(x) = -softplus(-x), as torch computes
+// them in fp32: max(x, 0) + log1p(exp(-|x|))  /  min(x, 0) - log1p(exp(-|x|))
+__device__ __forceinline__ float log1p_exp_neg_abs(float x)
+{
+    const float t = __expf(-__builtin_fabsf(x));   // in (0, 1]
+    // log1p(t): log(1 + t) loses nothing that matters here (t <= 1, result >= t/2); for tiny t use t - t*t/2
+    return t < 1e-4f ? t * (1.0f - 0.5f * t) : __logf(1.0f + t);
+}
+__device__ __forceinline__ float softplus_f(float x)
+{
+    return x > 20.0f ? x : __builtin_fmaxf(x, 0.0f) + log1p_exp_neg_abs(x);
+}
+__device__ __forceinline__ float logsigmoid_f(float x)
+{
+    return __builtin_fminf(x, 0.0f) - log1p_exp_neg_abs(x);
+}
+
+}  // namespace sdp
+
+// grid = (ceil(M/128), ceil(N/128), tensors * B): blockIdx.z < B -> theta from (zx, zy), else A from (gx, gy)
+extern "C" __global__ void __launch_bounds__(256, 2)
+sdp_scores_kernel(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
+                  int M, int D)
+{
+    using namespace sdp;
+    // dynamic LDS, 2 x 2 x 128 x 36 floats = 72 KiB ([buffer][operand][row * pitch + k]): two workgroups per CU
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    float (*lds)[2][SC_TILE * SC_PITCH] = reinterpret_cast<float (*)[2][SC_TILE * SC_PITCH]>(lds_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kind = blockIdx.z >= (unsigned)B;
+    const int b = kind ? blockIdx.z - B : blockIdx.z;
+    const float *X = (kind ? gx : zx) + (size_t)b * N * D;
+    const float *Y = (kind ? gy : zy) + (size_t)b * M * D;
+    float *C = (kind ? A : theta) + (size_t)b * N * M;
+    const int i0 = blockIdx.y * SC_TILE, j0 = blockIdx.x * SC_TILE;
+
+    // raw buffers: rows past the end of a matrix fall outside the descriptor and load as zeros
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, N * D * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Y), 0, M * D * 4, 0x00020000);
+
+    // global -> register staging: a slab is 128 rows x 32 k per operand = 1024 float4; thread t moves float4 number
+    // t + 256 q (q = 0..3): row = (t >> 3) + 32 q, k = (t & 7) * 4 -- 8 lanes cover one 128-byte line
+    const int ld_row = tid >> 3, ld_k = (tid & 7) * 4;
+    f32x4 stage[2][4];
+    const bool k_vec = (D & 3) == 0;   // rows start 16-byte aligned and a float4 never straddles the end of a row
+    // per-thread row offsets of the four float4 it moves per operand (bytes; rows outside the matrix: out of range)
+    unsigned row_off[2][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int op = 0; op < 2; ++op) {
+            const int row = (op ? j0 : i0) + ld_row + 32 * q;
+            row_off[op][q] = row < (op ? M : N) ? (unsigned)((size_t)row * D + ld_k) * 4u : 0x80000000u;
+        }
+    auto load_slab = [&](int k0) {
+        // whole slab inside the rows and float4-aligned (always, for D a multiple of 32): eight independent 16-byte
+        // loads, no branch between them; a ragged last slab (or D not a multiple of 4) goes dword by dword
+        if (k_vec && k0 + SC_BK <= D) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int op = 0; op < 2; ++op) {
+                    const auto w = __builtin_amdgcn_raw_buffer_load_b128(op ? ry : rx, row_off[op][q], k0 * 4, 0);
+                    f32x4 v;
+                    v[0] = __uint_as_float(w[0]), v[1] = __uint_as_float(w[1]), v[2] = __uint_as_float(w[2]), v[3] = __uint_as_float(w[3]);
+                    stage[op][q] = v;
+                }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int op = 0; op < 2; ++op) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool ok = row_off[op][q] != 0x80000000u && k0 + ld_k + e < D;
+                        v[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(op ? ry : rx, ok ? row_off[op][q] + 4u * e + 4u * k0 : 0x80000000u, 0, 0));
+                    }
+                    stage[op][q] = v;
+                }
+        }
+    };
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int op = 0; op < 2; ++op)
+                *reinterpret_cast<f32x4 *>(&lds[buf][op][(ld_row + 32 * q) * SC_PITCH + ld_k]) = stage[op][q];
+    };
+
+    // this wave's 64 x 64 quadrant; MFMA operand rows: lane & 31 within each 32-row block, k half: lane >> 5
+    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+    const int fr = lane & 31, fk = (lane >> 5) * 4;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[a][c][v] = 0.f;
+
+    const int nslab = (D + SC_BK - 1) / SC_BK;
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nslab) load_slab((s + 1) * SC_BK);
+#pragma unroll
+        for (int ks = 0; ks < SC_BK / 8; ++ks) {
+            f32x4 fa[2], fb[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) fa[a] = *reinterpret_cast<const f32x4 *>(&lds[buf][0][(wr + 32 * a + fr) * SC_PITCH + 8 * ks + fk]);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) fb[c] = *reinterpret_cast<const f32x4 *>(&lds[buf][1][(wc + 32 * c + fr) * SC_PITCH + 8 * ks + fk]);
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][v], fb[c][v], acc[a][c], 0, 0, 0);
+        }
+        if (s + 1 < nslab) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 forms: col = lane & 31, row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5).
+    // For a fixed v the 32 lanes of a half-wave write 32 consecutive columns (128 bytes) of one row.
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(C, 0, N * M * 4, 0x00020000);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = j0 + wc + 32 * c + (lane & 31);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = i0 + wr + 32 * a + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+                const float x = acc[a][c][v];
+                const float y = kind ? logsigmoid_f(x) : softplus_f(x);
+                const unsigned off = (row < N && col < M) ? (unsigned)((size_t)row * M + col) * 4u : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rc, off, 0, 0);
+            }
+        }
+}

@@ -1,0 +1,58 @@
+"""Score tensors for the DP on MI355X.
+
+`alignment_scores(zx, zy, gx, gy)` replaces the two einsum + activation lines of the reference's
+NeuralAligner (deepblast/alignment.py:122-123 and :134-135)
+
+    theta = F.softplus(torch.einsum('bid,bjd->bij', zx, zy))
+    A = F.logsigmoid(torch.einsum('bid,bjd->bij', gx, gy))
+
+with one launch of a hand-written fp32-MFMA batched GEMM whose epilogue applies the activation
+(`sdp_scores_f32`, deepblast_amd/csrc/sdp_scores.hip).  Differentiable: the backward needs no saved
+pre-activations -- d softplus(s)/ds = sigmoid(s) = 1 - exp(-theta) and d logsigmoid(s)/ds = 1 - exp(A) -- and
+forms the gradients of the embeddings with plain library GEMMs (torch.bmm = rocBLAS/hipBLASLt).
+"""
+import torch
+
+from . import _lib
+from ._engine import get_engine, _ptr
+
+
+class _Scores(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, zx, zy, gx, gy):
+        eng = get_engine()
+        dev = eng._dev(zx)
+        eng._check(zx, zx=zx, zy=zy, gx=gx, gy=gy)
+        if zx.dim() != 3 or zy.dim() != 3 or zx.shape[0] != zy.shape[0] or zx.shape[2] != zy.shape[2]:
+            raise ValueError(f"zx must be (B,N,D) and zy (B,M,D); got {tuple(zx.shape)} and {tuple(zy.shape)}")
+        if gx.shape != zx.shape or gy.shape != zy.shape:
+            raise ValueError("gx / gy must have the shapes of zx / zy")
+        zx_, zy_, gx_, gy_ = (t.detach().contiguous() for t in (zx, zy, gx, gy))
+        B, N, D = zx_.shape
+        M = zy_.shape[1]
+        theta = torch.empty((B, N, M), dtype=torch.float32, device=zx.device)
+        A = torch.empty((B, N, M), dtype=torch.float32, device=zx.device)
+        with torch.cuda.device(dev), eng._bracket("sdp_scores_kernel"):
+            rc = eng.lib.sdp_scores_f32(_ptr(zx_), _ptr(zy_), _ptr(gx_), _ptr(gy_), _ptr(theta), _ptr(A), B, N, M, D, dev,
+                                        eng._stream(dev))
+        _lib.check(rc, "sdp_scores_f32")
+        ctx.save_for_backward(zx_, zy_, gx_, gy_, theta, A)
+        return theta, A
+
+    @staticmethod
+    def backward(ctx, g_theta, g_A):
+        zx, zy, gx, gy, theta, A = ctx.saved_tensors
+        out = [None, None, None, None]
+        if g_theta is not None:
+            ds = g_theta * (1.0 - torch.exp(-theta))          # sigmoid(s) = 1 - exp(-softplus(s))
+            out[0], out[1] = torch.bmm(ds, zy), torch.bmm(ds.transpose(1, 2), zx)
+        if g_A is not None:
+            ds = g_A * (1.0 - torch.exp(A))                   # 1 - sigmoid(s) = 1 - exp(logsigmoid(s))
+            out[2], out[3] = torch.bmm(ds, gy), torch.bmm(ds.transpose(1, 2), gx)
+        return tuple(out)
+
+
+def alignment_scores(zx, zy, gx, gy):
+    """zx, gx: (B,N,D); zy, gy: (B,M,D) fp32 on one ROCm device -> (theta, A), each (B,N,M)."""
+    return _Scores.apply(zx, zy, gx, gy)

@@ -115,6 +115,14 @@ int sdp_adjoint_backward_f32(const float *E, const float *state, const float *st
                              int B, int N, int M, const int32_t *lens, int variant, int device,
                              void *stream);
 
+/* The score tensors the DP reads (reference: NeuralAligner.forward / .score, deepblast/alignment.py:122-123, 134-135:
+ *   theta = F.softplus(torch.einsum('bid,bjd->bij', zx, zy));  A = F.logsigmoid(torch.einsum('bid,bjd->bij', gx, gy))).
+ * zx, gx: (B,N,D); zy, gy: (B,M,D); theta, A: (B,N,M); all fp32, contiguous.  gx, gy and A may be NULL together
+ * (theta only).  One launch: batched fp32 GEMM on the matrix cores (f32 MFMA, exact fp32 products and sums) with the
+ * activation applied to the accumulators. */
+int sdp_scores_f32(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
+                   int M, int D, int device, void *stream);
+
 /* Batched traceback (reference: Decoder.traceback, deepblast/nw.py:401-444, called once per pair by
  * NeuralAligner.traceback, alignment.py:165-170).  grad is (B,N,M); states receives, per pair, up to
  * sdp_traceback_capacity(N,M) triples (i, j, state) in the reference's order (start of the alignment first),

@@ -1,0 +1,79 @@
+"""Scores: CPU -- the numpy oracle against the fixture written from the real torch ops
+(alignment.py:122-123); GPU -- the MFMA kernel (sdp_scores_f32) against fixture and oracle, gradients included.
+Tolerance 1e-4 relative to max(1, |ref|) (north_star); observed ~1e-6."""
+import os
+
+import numpy as np
+import pytest
+
+import datagen
+import parity
+from oracle import scores_oracle
+
+
+def _cases(golden_dir):
+    d = np.load(os.path.join(golden_dir, "g11_scores.npz"))
+    for idx in range(len(d["shapes"])):
+        yield idx, {k[len(f"s{idx}_"):]: d[k] for k in d.files if k.startswith(f"s{idx}_")}
+
+
+def test_oracle_matches_the_reference_ops(golden_dir):
+    for idx, c in _cases(golden_dir):
+        theta, A = scores_oracle.scores(c["zx"], c["zy"], c["gx"], c["gy"])
+        # the fixture is torch's fp32 einsum (its own summation order): agreement to fp32 round-off of the inner product
+        assert parity.rel_err(theta, c["theta"]) <= 2e-6, idx
+        assert parity.rel_err(A, c["A"]) <= 2e-6, idx
+    s = np.array([-100.0, -20.0, -1e-3, 0.0, 1e-3, 19.9, 20.1, 100.0])
+    assert np.allclose(scores_oracle.softplus(s), np.logaddexp(0, s), rtol=1e-9, atol=0)
+    assert np.allclose(scores_oracle.logsigmoid(s), -np.logaddexp(0, -s), rtol=1e-9, atol=0)
+
+
+@pytest.mark.gpu
+def test_kernel_matches_fixture_and_gradients(golden_dir):
+    import torch
+    from deepblast_amd.scores import alignment_scores
+    for idx, c in _cases(golden_dir):
+        t = [torch.from_numpy(c[k]).cuda().requires_grad_() for k in ("zx", "zy", "gx", "gy")]
+        theta, A = alignment_scores(*t)
+        ((theta * torch.from_numpy(c["wt"]).cuda()).sum() + (A * torch.from_numpy(c["wa"]).cuda()).sum()).backward()
+        assert parity.rel_err(theta.detach().cpu().numpy(), c["theta"]) <= parity.TOL, idx
+        assert parity.rel_err(A.detach().cpu().numpy(), c["A"]) <= parity.TOL, idx
+        for k, a in zip(("dzx", "dzy", "dgx", "dgy"), t):
+            assert parity.abs_err(a.grad.cpu().numpy(), c[k], scale=True) <= parity.TOL, (idx, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(256, 512, 512, 512), (3, 127, 129, 31), (2, 300, 5, 100), (1, 1, 2048, 7)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_kernel_matches_oracle(shape):
+    import torch
+    from deepblast_amd.scores import alignment_scores
+    B, N, M, D = shape
+    Bo = min(B, 4)   # the float64 oracle on a few pairs of a full batch (the rest: batch independence, below)
+    sc = 2.0 / np.sqrt(D)
+    arrs = [datagen.normal(600 + i, (B, n, D)) * (sc if i % 2 == 0 else 2 * sc) for i, n in enumerate((N, M, N, M))]
+    t = [torch.from_numpy(a.astype(np.float32)).cuda() for a in arrs]
+    theta, A = alignment_scores(*t)
+    sel = np.linspace(0, B - 1, Bo).astype(int)
+    rt, ra = scores_oracle.scores(*[a.astype(np.float32)[sel] for a in arrs])
+    assert parity.rel_err(theta[sel].cpu().numpy(), rt) <= parity.TOL
+    assert parity.rel_err(A[sel].cpu().numpy(), ra) <= parity.TOL
+    # a pair's scores do not depend on the batch it is computed in (bit-exact)
+    alone_t, alone_a = alignment_scores(*[x[sel[-1]:sel[-1] + 1].contiguous() for x in t])
+    assert torch.equal(alone_t[0], theta[sel[-1]]) and torch.equal(alone_a[0], A[sel[-1]])
+
+
+@pytest.mark.gpu
+def test_scores_feed_the_dp():
+    """alignment.py:122-124 end to end: embeddings -> theta, A (MFMA kernel) -> decode (DP sweeps), against the oracles."""
+    import torch
+    from deepblast_amd import NeedlemanWunschDecoder
+    from deepblast_amd.scores import alignment_scores
+    B, N, M, D = 3, 70, 90, 64
+    arrs = [(datagen.normal(700 + i, (B, n, D)) / np.sqrt(D) * 2).astype(np.float32) for i, n in enumerate((N, M, N, M))]
+    theta, A = alignment_scores(*[torch.from_numpy(a).cuda() for a in arrs])
+    theta, A = theta.detach().requires_grad_(), A.detach().requires_grad_()   # decode differentiates w.r.t. both
+    aln = NeedlemanWunschDecoder("softmax").decode(theta, A)
+    rt, ra = scores_oracle.scores(*arrs)
+    ref = parity.oracle_all(rt, ra, None, None, 0)
+    assert parity.abs_err(aln.detach().cpu().numpy(), ref["E"]) <= parity.TOL

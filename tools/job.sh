@@ -1,6 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-for i in 1 2; do
-timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('hook  ', d['ms_per_step'], d['ms_per_step_median'], d['kernel_ms'])"
-BENCH_NO_KERNEL_EVENTS=1 timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('nohook', d['ms_per_step'], d['ms_per_step_median'])"
-done
+timeout 600 python -m pytest tests/test_scores.py -m gpu -x -q 2>&1 | tail -12 > gpurun_out/pytest_scores.txt
+tail -6 gpurun_out/pytest_scores.txt
+timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --mode scores+dp 2>&1 | tail -2 > gpurun_out/bench_scores.json
+python -c "
+import json; d=json.loads(open('gpurun_out/bench_scores.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['kernel_ms'], d.get('scores_roofline'))"
