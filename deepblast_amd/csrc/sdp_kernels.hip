@@ -107,6 +107,9 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #ifndef SDP_WF
 #define SDP_WF 1  // forward sweep: try the windowed form on interior chunks
 #endif
+#ifndef SDP_FWD_SUB
+#define SDP_FWD_SUB 1  // forward sweep: compute in WB-step blocks inside a K-step chunk (see fwd_blocks)
+#endif
 // cache policy: bit0 state stores, bit1 state loads, bit2 staged loads, bit3 staged stores use nt (aux=2).
 // The skewed state is read exactly once, so its loads stream past the caches (nt); its stores keep the
 // default policy: in the fwd -> bwd sequence the tail of the state is then still in the Infinity Cache when
@@ -262,6 +265,7 @@ struct Kind {
 };
 
 typedef unsigned long long u64;  // one boundary slot (LDS) / one edge value in registers
+typedef float f32x2 __attribute__((ext_vector_type(2)));  // operand of the packed fp32 instructions (v_pk_mul / v_pk_fma)
 
 __device__ __forceinline__ u64 pack2(unsigned lo, unsigned hi) { return ((u64)hi << 32) | lo; }
 __device__ __forceinline__ unsigned lo32(u64 x) { return (unsigned)x; }
@@ -530,6 +534,21 @@ __device__ __forceinline__ void sweep(const Params &p)
             }
         };
 
+        // packed state, forward: the two biased fields of a cell (bits of 1 + q * Q_SCALE) arrive per step; every
+        // second step three byte-permutes assemble the 12-byte record of the pair and one dwordx3 store moves it
+        unsigned qbits_x = 0, qbits_y = 0;
+        auto store_state_bits = [&](int t_base, int k, unsigned fx, unsigned fy) {
+            if ((k & 1) == 0) {
+                qbits_x = fx, qbits_y = fy;
+            } else {
+                unsigned w[3];
+                w[0] = __builtin_amdgcn_perm(qbits_y, qbits_x, 0x04020100u);
+                w[1] = __builtin_amdgcn_perm(fx, qbits_y, 0x05040201u);
+                w[2] = __builtin_amdgcn_perm(fy, fx, 0x06050402u);
+                store_q(t_base, k >> 1, w);
+            }
+        };
+
         Carry cy;
         cy.a = cy.b = cy.c = 0.0;
         cy.fa = cy.fb = cy.fc = 0.f;
@@ -690,6 +709,300 @@ __device__ __forceinline__ void sweep(const Params &p)
         load_block(c_first + 1);
         write_block(c_first + 1);
 
+        // ---- forward sweep, exp domain: the K steps of a chunk are computed in blocks of WB = 16 ----
+        // The chunk (K steps) stays the unit of the memory pipeline -- staged input blocks, state prefetch distance --
+        // but everything the recurrence itself touches is per block: the block's inputs (2 x 16 values from the LDS
+        // ring), the 16 boundary values of the strip above (waited for, read and converted per block), the 16 values
+        // handed to the strip below (published with their frame word and the progress word per block, which also
+        // shortens the lag between strips from 63+K to 63+16 steps).  Arrays of 16 instead of K entries keep the
+        // sweep's working set in VGPRs (the K = 32 build had ~340 instructions per chunk that only moved values
+        // between VGPRs and AGPRs).  A block first runs in the windowed form (frame shared by its 16 steps); if a
+        // value leaves the safe range nothing was committed and the block is redone in the per-step-normalised form.
+        // Both forms produce identical bits (same 2^theta, exact power-of-two rescaling), so results do not depend on
+        // which form a block ran in, on K, or on the batch.
+        constexpr bool FWD_SUB = PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_WF && SDP_FWD_SUB;
+        auto fwd_blocks = [&](int c, int t0) {
+            if constexpr (FWD_SUB) {
+                int thr = lane + (sw ? 1 : 0);  // EDGE: the lane's cell is live at step t iff t >= thr
+                if (sw && i0 + lane == 0) thr = 0x7fffffff;  // padded row 1 of Smith-Waterman never is
+                for (int sb = 0; sb < K / WB; ++sb) {
+                    const int tb = t0 + sb * WB;
+                    const bool blk_interior = plain_strip && tb >= 63 && tb + WB < m;
+                    // ---- boundary values of this block: lane 0 at step tb+j needs column tb+j ----
+                    // (read by each form on its own: the windowed form turns the registers into its `up` values in
+                    // place, and the rare fallback simply reads the row again -- the strip above cannot overwrite these
+                    // columns before this strip has produced its own)
+                    const bool use_pred = has_pred && tb < m;
+                    if (use_pred) {
+                        const int need = tb + WB < m ? tb + WB : m;
+                        bool ready = ABL_NOSYNC;
+                        const int spin_cap = (SDP_EXP_BUILD && (p.dbg & 8)) ? (1 << 10) : (1 << 21);
+                        for (int spin = 0; !ABL_NOSYNC && spin < spin_cap; ++spin) {
+                            if (__builtin_amdgcn_readfirstlane(lds_load_i32(prog + 4 * pword)) >= pbase + need) {
+                                ready = true;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        if (!ready && p.status && lane == 0) {
+                            if (__hip_atomic_fetch_add(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+                                p.status[1] = b, p.status[2] = s, p.status[3] = c | (PASS << 24);
+                            }
+                        }
+                    }
+                    auto read_bcv = [&](u64 *bcv) {
+                        if (use_pred) {
+                            if (tb + WB <= m) {
+#pragma unroll
+                                for (int j = 0; j < WB; ++j) bcv[j] = bnd_in[tb + j];
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < WB; ++j) bcv[j] = (tb + j < m) ? bnd_in[tb + j] : edge_zero<KIND>();
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < WB; ++j) bcv[j] = edge_zero<KIND>();
+                        }
+                    };
+                    // ---- staged inputs of this block ----
+                    float in0[WB], in1[WB];
+                    {
+                        const int pr = (tb & (RING - 1)) + 4 * ring_pi(lane & 7);
+#pragma unroll
+                        for (int g = 0; g < WB / 4; ++g) {
+                            const int idx = lane * PITCH + ((pr + 4 * g) & (RING - 1));
+                            const float4 v0 = *reinterpret_cast<const float4 *>(lds_in + idx);
+                            const float4 v1 = *reinterpret_cast<const float4 *>(lds_in + PLANE + idx);
+                            in0[4 * g] = v0.x, in0[4 * g + 1] = v0.y, in0[4 * g + 2] = v0.z, in0[4 * g + 3] = v0.w;
+                            in1[4 * g] = v1.x, in1[4 * g + 1] = v1.y, in1[4 * g + 2] = v1.z, in1[4 * g + 3] = v1.w;
+                        }
+                    }
+                    u64 hist[WB];
+                    int frame_pub = FRAME_NONE;
+
+                    // ---- windowed form; returns 1 = done, 0 = not applicable here, -1 = out of range ----
+                    auto wf_block = [&](auto edge_tag, auto pred_tag) -> int {
+                        constexpr bool EDGE = decltype(edge_tag)::value;
+                        constexpr bool use_pred = decltype(pred_tag)::value;  // (shadows the run-time flag: one body per case)
+                        int fa = 0, fb = 0;
+                        if (use_pred) {
+                            fa = __builtin_amdgcn_readfirstlane(frm_in[(tb + 63) / WB]);                   // block that produced column tb
+                            fb = tb + 1 < m ? __builtin_amdgcn_readfirstlane(frm_in[(tb + 64) / WB]) : fa;  // ... columns tb+1 .. tb+WB-1
+                            if (fa == FRAME_NONE || fb == FRAME_NONE) return 0;
+                        }
+                        int R = cy.xe + WF_BIAS;
+                        if (use_pred && lane == 0) R = fb;
+                        if constexpr (EDGE) {
+                            const int nstarted = tb - (sw ? 1 : 0);  // lanes below this were live at step tb - 1
+                            if (nstarted < 64) {  // the others take the frame of the last started lane (or of the boundary)
+                                const int rref = nstarted > 0 ? __builtin_amdgcn_readlane(R, nstarted - 1) : (use_pred ? fb : EXP_ONE_E + WF_BIAS);
+                                R = lane < nstarted ? R : rref;
+                            }
+                        }
+                        float x = __builtin_amdgcn_ldexpf(cy.xa, cy.xe - R);
+                        float d = __builtin_amdgcn_ldexpf(cy.da, cy.de - R);
+                        const float xz = __builtin_amdgcn_ldexpf(EXP_ONE_A, EXP_ONE_E - R);  // V = 0 in this frame
+                        const int Rn = dpp_i32<DPP_IN>(R, R);
+                        const float sc = __builtin_amdgcn_ldexpf(1.f, Rn - R);
+                        unsigned mx = max(__float_as_uint(x), __float_as_uint(d)), mn = 0x3f800000u, mc = 0;
+                        if (!EDGE || tb > thr) mn = __float_as_uint(x);  // a value that is not live yet may be arbitrarily small
+                        float bf[WB];  // lane 0's `up` values in its frame
+                        if (use_pred) {
+                            u64 bcv[WB];
+                            read_bcv(bcv);
+                            bf[0] = __builtin_amdgcn_ldexpf(__uint_as_float(lo32(bcv[0])), fa - R);
+#pragma unroll
+                            for (int j = 1; j < WB; ++j) bf[j] = __uint_as_float(lo32(bcv[j]));
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < WB; ++j) bf[j] = xz;
+                        }
+                        // 2^theta, 2^A of the block: the log2(e) scalings as packed multiplies (two values per instruction)
+                        // Range of the factors, tested on the exponents: |theta log2e| <= 12 (two-sided) and A log2e <= 12.
+                        // With 2^-12 <= 2^theta <= 2^12 the per-step test on the lane's own value x is enough: the sum it
+                        // was made from is x / 2^theta, i.e. within [2^-112, 2^122] -- normal, with a normal reciprocal --
+                        // whatever the neighbour's scaled values were (an overflow or NaN anywhere ends up in x).
+                        float ctv[WB], cav[WB];
+                        float mcf = 0.f;
+#pragma unroll
+                        for (int j = 0; j < WB; j += 2) {
+                            const f32x2 tt = (f32x2){in0[j], in0[j + 1]} * (f32x2){1.44269504088896340736f, 1.44269504088896340736f};
+                            const f32x2 ta = (f32x2){in1[j], in1[j + 1]} * (f32x2){1.44269504088896340736f, 1.44269504088896340736f};
+                            ctv[j] = __builtin_amdgcn_exp2f(tt[0]), ctv[j + 1] = __builtin_amdgcn_exp2f(tt[1]);
+                            cav[j] = __builtin_amdgcn_exp2f(ta[0]), cav[j + 1] = __builtin_amdgcn_exp2f(ta[1]);
+                            mcf = __builtin_fmaxf(__builtin_fmaxf(mcf, __builtin_fabsf(tt[0])), __builtin_fabsf(tt[1]));
+                            mcf = __builtin_fmaxf(__builtin_fmaxf(mcf, ta[0]), ta[1]);
+                        }
+                        // (a NaN in theta or A is ignored by the maxima above but turns x into NaN, whose bit pattern
+                        // fails the upper test below)
+                        mc = mcf <= 12.0f ? 0u : 0xffffffffu;
+#pragma unroll
+                        for (int j = 0; j < WB; ++j) {
+                            const float ct = ctv[j], ca = cav[j];
+                            const float ua = __uint_as_float(dpp_i32<DPP_IN>(__float_as_int(bf[j]), __float_as_int(x)));
+                            const float u = ua * sc;
+                            const float ssum = __builtin_fmaf(ca, u + x, d);
+                            const float rinv = __builtin_amdgcn_rcpf(ssum);
+                            const float tq = ca * rinv;
+                            if constexpr (QX) {
+                                float2 qq = make_float2(tq * u, tq * x);
+                                q_sharpen(qq.x, qq.y, d * rinv);
+                                if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(tb, j, qq);
+                            } else {
+                                // both weights with one packed multiply, their biased fields with one packed fma
+                                const f32x2 w = (f32x2){u, x} * (f32x2){tq, tq};
+                                const f32x2 f = __builtin_elementwise_fma(w, (f32x2){Q_SCALE, Q_SCALE}, (f32x2){1.0f, 1.0f});
+                                if constexpr (ABL_NOSTORE) { float fx = f[0], fy = f[1]; keep(fx); keep(fy); }
+                                else store_state_bits(tb, j, __float_as_uint(f[0]), __float_as_uint(f[1]));
+                            }
+                            d = u;
+                            x = ct * ssum;
+                            if constexpr (EDGE) {
+                                const bool live = tb + j >= thr;
+                                x = live ? x : xz;
+                                mn = min(mn, live ? __float_as_uint(x) : 0x3f800000u);
+                            } else {
+                                mn = min(mn, __float_as_uint(x));
+                            }
+                            mx = max(mx, __float_as_uint(x));
+                            hist[j] = pack2(__float_as_uint(x), (unsigned)R);
+                        }
+                        if (__builtin_amdgcn_ballot_w64(mx > WF_HI || mn < WF_LO || mc > WF_FMAX) != 0) return -1;  // carry untouched
+                        cy.xa = __builtin_amdgcn_frexp_mantf(x);
+                        cy.xe = R + __builtin_amdgcn_frexp_expf(x);
+                        cy.da = __builtin_amdgcn_frexp_mantf(d);
+                        cy.de = R + __builtin_amdgcn_frexp_expf(d);
+                        if constexpr (EDGE) {
+                            if (tb + WB - 1 < thr) cy.xa = EXP_ONE_A, cy.xe = EXP_ONE_E;  // still waiting: exactly V = 0
+                            const int tf = m - 1 + rows - 1;  // step at which the last strip meets the terminal cell
+                            if (s == nstrips - 1 && tf >= tb && tf < tb + WB) {
+                                const int ktf = t_final - tb;  // only that lane has t_final >= 0
+#pragma unroll
+                                for (int j = 0; j < WB; ++j) vt_keep = (j == ktf) ? hist[j] : vt_keep;
+                                // a terminal cell on the Smith-Waterman border is not live: V = 0 exactly (its value in
+                                // the frame may have underflowed to 0, which would read as -inf)
+                                if (t_final >= 0 && t_final < thr) vt_keep = edge_zero<KIND>();
+                            }
+                        }
+                        frame_pub = R;
+                        return 1;
+                    };
+
+                    // ---- per-step-normalised form (the verified fallback; cannot overflow for any finite input) ----
+                    auto norm_block = [&](auto edge_tag) {
+                        constexpr bool EDGE = decltype(edge_tag)::value;
+                        u64 bcv[WB];
+                        read_bcv(bcv);
+#pragma unroll
+                        for (int j = 0; j < WB; ++j) {
+                            const int t = tb + j;
+                            const int col = t - lane;
+                            const bool dead = EDGE && sw && (col == 0 || (i0 + lane) == 0);  // SW: padded row 1 / col 1
+                            // theta = (kt + ft) ln2, A = (ka + fa) ln2 with integer kt, ka; clamped to +-2^20 bits so that
+                            // A = -inf (a forbidden gap) behaves like the reference's exp(-inf) = 0 instead of inf - inf
+                            const float tt = __builtin_amdgcn_fmed3f(in0[j] * 1.44269504088896340736f, -1048576.f, 1048576.f);
+                            const float ta = __builtin_amdgcn_fmed3f(in1[j] * 1.44269504088896340736f, -1048576.f, 1048576.f);
+                            // Moderate exponents take mantissa and exponent of the SAME 2^tt the windowed form multiplies
+                            // with, so that both forms produce identical bits
+                            const float et2 = __builtin_amdgcn_exp2f(tt), ea2 = __builtin_amdgcn_exp2f(ta);
+                            const float kt = __builtin_floorf(tt), ka = __builtin_floorf(ta);
+                            const float st = __builtin_amdgcn_exp2f(tt - kt), sa = __builtin_amdgcn_exp2f(ta - ka);
+                            const bool mt = __builtin_fabsf(tt) <= 120.f, ma = __builtin_fabsf(ta) <= 120.f;
+                            const float ct = mt ? __builtin_amdgcn_frexp_mantf(et2) : st;
+                            const int kti = mt ? __builtin_amdgcn_frexp_expf(et2) : (int)kt;
+                            const float ca = ma ? __builtin_amdgcn_frexp_mantf(ea2) : sa;
+                            const int kai = ma ? __builtin_amdgcn_frexp_expf(ea2) : (int)ka;
+                            const float ua = __uint_as_float(dpp_i32<DPP_IN>((int)lo32(bcv[j]), __float_as_int(cy.xa)));
+                            const int ue = dpp_i32<DPP_IN>((int)hi32(bcv[j]), cy.xe);
+                            const int ex = ue + kai, ey = cy.xe + kai, ed = cy.de;
+                            const int er = max(max(ex, ey), ed);
+                            const float u = __builtin_amdgcn_ldexpf(ua, ex - er);
+                            const float l = __builtin_amdgcn_ldexpf(cy.xa, ey - er);
+                            const float d = __builtin_amdgcn_ldexpf(cy.da, ed - er);
+                            const float ssum = __builtin_fmaf(ca, u + l, d);  // the operand with the largest exponent is unshifted
+                            const float rinv = __builtin_amdgcn_rcpf(ssum);
+                            const float tq = ca * rinv;
+                            {
+                                float2 qq = make_float2(tq * u, tq * l);
+                                if constexpr (QX) q_sharpen(qq.x, qq.y, d * rinv);
+                                if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(tb, j, qq);
+                            }
+                            const float an = ct * ssum;
+                            float na = __builtin_amdgcn_frexp_mantf(an);
+                            int ne = er + kti + __builtin_amdgcn_frexp_expf(an);
+                            cy.da = ua;
+                            cy.de = ue;
+                            if constexpr (EDGE) {
+                                const bool live = col >= 0 && !dead;
+                                na = live ? na : EXP_ONE_A;
+                                ne = live ? ne : EXP_ONE_E;
+                            }
+                            cy.xa = na;
+                            cy.xe = ne;
+                            hist[j] = pack2(__float_as_uint(na), (unsigned)ne);
+                            if constexpr (EDGE) vt_keep = (t == t_final) ? hist[j] : vt_keep;
+                        }
+                        // publish in one frame whenever the 16 values fit (exact rescaling to the exponent of the last
+                        // one), so that the strip below can use the windowed form; only the publishing lane matters
+                        if (has_succ) {
+                            const int R = (int)hi32(hist[WB - 1]);
+                            float av[WB];
+                            unsigned mx = 0, mn = ~0u;
+#pragma unroll
+                            for (int j = 0; j < WB; ++j) {
+                                av[j] = __builtin_amdgcn_ldexpf(__uint_as_float(lo32(hist[j])), (int)hi32(hist[j]) - R);
+                                mx = max(mx, __float_as_uint(av[j]));
+                                mn = min(mn, __float_as_uint(av[j]));
+                            }
+                            const bool fits = mx <= WF_HI && mn >= WF_LO;
+                            if ((__builtin_amdgcn_ballot_w64(fits) >> PUB_LANE) & 1ull) {
+#pragma unroll
+                                for (int j = 0; j < WB; ++j) hist[j] = pack2(__float_as_uint(av[j]), (unsigned)R);
+                                frame_pub = R;
+                            }
+                        }
+                    };
+
+                    bool done = false;
+                    if (wf_skip == 0) {
+                        const int rc = use_pred ? (blk_interior ? wf_block(std::false_type{}, std::true_type{}) : wf_block(std::true_type{}, std::true_type{}))
+                                                : (blk_interior ? wf_block(std::false_type{}, std::false_type{}) : wf_block(std::true_type{}, std::false_type{}));
+                        done = rc > 0;
+                        if (rc < 0) wf_skip = K / WB;  // values move too fast for one frame per block here: try again a chunk later
+                    } else {
+                        --wf_skip;
+                    }
+                    if (!done) {
+                        if (blk_interior) norm_block(std::false_type{});
+                        else norm_block(std::true_type{});
+                    }
+
+                    // ---- publish the block: 16 boundary values, their frame word, then the progress word ----
+                    if (has_succ) {
+                        const int c_lo = tb - 63;  // lane 63 produced column tb+j-63 at step j
+                        if (lane == PUB_LANE) {
+                            if (c_lo >= 0 && c_lo + WB <= m) {
+#pragma unroll
+                                for (int j = 0; j < WB; ++j) bnd_out[c_lo + j] = hist[j];
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < WB; ++j) {
+                                    const int col = c_lo + j;
+                                    if (col >= 0 && col < m) bnd_out[col] = hist[j];
+                                }
+                            }
+                            frm_out[tb / WB] = frame_pub;
+                        }
+                        const int hi = tb + WB - 63;
+                        const int pub_done = hi < 0 ? 0 : (hi > m ? m : hi);
+                        // LDS executes a wave's DS instructions in order, so the data written above is visible to any
+                        // wave that observes this word (the asm statements also stop compiler reordering)
+                        if (lane == PUB_LANE && !(SDP_EXP_BUILD && (p.dbg & 8))) lds_store_i32(prog + 4 * oword, obase + pub_done);
+                    }
+                }
+            }
+        };
+
         for (int ci = 0; ci < nchunks; ++ci) {
             const int c = REV ? nchunks - 1 - ci : ci;
             const int t0 = c * K;
@@ -700,6 +1013,12 @@ __device__ __forceinline__ void sweep(const Params &p)
             // (the last chunk re-reads its own set: harmless, keeps the step body branch-free)
             const int bb_new = more ? (REV ? c - 1 : c + 2) : c;
             load_block(bb_new);
+
+            if constexpr (FWD_SUB) {
+                fwd_blocks(c, t0);
+                if (more) write_block(bb_new);
+                continue;
+            }
 
             // ---- boundary values for the edge lane: K broadcast LDS reads, off the dependency chain ----
             u64 bcv[K];

@@ -1,7 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_scores.py -m gpu -x -q 2>&1 | tail -12 > gpurun_out/pytest_scores.txt
-tail -6 gpurun_out/pytest_scores.txt
-timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --mode scores+dp 2>&1 | tail -2 > gpurun_out/bench_scores.json
-python -c "
-import json; d=json.loads(open('gpurun_out/bench_scores.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['kernel_ms'], d.get('scores_roofline'))"
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/pytest.txt
+tail -3 gpurun_out/pytest.txt
+timeout 600 python tools/ab.py 256x512x512 64x512x512 256x1024x1024 > gpurun_out/ab.txt 2>&1; cat gpurun_out/ab.txt
+timeout 300 python tools/alias_probe.py > gpurun_out/alias.txt 2>&1; cat gpurun_out/alias.txt
