@@ -104,7 +104,10 @@ __host__ __device__ constexpr int stage_floats(int pass, int K)
 __host__ __device__ inline int state_nstrips(int N) { return (N + 63) / 64; }
 __host__ __device__ inline int state_tpad(int M) { return (M + 63 + 63) / 64 * 64; }
 
-constexpr int SCORES_LDS_BYTES = 2 * 2 * 128 * 36 * 4;  // sdp_scores_kernel: [buffer][operand][128 rows][36 floats]
+#ifndef SDP_SC_BK
+#define SDP_SC_BK 16
+#endif
+constexpr int SCORES_LDS_BYTES = 2 * 2 * 128 * (SDP_SC_BK + 4) * 4;  // sdp_scores_kernel: [buffer][operand][128 rows][BK + 4 floats]
 
 }  // namespace sdp
 

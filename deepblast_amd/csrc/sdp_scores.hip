@@ -32,8 +32,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SC_TILE = 128;   // rows and columns of C per workgroup
-constexpr int SC_BK = 32;      // K slab
-constexpr int SC_PITCH = 36;   // LDS row pitch in floats (padding: see above)
+#ifndef SDP_SC_BK
+#define SDP_SC_BK 16
+#endif
+#ifndef SDP_SC_WAVES_PER_SIMD
+#define SDP_SC_WAVES_PER_SIMD 3
+#endif
+constexpr int SC_BK = SDP_SC_BK;      // K slab
+constexpr int SC_PITCH = SC_BK + 4;   // LDS row pitch in floats (padding: see above)
+constexpr int SC_NQ = SC_BK / 8;         // float4 per thread, operand and slab (128 rows x BK / 4 float4 over 256 threads)
+constexpr int SC_LPR = SC_BK / 4;        // lanes per row of a slab
 
 // F.softplus(x) (beta 1, threshold 20: x itself above it) and F.logsigmoid(x) = -softplus(-x), as torch computes
 // them in fp32: max(x, 0) + log1p(exp(-|x|))  /  min(x, 0) - log1p(exp(-|x|))
@@ -55,7 +63,7 @@ __device__ __forceinline__ float logsigmoid_f(float x)
 }  // namespace sdp
 
 // grid = (ceil(M/128), ceil(N/128), tensors * B): blockIdx.z < B -> theta from (zx, zy), else A from (gx, gy)
-extern "C" __global__ void __launch_bounds__(256, 2)
+extern "C" __global__ void __launch_bounds__(256, SDP_SC_WAVES_PER_SIMD)
 sdp_scores_kernel(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
                   int M, int D)
 {
@@ -78,16 +86,16 @@ sdp_scores_kernel(const float *zx, const float *zy, const float *gx, const float
 
     // global -> register staging: a slab is 128 rows x 32 k per operand = 1024 float4; thread t moves float4 number
     // t + 256 q (q = 0..3): row = (t >> 3) + 32 q, k = (t & 7) * 4 -- 8 lanes cover one 128-byte line
-    const int ld_row = tid >> 3, ld_k = (tid & 7) * 4;
-    f32x4 stage[2][4];
+    const int ld_row = tid / SC_LPR, ld_k = (tid % SC_LPR) * 4;
+    f32x4 stage[2][SC_NQ];
     const bool k_vec = (D & 3) == 0;   // rows start 16-byte aligned and a float4 never straddles the end of a row
     // per-thread row offsets of the four float4 it moves per operand (bytes; rows outside the matrix: out of range)
-    unsigned row_off[2][4];
+    unsigned row_off[2][SC_NQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < SC_NQ; ++q)
 #pragma unroll
         for (int op = 0; op < 2; ++op) {
-            const int row = (op ? j0 : i0) + ld_row + 32 * q;
+            const int row = (op ? j0 : i0) + ld_row + (256 / SC_LPR) * q;
             row_off[op][q] = row < (op ? M : N) ? (unsigned)((size_t)row * D + ld_k) * 4u : 0x80000000u;
         }
     auto load_slab = [&](int k0) {
@@ -95,7 +103,7 @@ sdp_scores_kernel(const float *zx, const float *zy, const float *gx, const float
         // loads, no branch between them; a ragged last slab (or D not a multiple of 4) goes dword by dword
         if (k_vec && k0 + SC_BK <= D) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < SC_NQ; ++q)
 #pragma unroll
                 for (int op = 0; op < 2; ++op) {
                     const auto w = __builtin_amdgcn_raw_buffer_load_b128(op ? ry : rx, row_off[op][q], k0 * 4, 0);
@@ -105,7 +113,7 @@ sdp_scores_kernel(const float *zx, const float *zy, const float *gx, const float
                 }
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < SC_NQ; ++q)
 #pragma unroll
                 for (int op = 0; op < 2; ++op) {
                     f32x4 v;
@@ -120,10 +128,10 @@ sdp_scores_kernel(const float *zx, const float *zy, const float *gx, const float
     };
     auto store_slab = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < SC_NQ; ++q)
 #pragma unroll
             for (int op = 0; op < 2; ++op)
-                *reinterpret_cast<f32x4 *>(&lds[buf][op][(ld_row + 32 * q) * SC_PITCH + ld_k]) = stage[op][q];
+                *reinterpret_cast<f32x4 *>(&lds[buf][op][(ld_row + (256 / SC_LPR) * q) * SC_PITCH + ld_k]) = stage[op][q];
     };
 
     // this wave's 64 x 64 quadrant; MFMA operand rows: lane & 31 within each 32-row block, k half: lane >> 5

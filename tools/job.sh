@@ -1,6 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/pytest.txt
-tail -3 gpurun_out/pytest.txt
-timeout 600 python tools/ab.py 256x512x512 64x512x512 256x1024x1024 > gpurun_out/ab.txt 2>&1; cat gpurun_out/ab.txt
-timeout 300 python tools/alias_probe.py > gpurun_out/alias.txt 2>&1; cat gpurun_out/alias.txt
+timeout 600 python tools/lens_probe.py > gpurun_out/lens_probe.txt 2>&1; cat gpurun_out/lens_probe.txt
