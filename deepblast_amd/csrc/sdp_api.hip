@@ -171,6 +171,16 @@ int pending_handoff_error(int device)
     return SDP_E_HANDOFF;
 }
 
+// Variable-length batches with more pairs than CUs run longest-first.  The order is computed by the forward call
+// (sdp_order_kernel) into the tail of the state buffer it fills, and the other sweeps -- which receive that state
+// and must be given the same lengths -- read it from there.
+bool wants_order(int B, const int32_t *lens, int device) { return lens != nullptr && B > num_cus(device); }
+const int *order_in_state(const void *state, int B, int N, int M, bool exact)
+{
+    const size_t body = (size_t)B * sdp::state_nstrips(N) * sdp::state_tpad(M) * 64 * (exact ? sizeof(float2) : 6);
+    return reinterpret_cast<const int *>(static_cast<const char *>(state) + body);
+}
+
 // flags or-ed into `variant` (include/sdp.h): SDP_EXACT_STATE, SDP_WAVES(w)
 struct VariantBits {
     int variant, waves;
@@ -231,13 +241,14 @@ int sdp_max_cols(void) { return sdp::MAX_COLS; }
 size_t sdp_state_bytes(int B, int N, int M)
 {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
-    return (size_t)B * sdp::state_nstrips(N) * sdp::state_tpad(M) * 64 * 6;  // 2 x 23 bits per cell, 3 dwords per 2 cells
+    // 2 x 23 bits per cell, 3 dwords per 2 cells; + the launch order of a variable-length batch
+    return (size_t)B * sdp::state_nstrips(N) * sdp::state_tpad(M) * 64 * 6 + sdp::state_order_bytes(B);
 }
 
 size_t sdp_state_d_bytes(int B, int N, int M)
 {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
-    return (size_t)B * sdp::state_nstrips(N) * sdp::state_tpad(M) * 64 * sizeof(float2);
+    return (size_t)B * sdp::state_nstrips(N) * sdp::state_tpad(M) * 64 * sizeof(float2) + sdp::state_order_bytes(B);
 }
 
 int sdp_plan(int pass, int B, int N, int M, int has_lens, int exact_state, int cus, int *kernel_id, int *chunk,
@@ -287,6 +298,15 @@ int sdp_forward_f32(const float *theta, const float *A, float *state, float *Vt,
     p.vout = Vt;
     p.lens = lens;
     p.B = B, p.N = N, p.M = M, p.variant = variant;
+    if (wants_order(B, lens, device)) {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+        int *order = const_cast<int *>(order_in_state(state, B, N, M, exact));
+        hipLaunchKernelGGL(sdp_order_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, lens, order, B, N, M);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail_hip(e, "sdp_order_kernel");
+        p.order = order;
+    }
     return launch(sdp::PASS_FWD, p, device, stream, exact, vb.waves);
 }
 
@@ -304,6 +324,7 @@ int sdp_backward_f32(const float *Et, const float *state, float *E, int B, int N
     p.sout = E;
     p.lens = lens;
     p.B = B, p.N = N, p.M = M, p.variant = variant;
+    if (wants_order(B, lens, device)) p.order = order_in_state(state, B, N, M, exact);
     return launch(sdp::PASS_BWD, p, device, stream, exact, vb.waves);
 }
 
@@ -322,6 +343,7 @@ int sdp_adjoint_forward_f32(const float *state, const float *Ztheta, const float
     p.vout = Vtd;
     p.lens = lens;
     p.B = B, p.N = N, p.M = M, p.variant = variant;
+    if (wants_order(B, lens, device)) p.order = order_in_state(state, B, N, M, true);
     return launch(sdp::PASS_AFWD, p, device, stream, false, vb.waves);
 }
 
@@ -339,6 +361,7 @@ int sdp_adjoint_backward_f32(const float *E, const float *state, const float *st
     p.sout = Ed;
     p.lens = lens;
     p.B = B, p.N = N, p.M = M, p.variant = variant;
+    if (wants_order(B, lens, device)) p.order = order_in_state(state, B, N, M, true);
     return launch(sdp::PASS_ABWD, p, device, stream, false, vb.waves);
 }
 

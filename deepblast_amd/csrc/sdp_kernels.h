@@ -88,6 +88,7 @@ struct Params {
     int variant;
     int dbg;             // experiments build only (sdp_set_debug): bit0 inputs, bit1 outputs, bit2 state: all pairs alias
                          // pair 0; bit3: strips never publish their progress (exercises the hand-off time-out)
+    const int *order;    // launch order (pair per workgroup) or null = identity; lives in the tail of the Q state buffer
     int *status;         // host-visible status words of the device: [0] hand-off time-outs, [1..3] first (pair, strip, chunk | pass << 24)
 };
 
@@ -99,6 +100,9 @@ __host__ __device__ constexpr int stage_floats(int pass, int K)
     const int nout = (pass == PASS_BWD || pass == PASS_ABWD) ? 1 : 0;
     return nin * 64 * (2 * K) + nout * 64 * stage_out_pitch(K);
 }
+
+// tail of both state buffers: room for the launch order of a variable-length batch (B ints, 256-byte granules)
+__host__ __device__ inline size_t state_order_bytes(int B) { return ((size_t)B * 4 + 255) / 256 * 256; }
 
 // state geometry (shared by host and device)
 __host__ __device__ inline int state_nstrips(int N) { return (N + 63) / 64; }
@@ -127,6 +131,7 @@ __global__ void sdp_loss_fwd_kernel(const float *ref, const float *pred, const f
 __global__ void sdp_loss_bwd_kernel(const float *ref, const float *pred, const float *G, const int *lens, const float *scale, float *grad, int N, int M, int kind);
 __global__ void sdp_scores_kernel(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
                                   int M, int D);
+__global__ void sdp_order_kernel(const int *lens, int *order, int B, int N, int M);
 __global__ void sdp_traceback_kernel(const float *grad, int *states, int *counts, const int *lens, int B, int N, int M, int cap);
 }
 

@@ -344,7 +344,10 @@ __device__ __forceinline__ void sweep(const Params &p)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = blockDim.x >> 6;
-    const int b = blockIdx.x;
+    // batches with per-pair lengths and more pairs than CUs are launched longest-first (p.order: pair handled by
+    // each workgroup, written by sdp_order_kernel): the hardware hands workgroups to CUs in index order as they
+    // free up, which then is the longest-processing-time-first rule
+    const int b = p.order ? p.order[blockIdx.x] : (int)blockIdx.x;
 
     int n = p.N, m = p.M;
     if (p.lens) {
@@ -1591,6 +1594,29 @@ SDP_KERNEL(sdp_bwd_x_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, true)
 SDP_KERNEL(sdp_bwd_x_lat_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, true)
 SDP_KERNEL(sdp_adj_fwd_kernel, sdp::PASS_AFWD, SDP_K_AFWD, SDP_MAXW_AFWD)
 SDP_KERNEL(sdp_adj_bwd_kernel, sdp::PASS_ABWD, SDP_K_ABWD, SDP_MAXW_ABWD)
+
+// ----------------------------------------------------------------------------------
+// launch order for variable-length batches: order[r] = the pair with the r-th largest n*m (ties: lower index first).
+// Rank by counting -- B is at most a few thousand, the (B,2) lengths sit in L2 -- so no sort, no scratch memory.
+// ----------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(256) sdp_order_kernel(const int *lens, int *order, int B, int N, int M)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    auto work = [&](int i) {
+        int n = lens[2 * i], m = lens[2 * i + 1];
+        n = n < 1 ? 1 : (n > N ? N : n);
+        m = m < 1 ? 1 : (m > M ? M : m);
+        return n * m;
+    };
+    const int mine = work(b);
+    int rank = 0;
+    for (int i = 0; i < B; ++i) {
+        const int w = work(i);
+        rank += (w > mine || (w == mine && i < b)) ? 1 : 0;
+    }
+    order[rank] = b;
+}
 
 // ----------------------------------------------------------------------------------
 // batched traceback: the reference's greedy arg-max walk (deepblast/nw.py:401-444,

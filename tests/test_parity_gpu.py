@@ -163,6 +163,26 @@ def test_headline_config_second_order_full_batch():
     _assert(errs, "headline second order")
 
 
+@pytest.mark.parametrize("variant", [0, 1], ids=["nw", "sw"])
+def test_variable_length_batch_larger_than_the_gpu_runs_longest_first(variant):
+    """More pairs than CUs with per-pair lengths: the library launches them longest-first (sdp_order_kernel writes
+    the order into the tail of the state buffer, every sweep reads it).  Results must be those of the per-item
+    reference calls, in the ORIGINAL batch order, for all four sweeps."""
+    B, N, M = 700, 130, 150
+    theta, A = datagen.theta_A(4100, B, N, M)
+    Z = datagen.normal(4101, (B, N, M))
+    lens = datagen.lengths(4102, B, 1, 130)
+    lens[5] = (N, M)
+    lens[699] = (N, M - 1)
+    ref = parity.oracle_lens(theta, A, None, Z, variant, lens)
+    got = parity.engine_all(theta, A, None, Z, variant, lens=lens)
+    _assert(parity.compare(got, ref))
+    sel = [5, 6, 350, 699]   # a pair's results do not depend on the batch (or the launch position) it ran in
+    alone = parity.engine_all(theta[sel], A[sel], None, Z[sel], variant, lens=lens[sel])
+    for k in ("Vt", "E", "Ed", "Vtd"):
+        assert np.array_equal(alone[k], got[k][sel]), k
+
+
 def test_headline_config_full_batch():
     """BASELINE.json configs[1]: B=256, N=M=512, whole batch against the oracle, plus
     size-independent properties: batch independence (bit-exact) and linearity in Et."""
