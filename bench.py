@@ -155,13 +155,22 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"[bench] WORLD_SIZE={world} does not match --gpus {args.gpus}: refusing to time a "
                          f"different job than the one asked for")
+    # test hook (tests/test_distributed_nccl_gpu.py): exercise the N > 1 flow of this script on a 1-GPU box -- all ranks
+    # on device 0, collectives over gloo.  Never set for a measurement: the JSON line says so in config.backend.
+    shared = os.environ.get("BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if shared:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"[bench] rank {rank}: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} device(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import datagen
     from deepblast_amd import NeedlemanWunschDecoder, SmithWatermanDecoder
@@ -277,6 +286,7 @@ def main():
                                       f"(BASELINE.json configs[4] sharding: {B * world} pairs over {world} GPUs)"),
                        "global_batch": B * world, "N": N, "M": M, "variant": args.variant,
                        "parallelism": f"batch-sharded x{world}", "gather": args.gather if world > 1 else "none",
+                       "backend": ("rccl" if backend == "nccl" else backend + (" (ranks share one GPU: test mode)" if shared else "")) if world > 1 else "none",
                        "arith": "fwd: scaled exp-domain f32 (exact power-of-two rescaling); bwd: f32; adjoint pair: f64 carries; f32 storage"},
             "kernel_ms": ms,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

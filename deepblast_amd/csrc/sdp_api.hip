@@ -428,8 +428,8 @@ int sdp_loss_backward_f32(const float *ref, const float *pred, const float *G, c
     if (kind < 0 || kind > 2) return fail(SDP_E_VARIANT, "loss kind must be 0 (cross entropy), 1 (path) or 2 (alignment)");
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
-    const long long cells = (long long)N * M;
-    int gx = (int)((cells + 256 * 8 - 1) / (256 * 8));
+    const long long groups = (long long)N * ((M + 3) / 4);   // a thread writes four columns per iteration
+    int gx = (int)((groups + 256 * 4 - 1) / (256 * 4));
     if (gx < 1) gx = 1;
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(sdp_loss_bwd_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, ref, pred, G, lens, scale, grad, N, M,

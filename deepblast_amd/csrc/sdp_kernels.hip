@@ -1714,6 +1714,29 @@ __device__ __forceinline__ float loss_clamp(float p)
     return fminf(fmaxf(p, eps), 1.0f - eps);
 }
 
+// value of one counted cell (kind as above)
+__device__ __forceinline__ float loss_term(float r, float y, int kind)
+{
+    if (kind == 0) {
+        const float p = loss_clamp(y);
+        return r * logf(p) + (1.0f - r) * logf(1.0f - p);
+    }
+    const float d = kind == 1 ? r * y : r - y;
+    return d * d;
+}
+// derivative factor of one counted cell w.r.t. the predicted value
+__device__ __forceinline__ float loss_dterm(float r, float y, float sc, int kind)
+{
+    if (kind == 0) {
+        const float eps = 3e-8f;
+        return (y >= eps && y <= 1.0f - eps) ? sc * (r / y - (1.0f - r) / (1.0f - y)) : 0.f;  // clamp passes the gradient inside only
+    }
+    return kind == 1 ? sc * r * r * y : sc * (r - y);
+}
+
+// One workgroup per pair; a thread takes four consecutive columns of a row per iteration (one 16-byte load per
+// tensor when the rows are 16-byte aligned, i.e. M a multiple of 4), so the three tensors stream at full width and
+// there is one index division per four cells.  Per-thread float64 partial sums, fixed reduction order: deterministic.
 extern "C" __global__ void __launch_bounds__(1024) sdp_loss_fwd_kernel(const float *ref, const float *pred, const float *G,
                                                                        const int *lens, double *acc, int *cnt, int N, int M,
                                                                        int kind)
@@ -1729,25 +1752,34 @@ extern "C" __global__ void __launch_bounds__(1024) sdp_loss_fwd_kernel(const flo
     const size_t base = (size_t)b * N * M;
     double a = 0.0;
     int c = 0;
-    const int total = n * m;
+    const int q4 = (m + 3) >> 2;            // groups of four columns per row
+    const int total = n * q4;
+    const bool vec = (M & 3) == 0;
     for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-        const int i = idx / m, j = idx - i * m;
+        const int i = idx / q4, j = (idx - i * q4) << 2;
         const size_t o = base + (size_t)i * M + j;
-        if (G[o] != 0.f) {
-            const float r = ref[o], y = pred[o];
-            float v;
-            if (kind == 0) {
-                const float p = loss_clamp(y);
-                v = r * logf(p) + (1.0f - r) * logf(1.0f - p);
-            } else if (kind == 1) {
-                const float d = r * y;
-                v = d * d;
-            } else {
-                const float d = r - y;
-                v = d * d;
+        float g[4], r[4], y[4];
+        if (vec && j + 4 <= m) {
+            const float4 g4 = *reinterpret_cast<const float4 *>(G + o), r4 = *reinterpret_cast<const float4 *>(ref + o),
+                         y4 = *reinterpret_cast<const float4 *>(pred + o);
+            g[0] = g4.x, g[1] = g4.y, g[2] = g4.z, g[3] = g4.w;
+            r[0] = r4.x, r[1] = r4.y, r[2] = r4.z, r[3] = r4.w;
+            y[0] = y4.x, y[1] = y4.y, y[2] = y4.z, y[3] = y4.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool in = j + e < m;
+                g[e] = in ? G[o + e] : 0.f;
+                r[e] = in ? ref[o + e] : 0.f;
+                y[e] = in ? pred[o + e] : 0.5f;
             }
-            a += (double)v;
-            ++c;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (g[e] != 0.f) {
+                a += (double)loss_term(r[e], y[e], kind);
+                ++c;
+            }
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -1766,6 +1798,8 @@ extern "C" __global__ void __launch_bounds__(1024) sdp_loss_fwd_kernel(const flo
     }
 }
 
+// grid (x, B): the workgroups of a pair stride over groups of four columns of the FULL padded matrix (grad is written
+// in full: zero outside the pair's block and where G is 0)
 extern "C" __global__ void __launch_bounds__(256) sdp_loss_bwd_kernel(const float *ref, const float *pred, const float *G,
                                                                       const int *lens, const float *scale, float *grad, int N,
                                                                       int M, int kind)
@@ -1778,23 +1812,41 @@ extern "C" __global__ void __launch_bounds__(256) sdp_loss_bwd_kernel(const floa
     }
     const float sc = scale[b];
     const size_t base = (size_t)b * N * M;
-    const int total = N * M;
+    const int q4 = (M + 3) >> 2;
+    const int total = N * q4;
+    const bool vec = (M & 3) == 0;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int i = idx / M, j = idx - i * M;
-        const size_t o = base + idx;
-        float g = 0.f;
-        if (i < n && j < m && G[o] != 0.f) {
-            const float r = ref[o], y = pred[o];
-            if (kind == 0) {
-                const float eps = 3e-8f;
-                if (y >= eps && y <= 1.0f - eps) g = sc * (r / y - (1.0f - r) / (1.0f - y));  // clamp passes the gradient inside only
-            } else if (kind == 1) {
-                g = sc * r * r * y;
+        const int i = idx / q4, j = (idx - i * q4) << 2;
+        const size_t o = base + (size_t)i * M + j;
+        float out[4] = {0.f, 0.f, 0.f, 0.f};
+        if (i < n && j < m) {
+            float g[4], r[4], y[4];
+            if (vec) {   // j + 4 <= M: the group lies inside the row (cells at or beyond m are masked below)
+                const float4 g4 = *reinterpret_cast<const float4 *>(G + o), r4 = *reinterpret_cast<const float4 *>(ref + o),
+                             y4 = *reinterpret_cast<const float4 *>(pred + o);
+                g[0] = g4.x, g[1] = g4.y, g[2] = g4.z, g[3] = g4.w;
+                r[0] = r4.x, r[1] = r4.y, r[2] = r4.z, r[3] = r4.w;
+                y[0] = y4.x, y[1] = y4.y, y[2] = y4.z, y[3] = y4.w;
             } else {
-                g = sc * (r - y);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool in = j + e < m;
+                    g[e] = in ? G[o + e] : 0.f;
+                    r[e] = in ? ref[o + e] : 0.f;
+                    y[e] = in ? pred[o + e] : 0.5f;
+                }
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (j + e < m && g[e] != 0.f) out[e] = loss_dterm(r[e], y[e], sc, kind);
         }
-        grad[o] = g;
+        if (vec) {
+            *reinterpret_cast<float4 *>(grad + o) = make_float4(out[0], out[1], out[2], out[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (j + e < M) grad[o + e] = out[e];
+        }
     }
 }
 

@@ -92,3 +92,25 @@ def test_bench_refuses_more_gpus_than_present():
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "device(s) visible" in (r.stderr + r.stdout)
     assert '"n_gpus"' not in r.stdout
+
+
+def test_bench_two_ranks_flow_on_one_gpu():
+    """The N > 1 flow of bench.py (rank setup, sharded step, Vt gather under the backward sweep, max-over-ranks timing,
+    the secondary E-gather figure, one JSON line from rank 0) exercised with two ranks that share GPU 0 and talk over
+    gloo -- what a 1-GPU box can check of the path the driver runs on 8 GPUs over RCCL."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(BENCH_SHARE_GPU="1", BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--B", "24", "--N", "200", "--M", "180"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["global_batch"] == 48 and d["config"]["gather"] == "vt"
+    assert d["value"] > 0 and d["with_e_gather"]["value"] > 0 and "cpu_baseline" not in d
+    assert d["scaling"] == "weak" and "test mode" in d["config"]["backend"]
