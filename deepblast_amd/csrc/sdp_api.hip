@@ -177,7 +177,8 @@ int pending_handoff_error(int device)
 bool wants_order(int B, const int32_t *lens, int device) { return lens != nullptr && B > num_cus(device); }
 const int *order_in_state(const void *state, int B, int N, int M, bool exact)
 {
-    const size_t body = (size_t)B * sdp::state_nstrips(N) * sdp::state_tpad(M) * 64 * (exact ? sizeof(float2) : 6);
+    const size_t body = exact ? (size_t)B * sdp::state_rows2(N, M) * 64 * sizeof(float2)
+                              : (size_t)B * sdp::state_nstrips(N) * sdp::state_tpad(M) * 64 * 6;
     return reinterpret_cast<const int *>(static_cast<const char *>(state) + body);
 }
 
@@ -248,7 +249,7 @@ size_t sdp_state_bytes(int B, int N, int M)
 size_t sdp_state_d_bytes(int B, int N, int M)
 {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
-    return (size_t)B * sdp::state_nstrips(N) * sdp::state_tpad(M) * 64 * sizeof(float2) + sdp::state_order_bytes(B);
+    return (size_t)B * sdp::state_rows2(N, M) * 64 * sizeof(float2) + sdp::state_order_bytes(B);
 }
 
 int sdp_plan(int pass, int B, int N, int M, int has_lens, int exact_state, int cus, int *kernel_id, int *chunk,

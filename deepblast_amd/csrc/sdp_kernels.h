@@ -104,6 +104,11 @@ __host__ __device__ constexpr int stage_floats(int pass, int K)
 // tail of both state buffers: room for the launch order of a variable-length batch (B ints, 256-byte granules)
 __host__ __device__ inline size_t state_order_bytes(int B) { return ((size_t)B * 4 + 255) / 256 * 256; }
 
+// float2 states (exact Q, Qd): strips lie M rows apart (no skew padding, see sdp_kernels.hip); a pair owns
+// nstrips * M rows plus room for the last strip's tail ramp and the chunk rounding of the last prefetch
+constexpr int STATE2_SLACK = 64 + 64;
+__host__ __device__ inline size_t state_rows2(int N, int M) { return (size_t)((N + 63) / 64) * M + STATE2_SLACK; }
+
 // state geometry (shared by host and device)
 __host__ __device__ inline int state_nstrips(int N) { return (N + 63) / 64; }
 __host__ __device__ inline int state_tpad(int M) { return (M + 63 + 63) / 64 * 64; }

@@ -497,13 +497,19 @@ __device__ __forceinline__ void sweep(const Params &p)
         };
         // float2 states (Qd, and Q in its exact form): one step is a 512-byte row: step t, lane l lives at byte
         // t*512 + l*8.  Step offsets go through the scalar offset operand, the lane offset is a per-lane constant.
-        const unsigned st_bytes = (unsigned)p.tpad * 512u;
+        // The float2 states carry NO skew padding: the rows of strip s start M rows after those of strip s-1, so the
+        // 63 rows of its tail ramp (steps t >= M, where only the lanes l > t - M still sit on real cells) are the rows
+        // of the head ramp of strip s+1 (steps t' = t - M, live lanes l <= t') -- complementary halves of the same
+        // rows.  Cells outside the matrix are therefore never stored (store_f2's `ok`); loading them returns whatever
+        // the other strip put there, which every reader masks (a dead cell's weights are forced to 0).
+        const size_t st_base2 = ((size_t)b_st * state_rows2(p.N, p.M) + (size_t)s * p.M) * 64;
+        const unsigned st_bytes = (unsigned)(p.M + STATE2_SLACK) * 512u;
         const unsigned st_lane = lane * 8;
-        __amdgpu_buffer_rsrc_t rs_d = make_rsrc(T::DIN ? (const void *)(p.din + st_base)
-                                                       : (T::DOUT ? (const void *)(static_cast<float2 *>(p.dout) + st_base) : (const void *)p.vout),
+        __amdgpu_buffer_rsrc_t rs_d = make_rsrc(T::DIN ? (const void *)(p.din + st_base2)
+                                                       : (T::DOUT ? (const void *)(static_cast<float2 *>(p.dout) + st_base2) : (const void *)p.vout),
                                                 (T::DIN || T::DOUT) ? st_bytes : 0u);
-        __amdgpu_buffer_rsrc_t rs_qx = make_rsrc(T::QIN == Q_EXACT ? (const void *)(reinterpret_cast<const float2 *>(p.qin) + st_base)
-                                                 : (T::QOUT == Q_EXACT ? (const void *)(static_cast<float2 *>(p.dout) + st_base) : (const void *)p.vout),
+        __amdgpu_buffer_rsrc_t rs_qx = make_rsrc(T::QIN == Q_EXACT ? (const void *)(reinterpret_cast<const float2 *>(p.qin) + st_base2)
+                                                 : (T::QOUT == Q_EXACT ? (const void *)(static_cast<float2 *>(p.dout) + st_base2) : (const void *)p.vout),
                                                  (T::QIN == Q_EXACT || T::QOUT == Q_EXACT) ? st_bytes : 0u);
         auto load_f2 = [&](__amdgpu_buffer_rsrc_t rs, int t_base, int k) {  // row t_base + k
             const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, st_lane + (k & 7) * 512, (t_base + (k & ~7)) * 512, AUX_ST_LOAD);
@@ -512,16 +518,17 @@ __device__ __forceinline__ void sweep(const Params &p)
             const unsigned lo = v[0], hi = v[1];
             return make_float2(__uint_as_float(lo), __uint_as_float(hi));
         };
-        auto store_f2 = [&](__amdgpu_buffer_rsrc_t rs, int t_base, int k, float2 qq) {
+        auto store_f2 = [&](__amdgpu_buffer_rsrc_t rs, int t_base, int k, float2 qq, bool ok) {
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             u32x2 v;
             v[0] = __float_as_uint(qq.x);
             v[1] = __float_as_uint(qq.y);
-            __builtin_amdgcn_raw_buffer_store_b64(v, rs, st_lane + (k & 7) * 512, (t_base + (k & ~7)) * 512, AUX_ST_STORE);
+            __builtin_amdgcn_raw_buffer_store_b64(v, rs, ok ? st_lane + (k & 7) * 512 : OOB, (t_base + (k & ~7)) * 512, AUX_ST_STORE);
         };
         auto load_d = [&](int t_base, int k) { return load_f2(rs_d, t_base, k); };
         float2 qhold;  // forward: weights of the even step of the current pair of steps
-        auto store_state = [&](int t_base, int k, float2 qq) {  // the state this pass produces, step t_base + k
+        // the state this pass produces, step t_base + k; `ok`: the lane's cell lies inside the matrix (float2 formats only)
+        auto store_state = [&](int t_base, int k, float2 qq, bool ok = true) {
             if constexpr (T::QOUT == Q_PACKED) {
                 if ((k & 1) == 0) {
                     qhold = qq;
@@ -531,9 +538,9 @@ __device__ __forceinline__ void sweep(const Params &p)
                     store_q(t_base, k >> 1, w);
                 }
             } else if constexpr (T::QOUT == Q_EXACT) {
-                store_f2(rs_qx, t_base, k, qq);
+                store_f2(rs_qx, t_base, k, qq, ok);
             } else {
-                store_f2(rs_d, t_base, k, qq);
+                store_f2(rs_d, t_base, k, qq, ok);
             }
         };
 
@@ -850,7 +857,8 @@ __device__ __forceinline__ void sweep(const Params &p)
                             if constexpr (QX) {
                                 float2 qq = make_float2(tq * u, tq * x);
                                 q_sharpen(qq.x, qq.y, d * rinv);
-                                if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(tb, j, qq);
+                                if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); }
+                                else store_state(tb, j, qq, !EDGE || (unsigned)(tb + j - lane) < (unsigned)m);
                             } else {
                                 // both weights with one packed multiply, their biased fields with one packed fma
                                 const f32x2 w = (f32x2){u, x} * (f32x2){tq, tq};
@@ -928,7 +936,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                             {
                                 float2 qq = make_float2(tq * u, tq * l);
                                 if constexpr (QX) q_sharpen(qq.x, qq.y, d * rinv);
-                                if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(tb, j, qq);
+                                if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(tb, j, qq, !EDGE || (unsigned)col < (unsigned)m);
                             }
                             const float an = ct * ssum;
                             float na = __builtin_amdgcn_frexp_mantf(an);
@@ -1162,7 +1170,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                     if constexpr (ABL_NOMATH) {
                         if constexpr (T::QOUT != Q_NONE || T::DOUT) {
                             float2 qq = make_float2(in0[k], T::QIN != Q_NONE ? q0.x + q0.y : in1[k]);
-                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
+                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq, inside);
                         }
                         if constexpr (T::SOUT > 0) lo[k] = q0.x + q0.y + (T::DIN ? q1.x + q1.y : 0.f) + (T::SIN > 0 ? in0[k] : 0.f);
                         hist[k] = 0;
@@ -1193,7 +1201,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         {
                             float2 qq = make_float2(tq * u, tq * l);
                             if constexpr (QX) q_sharpen(qq.x, qq.y, d * rinv);
-                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
+                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq, inside);
                         }
                         const float an = ct * ssum;
                         float na = __builtin_amdgcn_frexp_mantf(an);
@@ -1225,7 +1233,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         const double v = ((double)th + mx) + (double)fast_log(ssum);
                         {
                             float2 qq = make_float2(ex * inv, ey * inv);
-                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
+                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq, inside);
                         }
                         cy.b = up;
                         cy.a = (!EDGE || (col >= 0 && !dead)) ? v : 0.0;
@@ -1245,7 +1253,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         const double vd = (double)zt + tot;
                         {
                             float2 qq = make_float2((float)(qx * (a0 - tot)), (float)(qy * (a2 - tot)));
-                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
+                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq, inside);
                         }
                         cy.b = up;
                         cy.a = inside ? vd : 0.0;
@@ -1398,7 +1406,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         {
                             float2 qq = make_float2(tq * u, tq * x);
                             if constexpr (QX) q_sharpen(qq.x, qq.y, d * rinv);
-                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
+                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq, !EDGE || (unsigned)(t0 + k - lane) < (unsigned)m);
                         }
                         d = u;
                         x = ct * ssum;

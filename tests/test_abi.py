@@ -52,7 +52,8 @@ def test_state_bytes(lib):
     assert lib.sdp_state_bytes(256, 512, 512) == 256 * 8 * 576 * 64 * 6 + 1024
     assert lib.sdp_state_bytes(1, 1, 1) == 1 * 1 * 64 * 64 * 6 + 256
     assert lib.sdp_state_bytes(3, 65, 2) == 3 * 2 * 128 * 64 * 6 + 256
-    assert lib.sdp_state_d_bytes(256, 512, 512) == 256 * 8 * 576 * 64 * 8 + 1024
+    # float2 states: strips M rows apart (no skew padding) + 128 rows of slack per pair
+    assert lib.sdp_state_d_bytes(256, 512, 512) == 256 * (8 * 512 + 128) * 64 * 8 + 1024
     assert lib.sdp_state_d_bytes(0, 5, 5) == 0
     assert lib.sdp_state_bytes(0, 5, 5) == 0
 
