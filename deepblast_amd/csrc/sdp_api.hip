@@ -174,11 +174,15 @@ int pending_handoff_error(int device)
 // Variable-length batches with more pairs than CUs run longest-first.  The order is computed by the forward call
 // (sdp_order_kernel) into the tail of the state buffer it fills, and the other sweeps -- which receive that state
 // and must be given the same lengths -- read it from there.
+size_t packed_body_bytes(int B, int N, int M)
+{
+    return SDP_PACKED_DEPAD ? (size_t)B * sdp::stateq_rows(N, M) * 768 : (size_t)B * sdp::state_nstrips(N) * sdp::state_tpad(M) * 64 * 6;
+}
 bool wants_order(int B, const int32_t *lens, int device) { return lens != nullptr && B > num_cus(device); }
 const int *order_in_state(const void *state, int B, int N, int M, bool exact)
 {
     const size_t body = exact ? (size_t)B * sdp::state_rows2(N, M) * 64 * sizeof(float2)
-                              : (size_t)B * sdp::state_nstrips(N) * sdp::state_tpad(M) * 64 * 6;
+                              : packed_body_bytes(B, N, M);
     return reinterpret_cast<const int *>(static_cast<const char *>(state) + body);
 }
 
@@ -242,8 +246,9 @@ int sdp_max_cols(void) { return sdp::MAX_COLS; }
 size_t sdp_state_bytes(int B, int N, int M)
 {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
-    // 2 x 23 bits per cell, 3 dwords per 2 cells; + the launch order of a variable-length batch
-    return (size_t)B * sdp::state_nstrips(N) * sdp::state_tpad(M) * 64 * 6 + sdp::state_order_bytes(B);
+    // 2 x 23 bits per cell, 3 dwords per 2 cells (a 768-byte record row per pair of steps); + the launch order of a
+    // variable-length batch
+    return packed_body_bytes(B, N, M) + sdp::state_order_bytes(B);
 }
 
 size_t sdp_state_d_bytes(int B, int N, int M)

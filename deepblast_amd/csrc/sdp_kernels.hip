@@ -474,9 +474,18 @@ __device__ __forceinline__ void sweep(const Params &p)
         const size_t st_base = (b_st * p.nstrips_max + s) * p.tpad * 64;
         // Q: 6 bytes per cell, two steps per lane and access: steps 2j, 2j+1 of lane l are the 12 bytes at
         // j*768 + l*12, so one dwordx3 per lane moves two steps (768 B per wave access).
-        const unsigned q_bytes = (unsigned)p.tpad * 384u, q_lane = lane * 12;
-        __amdgpu_buffer_rsrc_t rs_q = make_rsrc(T::QIN == Q_PACKED ? (const void *)(p.qin + st_base * 3 / 2)
-                                                : (T::QOUT == Q_PACKED ? (const void *)(static_cast<uint32_t *>(p.dout) + st_base * 3 / 2) : (const void *)p.vout),
+        // Shared ramp rows (SDP_PACKED_DEPAD): like the float2 states the packed state carries no skew padding -- strip
+        // s+1's records start ceil(M/2) record rows after strip s's, so the tail ramp of strip s (steps t >= M, live
+        // lanes l > t - M) and the head ramp of strip s+1 (steps t - M, live lanes l <= t - M) fill complementary lanes
+        // of the same rows.  A record holds TWO steps of a lane, so the lane on the boundary of a row owns only half
+        // of its record (first step from one strip, second from the other): the forward sweep stores records whose
+        // two cells are inside the matrix whole, half-inside ones as 6 bytes (dword + short), others not at all.
+        const size_t stq_base = SDP_PACKED_DEPAD ? ((size_t)b_st * stateq_rows(p.N, p.M) + (size_t)s * stateq_pitch(p.M)) * 192
+                                                 : st_base * 3 / 2;   // in dwords
+        const unsigned q_bytes = SDP_PACKED_DEPAD ? (unsigned)(stateq_pitch(p.M) + STATEQ_SLACK) * 768u : (unsigned)p.tpad * 384u;
+        const unsigned q_lane = lane * 12;
+        __amdgpu_buffer_rsrc_t rs_q = make_rsrc(T::QIN == Q_PACKED ? (const void *)(p.qin + stq_base)
+                                                : (T::QOUT == Q_PACKED ? (const void *)(static_cast<uint32_t *>(p.dout) + stq_base) : (const void *)p.vout),
                                                 (T::QIN == Q_PACKED || T::QOUT == Q_PACKED) ? q_bytes : 0u);
         typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
         auto load_q = [&](int t_base, int g, unsigned *dst) {  // steps t_base + 2g, + 1
@@ -484,10 +493,10 @@ __device__ __forceinline__ void sweep(const Params &p)
             const unsigned v0 = v[0], v1 = v[1], v2 = v[2];
             dst[0] = v0, dst[1] = v1, dst[2] = v2;
         };
-        auto store_q = [&](int t_base, int g, const unsigned *src) {
+        auto store_q = [&](int t_base, int g, const unsigned *src, bool ok = true) {
             u32x3 v;
             v[0] = src[0], v[1] = src[1], v[2] = src[2];
-            __builtin_amdgcn_raw_buffer_store_b96(v, rs_q, q_lane + (g & 3) * 768, (t_base / 2 + (g & ~3)) * 768, AUX_ST_STORE);
+            __builtin_amdgcn_raw_buffer_store_b96(v, rs_q, ok ? q_lane + (g & 3) * 768 : OOB, (t_base / 2 + (g & ~3)) * 768, AUX_ST_STORE);
             // A VALU instruction that overwrites a data register of a store wider than 64 bits in the very next
             // issue slot corrupts the stored value for part of the wave on gfx950 (seen: lanes 12-15 of every
             // 16).  The compiler only inserts the wait state for stores without a scalar offset register, so it
@@ -502,8 +511,8 @@ __device__ __forceinline__ void sweep(const Params &p)
         // of the head ramp of strip s+1 (steps t' = t - M, live lanes l <= t') -- complementary halves of the same
         // rows.  Cells outside the matrix are therefore never stored (store_f2's `ok`); loading them returns whatever
         // the other strip put there, which every reader masks (a dead cell's weights are forced to 0).
-        const size_t st_base2 = ((size_t)b_st * state_rows2(p.N, p.M) + (size_t)s * p.M) * 64;
-        const unsigned st_bytes = (unsigned)(p.M + STATE2_SLACK) * 512u;
+        const size_t st_base2 = SDP_F2_DEPAD ? ((size_t)b_st * state_rows2(p.N, p.M) + (size_t)s * p.M) * 64 : st_base;
+        const unsigned st_bytes = SDP_F2_DEPAD ? (unsigned)(p.M + STATE2_SLACK) * 512u : (unsigned)p.tpad * 512u;
         const unsigned st_lane = lane * 8;
         __amdgpu_buffer_rsrc_t rs_d = make_rsrc(T::DIN ? (const void *)(p.din + st_base2)
                                                        : (T::DOUT ? (const void *)(static_cast<float2 *>(p.dout) + st_base2) : (const void *)p.vout),
@@ -523,7 +532,7 @@ __device__ __forceinline__ void sweep(const Params &p)
             u32x2 v;
             v[0] = __float_as_uint(qq.x);
             v[1] = __float_as_uint(qq.y);
-            __builtin_amdgcn_raw_buffer_store_b64(v, rs, ok ? st_lane + (k & 7) * 512 : OOB, (t_base + (k & ~7)) * 512, AUX_ST_STORE);
+            __builtin_amdgcn_raw_buffer_store_b64(v, rs, (ok || !SDP_F2_DEPAD) ? st_lane + (k & 7) * 512 : OOB, (t_base + (k & ~7)) * 512, AUX_ST_STORE);
         };
         auto load_d = [&](int t_base, int k) { return load_f2(rs_d, t_base, k); };
         float2 qhold;  // forward: weights of the even step of the current pair of steps
@@ -546,16 +555,43 @@ __device__ __forceinline__ void sweep(const Params &p)
 
         // packed state, forward: the two biased fields of a cell (bits of 1 + q * Q_SCALE) arrive per step; every
         // second step three byte-permutes assemble the 12-byte record of the pair and one dwordx3 store moves it
+        // `live`: the step's cell lies inside the matrix (always true in blocks that are wholly inside).  Half-inside
+        // records are remembered -- a lane has at most one that starts and one that ends per strip -- and written by
+        // flush_half_records() at the end of the block.
         unsigned qbits_x = 0, qbits_y = 0;
-        auto store_state_bits = [&](int t_base, int k, unsigned fx, unsigned fy) {
+        bool qlive0 = true;
+        unsigned half_off[2] = {OOB, OOB}, half_dw[2] = {0u, 0u}, half_sh[2] = {0u, 0u};   // [0] second half, [1] first half
+        auto store_state_bits = [&](int t_base, int k, unsigned fx, unsigned fy, bool live = true) {
             if ((k & 1) == 0) {
-                qbits_x = fx, qbits_y = fy;
+                qbits_x = fx, qbits_y = fy, qlive0 = live;
             } else {
                 unsigned w[3];
                 w[0] = __builtin_amdgcn_perm(qbits_y, qbits_x, 0x04020100u);
                 w[1] = __builtin_amdgcn_perm(fx, qbits_y, 0x05040201u);
                 w[2] = __builtin_amdgcn_perm(fy, fx, 0x06050402u);
-                store_q(t_base, k >> 1, w);
+                if constexpr (SDP_PACKED_DEPAD) {
+                    store_q(t_base, k >> 1, w, qlive0 && live);
+                    const unsigned rec = q_lane + (unsigned)(k >> 1) * 768u;   // relative to the block's first record row
+                    const bool second = !qlive0 && live, first = qlive0 && !live;
+                    half_off[0] = second ? rec + 6u : half_off[0];   // bytes 6..11: short at +6, dword at +8
+                    half_sh[0] = second ? w[1] >> 16 : half_sh[0];
+                    half_dw[0] = second ? w[2] : half_dw[0];
+                    half_off[1] = first ? rec : half_off[1];         // bytes 0..5: dword at +0, short at +4
+                    half_dw[1] = first ? w[0] : half_dw[1];
+                    half_sh[1] = first ? (w[1] & 0xffffu) : half_sh[1];
+                } else {
+                    store_q(t_base, k >> 1, w);
+                }
+            }
+        };
+        auto flush_half_records = [&](int t_base) {
+            if constexpr (SDP_PACKED_DEPAD && T::QOUT == Q_PACKED) {
+                const int soff = (t_base / 2) * 768;
+                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)half_sh[0], rs_q, half_off[0], soff, AUX_ST_STORE);
+                __builtin_amdgcn_raw_buffer_store_b32(half_dw[0], rs_q, half_off[0] + 2u, soff, AUX_ST_STORE);
+                __builtin_amdgcn_raw_buffer_store_b32(half_dw[1], rs_q, half_off[1], soff, AUX_ST_STORE);
+                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)half_sh[1], rs_q, half_off[1] + 4u, soff, AUX_ST_STORE);
+                half_off[0] = half_off[1] = OOB;
             }
         };
 
@@ -731,6 +767,8 @@ __device__ __forceinline__ void sweep(const Params &p)
         // Both forms produce identical bits (same 2^theta, exact power-of-two rescaling), so results do not depend on
         // which form a block ran in, on K, or on the batch.
         constexpr bool FWD_SUB = PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_WF && SDP_FWD_SUB;
+        static_assert(!(SDP_PACKED_DEPAD && PASS == PASS_FWD && !QX) || FWD_SUB,
+                      "the packed state without padding needs the block-wise forward sweep: build with -DSDP_PACKED_DEPAD=0");
         auto fwd_blocks = [&](int c, int t0) {
             if constexpr (FWD_SUB) {
                 int thr = lane + (sw ? 1 : 0);  // EDGE: the lane's cell is live at step t iff t >= thr
@@ -864,7 +902,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                                 const f32x2 w = (f32x2){u, x} * (f32x2){tq, tq};
                                 const f32x2 f = __builtin_elementwise_fma(w, (f32x2){Q_SCALE, Q_SCALE}, (f32x2){1.0f, 1.0f});
                                 if constexpr (ABL_NOSTORE) { float fx = f[0], fy = f[1]; keep(fx); keep(fy); }
-                                else store_state_bits(tb, j, __float_as_uint(f[0]), __float_as_uint(f[1]));
+                                else store_state_bits(tb, j, __float_as_uint(f[0]), __float_as_uint(f[1]), !EDGE || (unsigned)(tb + j - lane) < (unsigned)m);
                             }
                             d = u;
                             x = ct * ssum;
@@ -878,6 +916,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                             mx = max(mx, __float_as_uint(x));
                             hist[j] = pack2(__float_as_uint(x), (unsigned)R);
                         }
+                        if constexpr (EDGE && !QX) flush_half_records(tb);
                         if (__builtin_amdgcn_ballot_w64(mx > WF_HI || mn < WF_LO || mc > WF_FMAX) != 0) return -1;  // carry untouched
                         cy.xa = __builtin_amdgcn_frexp_mantf(x);
                         cy.xe = R + __builtin_amdgcn_frexp_expf(x);
@@ -935,8 +974,12 @@ __device__ __forceinline__ void sweep(const Params &p)
                             const float tq = ca * rinv;
                             {
                                 float2 qq = make_float2(tq * u, tq * l);
+                                const bool cell_in = !EDGE || (unsigned)col < (unsigned)m;
                                 if constexpr (QX) q_sharpen(qq.x, qq.y, d * rinv);
-                                if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(tb, j, qq, !EDGE || (unsigned)col < (unsigned)m);
+                                if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); }
+                                else if constexpr (QX) store_state(tb, j, qq, cell_in);
+                                else store_state_bits(tb, j, __float_as_uint(__builtin_fmaf(qq.x, Q_SCALE, 1.0f)),
+                                                      __float_as_uint(__builtin_fmaf(qq.y, Q_SCALE, 1.0f)), cell_in);
                             }
                             const float an = ct * ssum;
                             float na = __builtin_amdgcn_frexp_mantf(an);
@@ -953,6 +996,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                             hist[j] = pack2(__float_as_uint(na), (unsigned)ne);
                             if constexpr (EDGE) vt_keep = (t == t_final) ? hist[j] : vt_keep;
                         }
+                        if constexpr (EDGE && !QX) flush_half_records(tb);
                         // publish in one frame whenever the 16 values fit (exact rescaling to the exponent of the last
                         // one), so that the strip below can use the windowed form; only the publishing lane matters
                         if (has_succ) {

@@ -48,12 +48,12 @@ def test_version_and_limits(lib):
 
 def test_state_bytes(lib):
     # Q: 6 B (two 23-bit weights) per cell of the skewed layout; Qd: float2 per cell
-    # (+ a tail for the launch order of variable-length batches: B ints, rounded up to 256 bytes)
+    # Q: 6 B (two 23-bit weights) per cell of the skewed, padded layout (+ a tail for the launch order of
+    # variable-length batches: B ints, 256-byte granules)
     assert lib.sdp_state_bytes(256, 512, 512) == 256 * 8 * 576 * 64 * 6 + 1024
     assert lib.sdp_state_bytes(1, 1, 1) == 1 * 1 * 64 * 64 * 6 + 256
     assert lib.sdp_state_bytes(3, 65, 2) == 3 * 2 * 128 * 64 * 6 + 256
-    # float2 states: strips M rows apart (no skew padding) + 128 rows of slack per pair
-    assert lib.sdp_state_d_bytes(256, 512, 512) == 256 * (8 * 512 + 128) * 64 * 8 + 1024
+    assert lib.sdp_state_d_bytes(256, 512, 512) == 256 * 8 * 576 * 64 * 8 + 1024
     assert lib.sdp_state_d_bytes(0, 5, 5) == 0
     assert lib.sdp_state_bytes(0, 5, 5) == 0
 

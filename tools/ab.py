@@ -10,7 +10,7 @@ L = {k: gpu_tune.load(v) for k, v in libs.items()}
 shapes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:] if "x" in a] or [(16, 512, 512), (256, 512, 512)]
 W = [int(a[2:]) for a in sys.argv[1:] if a.startswith("W=")]
 W = W[0] if W else 0
-passes = "fba" if "adj" in sys.argv else "fb"
+passes = "fba" if "adj" in sys.argv else "fb"  # adj: also the exact-state forward and the adjoint pair
 for (B, N, M) in shapes:
     res = {k: [] for k in L}
     for rep in range(3):
