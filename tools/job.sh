@@ -1,3 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 600 python tools/ab.py 256x512x512 adj > gpurun_out/ab.txt 2>&1; cat gpurun_out/ab.txt
+bash tools/gpu_sq.sh sqr2 256 > gpurun_out/sq_r2.txt 2>&1; tail -12 gpurun_out/sq_r2.txt
