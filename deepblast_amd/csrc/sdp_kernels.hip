@@ -134,6 +134,17 @@ __device__ __forceinline__ int lds_load_i32(unsigned addr)
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
     return v;
 }
+// split form: issue the read, do other LDS reads behind it (a wave's DS instructions execute in order), wait once
+__device__ __forceinline__ int lds_issue_i32(unsigned addr)
+{
+    int v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_wait(int &v)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) : : "memory");
+}
 __device__ __forceinline__ void lds_store_i32(unsigned addr, int v)
 {
     asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(v) : "memory");
@@ -781,23 +792,6 @@ __device__ __forceinline__ void sweep(const Params &p)
                     // place, and the rare fallback simply reads the row again -- the strip above cannot overwrite these
                     // columns before this strip has produced its own)
                     const bool use_pred = has_pred && tb < m;
-                    if (use_pred) {
-                        const int need = tb + WB < m ? tb + WB : m;
-                        bool ready = ABL_NOSYNC;
-                        const int spin_cap = (SDP_EXP_BUILD && (p.dbg & 8)) ? (1 << 10) : (1 << 21);
-                        for (int spin = 0; !ABL_NOSYNC && spin < spin_cap; ++spin) {
-                            if (__builtin_amdgcn_readfirstlane(lds_load_i32(prog + 4 * pword)) >= pbase + need) {
-                                ready = true;
-                                break;
-                            }
-                            __builtin_amdgcn_s_sleep(1);
-                        }
-                        if (!ready && p.status && lane == 0) {
-                            if (__hip_atomic_fetch_add(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
-                                p.status[1] = b, p.status[2] = s, p.status[3] = c | (PASS << 24);
-                            }
-                        }
-                    }
                     auto read_bcv = [&](u64 *bcv) {
                         if (use_pred) {
                             if (tb + WB <= m) {
@@ -812,6 +806,20 @@ __device__ __forceinline__ void sweep(const Params &p)
                             for (int j = 0; j < WB; ++j) bcv[j] = edge_zero<KIND>();
                         }
                     };
+                    // One LDS round trip per block instead of four: the progress word of the strip above is read FIRST,
+                    // the boundary values, their frame words and (below) this block's inputs are read right behind it, and
+                    // there is a single wait.  LDS executes a wave's reads in order, so if the progress word already covers
+                    // the block, the values read behind it are the published ones; otherwise (only while the pipeline
+                    // fills) the wave spins as before and reads them again.
+                    u64 bcv0[WB];
+                    int fa0 = 0, fb0 = 0, prog_seen = 0;
+                    const int need = tb + WB < m ? tb + WB : m;
+                    if (use_pred) {
+                        if constexpr (!ABL_NOSYNC) prog_seen = lds_issue_i32(prog + 4 * pword);
+                        read_bcv(bcv0);
+                        fa0 = frm_in[(tb + 63) / WB];                    // block that produced column tb
+                        fb0 = tb + 1 < m ? frm_in[(tb + 64) / WB] : fa0;  // ... columns tb+1 .. tb+WB-1
+                    }
                     // ---- staged inputs of this block ----
                     float in0[WB], in1[WB];
                     {
@@ -825,6 +833,34 @@ __device__ __forceinline__ void sweep(const Params &p)
                             in1[4 * g] = v1.x, in1[4 * g + 1] = v1.y, in1[4 * g + 2] = v1.z, in1[4 * g + 3] = v1.w;
                         }
                     }
+                    if (use_pred) {
+                        bool ready = ABL_NOSYNC;
+                        if constexpr (!ABL_NOSYNC) {
+                            lds_wait(prog_seen);
+                            ready = __builtin_amdgcn_readfirstlane(prog_seen) >= pbase + need;
+                        }
+                        if (!ready) {
+                            // bounded spin: a missed hand-off must never hang the device (~0.2 s at the cap).  If it ever
+                            // gives up the results of this pair are wrong, so the wave says so in the status words the host
+                            // checks on its next call (sdp_api.hip: SDP_E_HANDOFF) -- it does not carry on silently.
+                            const int spin_cap = (SDP_EXP_BUILD && (p.dbg & 8)) ? (1 << 10) : (1 << 21);
+                            for (int spin = 0; spin < spin_cap; ++spin) {
+                                if (__builtin_amdgcn_readfirstlane(lds_load_i32(prog + 4 * pword)) >= pbase + need) {
+                                    ready = true;
+                                    break;
+                                }
+                                __builtin_amdgcn_s_sleep(1);
+                            }
+                            if (!ready && p.status && lane == 0) {
+                                if (__hip_atomic_fetch_add(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+                                    p.status[1] = b, p.status[2] = s, p.status[3] = c | (PASS << 24);
+                                }
+                            }
+                            read_bcv(bcv0);
+                            fa0 = frm_in[(tb + 63) / WB];
+                            fb0 = tb + 1 < m ? frm_in[(tb + 64) / WB] : fa0;
+                        }
+                    }
                     u64 hist[WB];
                     int frame_pub = FRAME_NONE;
 
@@ -834,8 +870,8 @@ __device__ __forceinline__ void sweep(const Params &p)
                         constexpr bool use_pred = decltype(pred_tag)::value;  // (shadows the run-time flag: one body per case)
                         int fa = 0, fb = 0;
                         if (use_pred) {
-                            fa = __builtin_amdgcn_readfirstlane(frm_in[(tb + 63) / WB]);                   // block that produced column tb
-                            fb = tb + 1 < m ? __builtin_amdgcn_readfirstlane(frm_in[(tb + 64) / WB]) : fa;  // ... columns tb+1 .. tb+WB-1
+                            fa = __builtin_amdgcn_readfirstlane(fa0);
+                            fb = __builtin_amdgcn_readfirstlane(fb0);
                             if (fa == FRAME_NONE || fb == FRAME_NONE) return 0;
                         }
                         int R = cy.xe + WF_BIAS;
@@ -856,11 +892,9 @@ __device__ __forceinline__ void sweep(const Params &p)
                         if (!EDGE || tb > thr) mn = __float_as_uint(x);  // a value that is not live yet may be arbitrarily small
                         float bf[WB];  // lane 0's `up` values in its frame
                         if (use_pred) {
-                            u64 bcv[WB];
-                            read_bcv(bcv);
-                            bf[0] = __builtin_amdgcn_ldexpf(__uint_as_float(lo32(bcv[0])), fa - R);
+                            bf[0] = __builtin_amdgcn_ldexpf(__uint_as_float(lo32(bcv0[0])), fa - R);
 #pragma unroll
-                            for (int j = 1; j < WB; ++j) bf[j] = __uint_as_float(lo32(bcv[j]));
+                            for (int j = 1; j < WB; ++j) bf[j] = __uint_as_float(lo32(bcv0[j]));
                         } else {
 #pragma unroll
                             for (int j = 0; j < WB; ++j) bf[j] = xz;
