@@ -42,9 +42,11 @@ def parse():
     ap.add_argument("--N", type=int, default=512)
     ap.add_argument("--M", type=int, default=512)
     ap.add_argument("--variant", choices=["nw", "sw"], default="nw")
-    ap.add_argument("--mode", choices=["fwdbwd", "train", "scores+dp"], default="fwdbwd",
+    ap.add_argument("--mode", choices=["fwdbwd", "train", "scores+dp", "train-mce", "train-mce-fused"], default="fwdbwd",
                     help="fwdbwd: headline; train: decode -> loss -> backward (adds the adjoint pair); scores+dp: theta/A "
-                         "from (B,N,D) embeddings on the matrix cores (alignment.py:122-123), then the headline step")
+                         "from (B,N,D) embeddings on the matrix cores (alignment.py:122-123), then the headline step; "
+                         "train-mce: decode -> MatrixCrossEntropy (the reference's training loss, trainer.py:154-171) -> backward; "
+                         "train-mce-fused: the same as one op, the loss gradient seeding the adjoint sweep inside the kernel")
     ap.add_argument("--D", type=int, default=512, help="embedding width of --mode scores+dp (reference default n_embed)")
     ap.add_argument("--gather", choices=["vt", "e", "none"], default="vt")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -195,7 +197,24 @@ def main():
         emb = [torch.from_numpy((datagen.normal(20 + i, (B, n, args.D)) * sc).astype(np.float32)).to(dev)
                for i, n in enumerate((N, M, N, M))]
 
+    mce = None
+    if args.mode.startswith("train-mce"):
+        from deepblast_amd.losses import MatrixCrossEntropy, decode_loss
+        mce = MatrixCrossEntropy()
+        Yt = torch.from_numpy((datagen.uniform(30, (B, N, M)) < 0.05).astype(np.float32)).to(dev)
+        Gm = torch.from_numpy((datagen.uniform(31, (B, N, M)) < 0.8).astype(np.float32)).to(dev)
+        xl, yl = [N] * B, [M] * B
+
     def step():
+        if mce is not None:
+            t = theta.detach().requires_grad_(True)
+            a = A.detach().requires_grad_(True)
+            if args.mode == "train-mce-fused":
+                loss, _ = decode_loss(dec, mce, t, a, Yt, xl, yl, Gm)
+            else:
+                loss = mce(Yt, dec.decode(t, a), xl, yl, Gm)
+            loss.backward()
+            return t.grad
         if args.mode == "scores+dp":
             th, ga = alignment_scores(*emb)     # one MFMA launch: both GEMMs + softplus / logsigmoid
             return aligner.align(th, ga)["E_local"]
@@ -248,7 +267,7 @@ def main():
         e_gather = dt_e / min(args.steps, 5)
 
     cells = B * N * M if args.variant == "nw" else B * (N - 1) * (M - 1)
-    per_step_updates = (4 if args.mode == "train" else 2) * cells
+    per_step_updates = (4 if args.mode.startswith("train") else 2) * cells
     value = world * per_step_updates * args.steps / elapsed
     ms = timer.means_ms()
 
@@ -274,13 +293,16 @@ def main():
                 traffic = None
         line = {
             "metric": {"fwdbwd": "DP cell-updates/sec (fwd+bwd)", "train": "DP cell-updates/sec (train: fwd+bwd+adjoint pair)",
-                       "scores+dp": "DP cell-updates/sec (scores from embeddings + fwd+bwd)"}[args.mode],
+                       "scores+dp": "DP cell-updates/sec (scores from embeddings + fwd+bwd)",
+                       "train-mce": "DP cell-updates/sec (train: decode + MatrixCrossEntropy + backward)",
+                       "train-mce-fused": "DP cell-updates/sec (train: fused decode + MatrixCrossEntropy + backward)"}[args.mode],
             "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": float(np.median(per_step_ms)),
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.variant.upper()} soft-DP " + {"fwdbwd": "fwd+bwd", "train": "decode+loss.backward",
-                                                                        "scores+dp": f"scores(D={args.D})+fwd+bwd"}[args.mode] +
+                                                                        "scores+dp": f"scores(D={args.D})+fwd+bwd", "train-mce": "decode+MatrixCrossEntropy.backward",
+                                                                        "train-mce-fused": "fused decode+MatrixCrossEntropy.backward"}[args.mode] +
                                    f", B={B} per GPU, N={N}, M={M}, random theta/A "
                                    + ("(BASELINE.json configs[1])" if world == 1 else
                                       f"(BASELINE.json configs[4] sharding: {B * world} pairs over {world} GPUs)"),

@@ -158,6 +158,23 @@ class HipEngine:
         _lib.check(rc, "sdp_adjoint_forward_f32")
         return Vtd, state_d
 
+    def adjoint_forward_loss(self, state, ref, pred, G, scale, kind, variant, lens=None):
+        """Adjoint forward sweep seeded with scale[b] * d(loss term)/d(pred) formed in the kernel (include/sdp.h:
+        sdp_adjoint_forward_loss_f32).  -> (Vtd (B,), state_d)."""
+        dev = self._dev(state)
+        self._check(state, first=ref, pred=pred, G=G, scale=scale)
+        ref, pred, G, scale = ref.contiguous(), pred.contiguous(), G.contiguous(), scale.contiguous()
+        B, N, M = pred.shape
+        lens = self._lens(lens, B, state.device)
+        state_d = self.new_state(B, N, M, state.device, derivative=True)
+        Vtd = torch.empty(B, dtype=torch.float32, device=state.device)
+        with torch.cuda.device(dev), self._bracket("sdp_adj_fwd_kernel"):
+            rc = self.lib.sdp_adjoint_forward_loss_f32(_ptr(state), _ptr(ref), _ptr(pred), _ptr(G), _ptr(scale), kind, _ptr(Vtd),
+                                                       _ptr(state_d), B, N, M, _ptr(lens), self._v(2, variant), dev,
+                                                       self._stream(dev))
+        _lib.check(rc, "sdp_adjoint_forward_loss_f32")
+        return Vtd, state_d
+
     def adjoint_backward(self, E, state, state_d, variant, lens=None):
         """-> Ed (B,N,M).  Replaces _adjoint_backward_pass_kernel (nw_cuda.py:160-165)."""
         dev = self._dev(state)

@@ -30,6 +30,8 @@ SIGNATURES = {
     "sdp_adjoint_forward_f32": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int, _c_i32p, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_void_p]),
+    "sdp_adjoint_forward_loss_f32": (ctypes.c_int, [_c_f32p] * 5 + [ctypes.c_int] + [_c_f32p] * 2 + [ctypes.c_int] * 3 +
+                                     [_c_i32p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "sdp_adjoint_backward_f32": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int, _c_i32p, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_void_p]),

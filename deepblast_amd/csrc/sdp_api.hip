@@ -77,6 +77,7 @@ Variant variant(int id)
     case 7: return {(const void *)sdp_bwd_x_kernel, SDP_K_BWD, SDP_MAXW_BWD, 7};
     case 8: return {(const void *)sdp_bwd_x_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 8};
     case 9: return {(const void *)sdp_fwd_x_tp_kernel, SDP_K_FWD, SDP_MAXW_FWD, 9};
+    case 10: return {(const void *)sdp_adj_fwd_loss_kernel, SDP_K_AFWD, 4, 10};  // adj-fwd with the loss seed formed in the kernel
     default: return {(const void *)sdp_bwd_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 4};
     }
 }
@@ -91,13 +92,13 @@ int num_cus(int device)
     return n;
 }
 
-size_t lds_bytes(int pass, int K, int W, int mcap, size_t *stage_off)
+size_t lds_bytes(int pass, int K, int W, int mcap, size_t *stage_off, int nin = 0)
 {
     const int nslot = 2;  // boundary rows are shared by alternate strips (see the kernel)
     size_t off = (size_t)nslot * mcap * sizeof(double) + 64 + (size_t)nslot * sdp::FRAME_CAP * 4;  // boundary rows, progress words, frame words
     off = (off + 15) & ~(size_t)15;
     if (stage_off) *stage_off = off;
-    return off + (size_t)W * sdp::stage_floats(pass, K) * sizeof(float);
+    return off + (size_t)W * sdp::stage_floats(pass, K, nin) * sizeof(float);
 }
 
 int check_shape(int B, int N, int M, int variant)
@@ -117,7 +118,7 @@ struct Plan {
     size_t lds, stage_off;
 };
 
-Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cus, int forced_waves)
+Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cus, int forced_waves, bool fused_seed = false)
 {
     const int nstrips = sdp::state_nstrips(N);
     const int mcap = (M + 63) / 64 * 64;
@@ -145,11 +146,13 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
     }
     if (pass == sdp::PASS_FWD && exact_state) v = variant(v.id == 0 ? 9 : 5);
     if (pass == sdp::PASS_BWD && exact_state) v = variant(v.id == 1 ? 7 : 8);
+    const int nin = (pass == sdp::PASS_AFWD && fused_seed) ? 3 : 0;   // three staged planes (ref, pred, G)
+    if (nin) v = variant(10);
     if (W > v.maxw) W = v.maxw;
     if (W > nstrips) W = nstrips;
     size_t off = 0, lds = 0;
     for (;; --W) {  // fewer waves if the boundary rows (long M) plus staging exceed the 160 KiB of LDS
-        lds = lds_bytes(pass, v.K, W, mcap, &off);
+        lds = lds_bytes(pass, v.K, W, mcap, &off, nin);
         if (lds <= 160 * 1024 || W == 1) break;
     }
     return {v, W, lds, off};
@@ -200,7 +203,7 @@ VariantBits split_variant(int variant)
     return v;
 }
 
-int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state = false, int forced_waves = 0)
+int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state = false, int forced_waves = 0, bool fused_seed = false)
 {
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
@@ -214,14 +217,14 @@ int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state 
 #else
     p.dbg = 0;
 #endif
-    const Plan pl = plan(pass, p.B, p.N, p.M, p.lens != nullptr, exact_state, num_cus(device), forced_waves);
+    const Plan pl = plan(pass, p.B, p.N, p.M, p.lens != nullptr, exact_state, num_cus(device), forced_waves, fused_seed);
     const Variant v = pl.v;
     const int W = pl.W;
     const size_t lds = pl.lds, off = pl.stage_off;
     p.stage_off = (int)off;
     // raise the dynamic-LDS limit once per (thread, device, kernel) -- it is sticky, and the value is the
     // 160 KiB the hardware has, so concurrent callers cannot disagree
-    static thread_local unsigned long long lds_raised[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // bit d = done on device d
+    static thread_local unsigned long long lds_raised[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // bit d = done on device d
     if (device >= 64 || !(lds_raised[v.id] >> device & 1ull)) {
         e = hipFuncSetAttribute(v.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -351,6 +354,31 @@ int sdp_adjoint_forward_f32(const float *state, const float *Ztheta, const float
     p.B = B, p.N = N, p.M = M, p.variant = variant;
     if (wants_order(B, lens, device)) p.order = order_in_state(state, B, N, M, true);
     return launch(sdp::PASS_AFWD, p, device, stream, false, vb.waves);
+}
+
+int sdp_adjoint_forward_loss_f32(const float *state, const float *ref, const float *pred, const float *G, const float *scale,
+                                 int kind, float *Vtd, float *state_d, int B, int N, int M, const int32_t *lens, int variant,
+                                 int device, void *stream)
+{
+    if (!state || !ref || !pred || !G || !scale || !Vtd || !state_d)
+        return fail(SDP_E_NULLPTR, "sdp_adjoint_forward_loss_f32: null pointer");
+    if (kind < 0 || kind > 2) return fail(SDP_E_VARIANT, "loss kind must be 0 (cross entropy), 1 (path) or 2 (alignment)");
+    const VariantBits vb = split_variant(variant);
+    variant = vb.variant;
+    if (int rc = check_shape(B, N, M, variant)) return rc;
+    sdp::Params p = {};
+    p.qin = reinterpret_cast<const uint32_t *>(state);
+    p.sin0 = ref;
+    p.sin1 = pred;
+    p.sin2 = G;
+    p.vin = scale;
+    p.loss_kind = kind;
+    p.dout = state_d;
+    p.vout = Vtd;
+    p.lens = lens;
+    p.B = B, p.N = N, p.M = M, p.variant = variant;
+    if (wants_order(B, lens, device)) p.order = order_in_state(state, B, N, M, true);
+    return launch(sdp::PASS_AFWD, p, device, stream, false, vb.waves, true);
 }
 
 int sdp_adjoint_backward_f32(const float *E, const float *state, const float *state_d, float *Ed, int B, int N,

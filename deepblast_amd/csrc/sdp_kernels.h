@@ -73,6 +73,8 @@ constexpr int PROG_STRIDE = 4096;  // > MAX_COLS: progress words are (use index)
 struct Params {
     const float *sin0;   // staged (row-major) input plane 0: theta | Ztheta | E
     const float *sin1;   // staged input plane 1: A | ZA (may be null = zeros)
+    const float *sin2;   // staged input plane 2: G (fused loss seed of the adjoint forward: planes ref, pred, G)
+    int loss_kind;       // fused loss seed: SDP_LOSS_*
     float *sout;         // staged (row-major) output: E | Ed
     const uint32_t *qin; // skewed state in: Q, packed (backward sweep) or float2 (adjoint sweeps)
     const float2 *din;   // skewed state in: Qd
@@ -94,9 +96,9 @@ struct Params {
 
 // per-wave LDS staging (floats): input planes are rings [64][2K], the output ring is [64][2K+1]
 __host__ __device__ constexpr int stage_out_pitch(int K) { return 2 * K + 1; }
-__host__ __device__ constexpr int stage_floats(int pass, int K)
+__host__ __device__ constexpr int stage_floats(int pass, int K, int nin_override = 0)
 {
-    const int nin = (pass == PASS_FWD || pass == PASS_AFWD) ? 2 : (pass == PASS_ABWD ? 1 : 0);
+    const int nin = nin_override > 0 ? nin_override : ((pass == PASS_FWD || pass == PASS_AFWD) ? 2 : (pass == PASS_ABWD ? 1 : 0));
     const int nout = (pass == PASS_BWD || pass == PASS_ABWD) ? 1 : 0;
     return nin * 64 * (2 * K) + nout * 64 * stage_out_pitch(K);
 }
@@ -152,6 +154,7 @@ __global__ void sdp_bwd_lat_kernel(const sdp::Params p);
 __global__ void sdp_bwd_x_kernel(const sdp::Params p);
 __global__ void sdp_bwd_x_lat_kernel(const sdp::Params p);
 __global__ void sdp_adj_fwd_kernel(const sdp::Params p);
+__global__ void sdp_adj_fwd_loss_kernel(const sdp::Params p);
 __global__ void sdp_adj_bwd_kernel(const sdp::Params p);
 __global__ void sdp_selftest_kernel(int *out);
 __global__ void sdp_loss_fwd_kernel(const float *ref, const float *pred, const float *G, const int *lens, double *acc, int *cnt, int N, int M, int kind);

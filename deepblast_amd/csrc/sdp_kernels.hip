@@ -182,7 +182,9 @@ struct Traits<PASS_BWD, QX> {  // nw.py:120-135
 };
 template <bool QX>
 struct Traits<PASS_AFWD, QX> {  // nw.py:178-199
-    static constexpr int SIN = 2, SOUT = 0;
+    // QX = true here means: the seed Ztheta is not read but formed from the loss's operands -- three staged planes
+    // (ref, pred, G) instead of (Ztheta, ZA); see "fused loss seed" in the step body
+    static constexpr int SIN = QX ? 3 : 2, SOUT = 0;
     static constexpr int QIN = Q_EXACT, QOUT = Q_NONE;
     static constexpr bool DIN = false, DOUT = true;
     static constexpr bool REV = false;
@@ -326,6 +328,33 @@ struct Carry {
     int de;
 };
 
+// per-cell terms of the masked alignment losses (used by the loss kernels and by the fused seed of the adjoint forward)
+__device__ __forceinline__ float loss_clamp(float p)
+{
+    const float eps = 3e-8f;  // losses.py:27
+    return fminf(fmaxf(p, eps), 1.0f - eps);
+}
+
+// value of one counted cell (kind as above)
+__device__ __forceinline__ float loss_term(float r, float y, int kind)
+{
+    if (kind == 0) {
+        const float p = loss_clamp(y);
+        return r * logf(p) + (1.0f - r) * logf(1.0f - p);
+    }
+    const float d = kind == 1 ? r * y : r - y;
+    return d * d;
+}
+// derivative factor of one counted cell w.r.t. the predicted value
+__device__ __forceinline__ float loss_dterm(float r, float y, float sc, int kind)
+{
+    if (kind == 0) {
+        const float eps = 3e-8f;
+        return (y >= eps && y <= 1.0f - eps) ? sc * (r / y - (1.0f - r) / (1.0f - y)) : 0.f;  // clamp passes the gradient inside only
+    }
+    return kind == 1 ? sc * r * r * y : sc * (r - y);
+}
+
 // ----------------------------------------------------------------------------------
 // the sweep
 // ----------------------------------------------------------------------------------
@@ -383,7 +412,7 @@ __device__ __forceinline__ void sweep(const Params &p)
     // frame words (forward sweep): one per boundary row and producer chunk, FRAME_NONE or the common exponent of
     // the K values that chunk published
     int *frm = reinterpret_cast<int *>(bnd + (size_t)nslot * p.mcap) + 16;
-    float *stage = reinterpret_cast<float *>(smem + p.stage_off) + (size_t)wave * stage_floats(PASS, K);
+    float *stage = reinterpret_cast<float *>(smem + p.stage_off) + (size_t)wave * stage_floats(PASS, K, T::SIN);
     float *lds_in = stage;
     float *lds_out = stage + T::SIN * PLANE;
 
@@ -440,6 +469,7 @@ __device__ __forceinline__ void sweep(const Params &p)
         rs_in[0] = make_rsrc(p.sin0 + b_in * plane_elems, plane_bytes);
         if constexpr (T::SIN > 1)
             rs_in[1] = make_rsrc(p.sin1 ? p.sin1 + b_in * plane_elems : p.sin0, p.sin1 ? plane_bytes : 0u);
+        if constexpr (T::SIN > 2) rs_in[2] = make_rsrc(p.sin2 + b_in * plane_elems, plane_bytes);
     }
     __amdgpu_buffer_rsrc_t rs_out = make_rsrc(T::SOUT ? (const void *)(p.sout + b_out * plane_elems) : (const void *)p.vout,
                                               T::SOUT ? plane_bytes : 0u);
@@ -451,6 +481,7 @@ __device__ __forceinline__ void sweep(const Params &p)
     const int lane_off = (r_l * ld + s_l - r_l) * 4;   // byte offset of this lane's element for k = 0, i0 = t0 = 0
 
     const float et = (PASS == PASS_BWD) ? p.vin[b] : 0.f;
+    const float seed_scale = (PASS == PASS_AFWD && QX) ? p.vin[b] : 0.f;   // fused loss seed: per-pair factor of dLoss/dE
 
     for (int sidx = wave; sidx < nstrips; sidx += W) {
         const int s = REV ? nstrips - 1 - sidx : sidx;  // strip handled now
@@ -1159,13 +1190,14 @@ __device__ __forceinline__ void sweep(const Params &p)
             }
 
             // ---- staged inputs of this chunk: one burst of LDS reads, off the dependency chain ----
-            float in0[K], in1[K];
+            float in0[K], in1[K], in2[T::SIN > 2 ? K : 1];
             if constexpr (T::SIN > 0) {
                 if constexpr (ABL_NOLDS) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         in0[k] = rs[0][k];
                         if constexpr (T::SIN > 1) in1[k] = rs[1][k];
+                        if constexpr (T::SIN > 2) in2[k] = rs[2][k];
                     }
                 } else {
                     const int pr = (t0 & (RING - 1)) + 4 * ring_pi(lane & 7);  // ring position of step t0 for this lane
@@ -1177,6 +1209,10 @@ __device__ __forceinline__ void sweep(const Params &p)
                         if constexpr (T::SIN > 1) {
                             const float4 v1 = *reinterpret_cast<const float4 *>(lds_in + PLANE + idx);
                             in1[4 * g] = v1.x, in1[4 * g + 1] = v1.y, in1[4 * g + 2] = v1.z, in1[4 * g + 3] = v1.w;
+                        }
+                        if constexpr (T::SIN > 2) {
+                            const float4 v2 = *reinterpret_cast<const float4 *>(lds_in + 2 * PLANE + idx);
+                            in2[4 * g] = v2.x, in2[4 * g + 1] = v2.y, in2[4 * g + 2] = v2.z, in2[4 * g + 3] = v2.w;
                         }
                     }
                 }
@@ -1318,8 +1354,19 @@ __device__ __forceinline__ void sweep(const Params &p)
                         hist[k] = (u64)__double_as_longlong(cy.a);
                         if constexpr (EDGE) vt_keep = (t == t_final) ? hist[k] : vt_keep;
                     } else if constexpr (PASS == PASS_AFWD) {
-                        const float zt = in0[k];
-                        const float za = in1[k];
+                        // Fused loss seed: Ztheta = dLoss/dE is formed here from the loss's own operands --
+                        // ref (Ytrue or the path matrix), pred (= E, the alignment matrix the loss was evaluated on), the
+                        // mask G and the per-pair factor -- instead of being written by the loss's backward kernel and read
+                        // back (deepblast/losses.py:26-46, 69-79, 108-118; same formulas as sdp_loss_bwd_kernel).  Cells
+                        // outside the pair's block are outside the matrix here (`inside`), so no extra length test.
+                        float zt, za;
+                        if constexpr (QX) {
+                            zt = (in2[k] != 0.f && inside) ? loss_dterm(in0[k], in1[k], seed_scale, p.loss_kind) : 0.f;
+                            za = 0.f;
+                        } else {
+                            zt = in0[k];
+                            za = in1[k];
+                        }
                         const double up = dpp_f64<DPP_IN>(__longlong_as_double((long long)bcv[k]), cy.a);
                         const double diag = cy.b, left = cy.a;
                         const bool live = inside && !dead;
@@ -1679,6 +1726,7 @@ SDP_KERNEL(sdp_bwd_lat_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT)
 SDP_KERNEL(sdp_bwd_x_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, true)
 SDP_KERNEL(sdp_bwd_x_lat_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, true)
 SDP_KERNEL(sdp_adj_fwd_kernel, sdp::PASS_AFWD, SDP_K_AFWD, SDP_MAXW_AFWD)
+SDP_KERNEL(sdp_adj_fwd_loss_kernel, sdp::PASS_AFWD, SDP_K_AFWD, 4, true)
 SDP_KERNEL(sdp_adj_bwd_kernel, sdp::PASS_ABWD, SDP_K_ABWD, SDP_MAXW_ABWD)
 
 // ----------------------------------------------------------------------------------
@@ -1794,32 +1842,6 @@ extern "C" __global__ void __launch_bounds__(64) sdp_traceback_kernel(const floa
 //   kind 2 SoftAlignmentLoss  : acc = sum_G (Yt - Yp)^2
 // HBM-bound elementwise work: 12 B read per cell in the forward, 12 B read + 4 B written in the backward.
 // ----------------------------------------------------------------------------------
-__device__ __forceinline__ float loss_clamp(float p)
-{
-    const float eps = 3e-8f;  // losses.py:27
-    return fminf(fmaxf(p, eps), 1.0f - eps);
-}
-
-// value of one counted cell (kind as above)
-__device__ __forceinline__ float loss_term(float r, float y, int kind)
-{
-    if (kind == 0) {
-        const float p = loss_clamp(y);
-        return r * logf(p) + (1.0f - r) * logf(1.0f - p);
-    }
-    const float d = kind == 1 ? r * y : r - y;
-    return d * d;
-}
-// derivative factor of one counted cell w.r.t. the predicted value
-__device__ __forceinline__ float loss_dterm(float r, float y, float sc, int kind)
-{
-    if (kind == 0) {
-        const float eps = 3e-8f;
-        return (y >= eps && y <= 1.0f - eps) ? sc * (r / y - (1.0f - r) / (1.0f - y)) : 0.f;  // clamp passes the gradient inside only
-    }
-    return kind == 1 ? sc * r * r * y : sc * (r - y);
-}
-
 // One workgroup per pair; a thread takes four consecutive columns of a row per iteration (one 16-byte load per
 // tensor when the rows are 16-byte aligned, i.e. M a multiple of 4), so the three tensors stream at full width and
 // there is one index division per four cells.  Per-thread float64 partial sums, fixed reduction order: deterministic.
@@ -1863,7 +1885,7 @@ extern "C" __global__ void __launch_bounds__(1024) sdp_loss_fwd_kernel(const flo
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (g[e] != 0.f) {
-                a += (double)loss_term(r[e], y[e], kind);
+                a += (double)sdp::loss_term(r[e], y[e], kind);
                 ++c;
             }
         }
@@ -1924,7 +1946,7 @@ extern "C" __global__ void __launch_bounds__(256) sdp_loss_bwd_kernel(const floa
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (j + e < m && g[e] != 0.f) out[e] = loss_dterm(r[e], y[e], sc, kind);
+                if (j + e < m && g[e] != 0.f) out[e] = sdp::loss_dterm(r[e], y[e], sc, kind);
         }
         if (vec) {
             *reinterpret_cast<float4 *>(grad + o) = make_float4(out[0], out[1], out[2], out[3]);

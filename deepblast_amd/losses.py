@@ -87,3 +87,80 @@ class SoftPathLoss(_Loss):
 class SoftAlignmentLoss(_Loss):
     """|| (Ytrue - Ypred)[G] ||_2 per pair, averaged over pairs (losses.py:82-118)."""
     kind = ALIGNMENT
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# decode + loss as ONE differentiable op (SURVEY 8f3, "masked loss on E fused with the adjoint seed")
+# ----------------------------------------------------------------------------------------------------------------
+class _DecodeLoss(torch.autograd.Function):
+    """loss(decode(theta, A)) with the loss's gradient fed to the adjoint forward sweep inside the kernel.
+
+    The unfused training step (reference: alignment.py:124 then losses.py, trainer.py:154-171) runs
+    forward -> backward (E) -> loss -> loss backward (writes dLoss/dE, a (B,N,M) tensor) -> adjoint forward (reads it)
+    -> adjoint backward.  Here the loss's backward kernel and its tensor disappear: `sdp_adjoint_forward_loss_f32`
+    forms dLoss/dE from (first, E, G, scale) while it stages them.  Same values as the unfused path."""
+
+    @staticmethod
+    def forward(ctx, theta, A, first, G, lens_loss, lens_dp, kind, variant):
+        from ._dp import _validate
+        _validate(theta, A, 'softmax', False)
+        eng = get_engine()
+        dev = eng._dev(theta)
+        first = first.detach().to(torch.float32).contiguous()
+        G = G.detach().to(torch.float32).contiguous()
+        th, a = theta.detach(), A.detach()
+        B, N, M = th.shape
+        Vt, Q = eng.forward(th, a, variant, lens_dp, exact_state=True)
+        ones = torch.ones(B, dtype=torch.float32, device=th.device)
+        E = eng.backward(ones, Q, (B, N, M), variant, lens_dp, exact_state=True)
+        acc = torch.empty(B, dtype=torch.float64, device=th.device)
+        cnt = torch.empty(B, dtype=torch.int32, device=th.device)
+        with torch.cuda.device(dev), eng._bracket("sdp_loss_fwd_kernel"):
+            rc = eng.lib.sdp_loss_forward_f32(_ptr(first), _ptr(E), _ptr(G), _ptr(lens_loss), _ptr(acc), _ptr(cnt), B, N, M, kind,
+                                              dev, eng._stream(dev))
+        _lib.check(rc, "sdp_loss_forward_f32")
+        if kind == CROSS_ENTROPY:
+            per_pair = -(acc / cnt.to(torch.float64))
+            scale = (-1.0 / (cnt.to(torch.float64) * B))
+        else:
+            per_pair = torch.sqrt(acc)
+            sign = 1.0 if kind == PATH else -1.0
+            scale = torch.where(per_pair > 0, sign / (per_pair * B), torch.zeros_like(per_pair))
+        ctx.save_for_backward(Q, E, first, G, lens_loss, scale.to(torch.float32))
+        ctx.others = (kind, variant, lens_dp)
+        ctx.mark_non_differentiable(E)
+        return (per_pair.sum() / B).to(torch.float32), E
+
+    @staticmethod
+    def backward(ctx, gout, _gE):
+        Q, E, first, G, lens_loss, scale = ctx.saved_tensors
+        kind, variant, lens_dp = ctx.others
+        eng = get_engine()
+        sc = (scale * gout.to(torch.float32)).contiguous()
+        # the loss masks with its own lengths; the DP sweeps use theirs (None = full padded matrix, as the reference)
+        if lens_dp is None and lens_loss is not None:
+            # cells outside a pair's block must not seed the sweep: fold the loss's lengths into the mask
+            B, N, M = E.shape
+            ii = torch.arange(N, device=E.device).view(1, N, 1) < lens_loss[:, 0].view(B, 1, 1)
+            jj = torch.arange(M, device=E.device).view(1, 1, M) < lens_loss[:, 1].view(B, 1, 1)
+            G = G * (ii & jj).to(G.dtype)
+        _, Qd = eng.adjoint_forward_loss(Q, first, E, G, sc, kind, variant, lens_dp)
+        Ed = eng.adjoint_backward(E, Q, Qd, variant, lens_dp)
+        return Ed, None, None, None, None, None, None, None
+
+
+def decode_loss(decoder, loss, theta, A, first, x_len, y_len, G, lengths=None):
+    """`loss(first, decoder.decode(theta, A[, lengths]), x_len, y_len, G)` as one op -> (loss scalar, E).
+
+    decoder : NeedlemanWunschDecoder / SmithWatermanDecoder of this package
+    loss    : MatrixCrossEntropy() / SoftPathLoss() / SoftAlignmentLoss() of this module (its `kind` is used)
+    lengths : optional (B,2) per-pair sizes for the DP itself (None = the reference's full padded DP)
+    The scalar is differentiable w.r.t. theta (the gradient w.r.t. A is None, as in the reference's second-order
+    path, nw.py:386); E is returned for inspection / traceback and is not differentiable through this op."""
+    from ._engine import NW, SW
+    from .sw import SmithWatermanDecoder
+    variant = SW if isinstance(decoder, SmithWatermanDecoder) else NW
+    B = theta.shape[0]
+    lens_loss = _lens(x_len, y_len, B, theta.device)
+    lens_dp = None if lengths is None else get_engine()._lens(lengths, B, theta.device)
+    return _DecodeLoss.apply(theta, A, first, G, lens_loss, lens_dp, loss.kind, variant)

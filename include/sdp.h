@@ -147,6 +147,16 @@ int sdp_loss_backward_f32(const float *ref, const float *pred, const float *G, c
                           const float *scale, float *grad, int B, int N, int M, int kind, int device,
                           void *stream);
 
+/* The adjoint forward sweep with the loss's gradient as its seed, formed inside the kernel: Ztheta[b,i,j] =
+ * scale[b] * d(term)/d(pred) where G != 0 (and inside the pair's block), 0 elsewhere -- exactly what
+ * sdp_loss_backward_f32 would write and sdp_adjoint_forward_f32 would read back, without the (B,N,M) tensor in
+ * between (training: decode -> masked loss on the alignment matrix -> backward; reference: losses.py:9-118 applied to
+ * NeuralAligner.forward's output, trainer.py:154-171).  pred is the alignment matrix E the loss was evaluated on;
+ * ZA is taken as zero.  state as for sdp_adjoint_forward_f32. */
+int sdp_adjoint_forward_loss_f32(const float *state, const float *ref, const float *pred, const float *G,
+                                 const float *scale, int kind, float *Vtd, float *state_d, int B, int N, int M,
+                                 const int32_t *lens, int variant, int device, void *stream);
+
 /* Runs a few-microsecond device check of the cross-lane (DPP) and buffer-addressing
  * behaviour the kernels rely on.  Synchronises the device.  0 = ok. */
 int sdp_selftest(int device);

@@ -1,5 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > gpurun_out/pytest.txt
-tail -3 gpurun_out/pytest.txt
-timeout 600 python tools/ab.py 256x512x512 64x512x512 256x1024x1024 > gpurun_out/ab.txt 2>&1; cat gpurun_out/ab.txt
+for m in train train-mce train-mce-fused; do
+timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --mode $m 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$m', round(d['ms_per_step'],4), {k: round(v,4) for k,v in d['kernel_ms'].items()})"
+done
