@@ -115,8 +115,11 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 // default policy: in the fwd -> bwd sequence the tail of the state is then still in the Infinity Cache when
 // the backward sweep starts reading it.  Measured on the back-to-back sequence (us): none 472, stores 471,
 // loads 468, both 476.  The row-major tensors are re-touched by neighbouring chunks and keep the default.
+// Round 2, same measurement with the block-wise forward (fwd;bwd back to back, one box): 2 (loads): 380.3, 0: 397.6,
+// 3 (+ state stores): 385.6, 11: 394.2, and 10 = state loads + staged OUTPUT stores (E, Ed -- nobody in this library
+// reads them back): 371.0 -- the outputs no longer push the state out of the Infinity Cache before it is re-read.
 #ifndef SDP_NT
-#define SDP_NT 2
+#define SDP_NT 10
 #endif
 constexpr int AUX_ST_STORE = (SDP_NT & 1) ? 2 : 0, AUX_ST_LOAD = (SDP_NT & 2) ? 2 : 0;
 constexpr int AUX_IN_LOAD = (SDP_NT & 4) ? 2 : 0, AUX_OUT_STORE = (SDP_NT & 8) ? 2 : 0;
