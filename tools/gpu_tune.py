@@ -83,6 +83,10 @@ def run(lib, B, N, M, waves=(0, 0, 0, 0), passes="fb"):
         ab = lambda: lib.sdp_adjoint_backward_f32(E.data_ptr(), stx.data_ptr(), std.data_ptr(), Ed.data_ptr(), B, N, M, None, wf[3], 0, stream)
         out["afwd"] = timeit(af)
         out["abwd"] = timeit(ab)
+        fx = lambda: lib.sdp_forward_f32(t.data_ptr(), a.data_ptr(), stx.data_ptr(), vt.data_ptr(), B, N, M, None, 0x100 | wf[0], 0, stream)
+        bx = lambda: lib.sdp_backward_f32(et.data_ptr(), stx.data_ptr(), E.data_ptr(), B, N, M, None, 0x100 | wf[1], 0, stream)
+        out["bwd_x"] = timeit(bx)
+        out["train4"] = timeit(lambda: (fx(), bx(), af(), ab()))   # the four sweeps of a training step, back to back
     return out
 
 
