@@ -43,6 +43,11 @@ SIGNATURES = {
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "sdp_loss_backward_f32": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_i32p, _c_f32p, _c_f32p, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "sdp_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "sdp_comm_init": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "sdp_comm_all_gather_f32": (ctypes.c_int, [ctypes.c_void_p, _c_f32p, _c_f32p, ctypes.c_size_t, ctypes.c_void_p]),
+    "sdp_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "sdp_comm_last_error_string": (ctypes.c_char_p, []),
     "sdp_selftest": (ctypes.c_int, [ctypes.c_int]),
     "sdp_device_status": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int32)]),
 }

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = [os.path.join(HERE, "csrc", "sdp_kernels.hip"), os.path.join(HERE, "csrc", "sdp_scores.hip"),
-       os.path.join(HERE, "csrc", "sdp_api.hip")]
+       os.path.join(HERE, "csrc", "sdp_comm.hip"), os.path.join(HERE, "csrc", "sdp_api.hip")]
 HDR = [os.path.join(HERE, "csrc", "sdp_kernels.h"), os.path.join(ROOT, "include", "sdp.h")]
 OUT = os.path.join(HERE, "libsdp_hip.so")
 
@@ -35,7 +35,7 @@ def build(force=False, extra=(), out=None):
     # which build or which body a cell happens to run in
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
-           *extra, *SRC, "-o", OUT]
+           *extra, *SRC, "-ldl", "-o", OUT]
     subprocess.check_call(cmd)
     return OUT
 

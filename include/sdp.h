@@ -77,6 +77,7 @@ extern "C" {
 #define SDP_E_VARIANT (-4)  /* variant is neither SDP_NW nor SDP_SW */
 #define SDP_E_TOOBIG (-5)   /* a tensor exceeds the 4 GiB-per-plane addressing limit */
 #define SDP_E_SELFTEST (-6) /* sdp_selftest found a hardware-semantics mismatch */
+#define SDP_E_COMM (-8)     /* RCCL could not be loaded or returned an error (sdp_comm_last_error_string) */
 #define SDP_E_HANDOFF (-7)  /* an earlier launch on this device timed out waiting for a strip hand-off: its results are invalid */
 
 /* or-ed into `variant` of the four sweeps: run with w (1..8) wavefronts per pair instead of the automatic choice
@@ -156,6 +157,18 @@ int sdp_loss_backward_f32(const float *ref, const float *pred, const float *G, c
 int sdp_adjoint_forward_loss_f32(const float *state, const float *ref, const float *pred, const float *G,
                                  const float *scale, int kind, float *Vtd, float *state_d, int B, int N, int M,
                                  const int32_t *lens, int variant, int device, void *stream);
+
+/* Collecting results across the GPUs of a node for callers without torch.distributed.  The sweeps need no
+ * collective; these four wrap the one RCCL all-gather (over xGMI) that gathers Vt -- or E -- from all ranks, one
+ * process per GPU.  Rank 0 calls sdp_comm_unique_id and distributes the 128 bytes to the other ranks by its own means;
+ * every rank then calls sdp_comm_init (collective) with its device, and sdp_comm_all_gather_f32 enqueues the gather of
+ * count_per_rank floats per rank on `stream` (recv holds world * count_per_rank floats, rank order).  RCCL is loaded
+ * at run time (a copy already in the process, e.g. PyTorch's, is reused).  Errors: SDP_E_COMM + sdp_comm_last_error_string. */
+int sdp_comm_unique_id(void *id128);
+int sdp_comm_init(void **comm, const void *id128, int rank, int world, int device);
+int sdp_comm_all_gather_f32(void *comm, const float *send, float *recv, size_t count_per_rank, void *stream);
+int sdp_comm_destroy(void *comm);
+const char *sdp_comm_last_error_string(void);
 
 /* Runs a few-microsecond device check of the cross-lane (DPP) and buffer-addressing
  * behaviour the kernels rely on.  Synchronises the device.  0 = ok. */

@@ -1,4 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 600 python tools/ab.py 256x512x512 adj 2>&1 | tail -2
-timeout 600 python tools/ab.py 256x512x512 adj 2>&1 | tail -2
+timeout 300 python -m pytest tests/test_comm_gpu.py -m gpu -x -q 2>&1 | tail -8
