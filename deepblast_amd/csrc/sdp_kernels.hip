@@ -692,23 +692,33 @@ __device__ __forceinline__ void sweep(const Params &p)
             }
         }
 
-        // Staged OUTPUT geometry.  Results are written to LDS by step ([lane][step mod 2K]) and leave as
-        // K-column blocks aligned to K columns of the row-major tensor (full 128-B lines for K = 32):
-        // after chunk t0, row r owns the complete block starting at column t0 - K*floor(r/K); its
-        // element e was produced at step offset s = (r mod K) + e, i.e. in this chunk (s < K) or in the
-        // previously processed one (s >= K).  fo_off0 is the LDS index when the current chunk has
-        // parity 0, fo_dk the change when it has parity 1, fo_voff the global byte offset (row i0, t0 = 0).
-        int fo_off0[K], fo_dk[K];
+        // Staged OUTPUT geometry.  Results are written to LDS by step ([lane][step mod 2K]) and leave as K-element
+        // blocks that are aligned to K floats IN MEMORY (full 128-B lines for K = 32), whatever M is: row r's blocks
+        // start where (address of the row's first element + column) is a multiple of K floats, i.e. after chunk t0 the
+        // row owns the complete block starting at column t0 - D_r with D_r = r - rho_r, rho_r = (r (1 - M) - beta) mod K
+        // (beta: misalignment of the pair's plane); its element e was produced at step offset s = rho_r + e, i.e. in
+        // this chunk (s < K) or in the previously processed one (s >= K).  For M a multiple of K and an aligned plane
+        // this is rho_r = r mod K, D_r = K floor(r/K): blocks aligned to K columns.  (With blocks aligned to columns
+        // only, a row pitch that is not a multiple of 32 floats made every 128-byte store straddle two lines: the
+        // backward sweep ran 2.1-2.4x slower at M = 516 than at M = 512.)  fo_off0 is the LDS index when the current
+        // chunk has parity 0, fo_dk the change when it has parity 1, fo_voff the global byte offset (row i0, t0 = 0),
+        // fo_d the D_r of the row each element belongs to.
+        int fo_off0[K], fo_dk[K], fo_d[K];
         unsigned fo_voff[K];
+        bool fo_need_tail = false;
         if constexpr (T::SOUT > 0) {
+            const int beta = (int)(((uintptr_t)(p.sout + b_out * plane_elems) >> 2) & (uintptr_t)(K - 1));
+            fo_need_tail = beta != 0 || (ld & (K - 1)) != 0;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int r = k * RPI + r_l;
-                const int sfull = (r % K) + s_l;
+                const int rho = (r * (1 - ld) - beta) & (K - 1);   // (i0 * M is a multiple of K: strips are 64 rows)
+                const int sfull = rho + s_l;
                 const bool prev = sfull >= K;
                 fo_off0[k] = r * PO + (prev ? sfull - K : sfull) + (prev ? K : 0);
                 fo_dk[k] = prev ? -K : K;
-                fo_voff[k] = (unsigned)((r * ld - K * (r / K) + s_l) * 4);
+                fo_d[k] = r - rho;
+                fo_voff[k] = (unsigned)((r * ld - fo_d[k] + s_l) * 4);
             }
         }
 
@@ -1121,6 +1131,43 @@ __device__ __forceinline__ void sweep(const Params &p)
                         // LDS executes a wave's DS instructions in order, so the data written above is visible to any
                         // wave that observes this word (the asm statements also stop compiler reordering)
                         if (lane == PUB_LANE && !(SDP_EXP_BUILD && (p.dbg & 8))) lds_store_i32(prog + 4 * oword, obase + pub_done);
+                    }
+                }
+            }
+        };
+
+        // ---- output flush after a chunk (reverse sweeps) ----
+        auto flush_out = [&](int t0, int par) {
+            if constexpr (T::SOUT > 0) {
+                const int ubase = (i0 * ld + t0) * 4;
+                // all K*64 elements are real cells: rows of a full strip, columns within t0-63 .. t0+2K-2 (D_r in (r-K, r])
+                // (aligned pitch: D_r = K floor(r/K), columns t0-K*(64/K-1) .. t0+K-1)
+                const bool flush_plain = rows == 64 && (fo_need_tail ? (t0 >= 64 && t0 + 2 * K <= m) : (t0 >= K * (64 / K - 1) && t0 + K <= m));
+                if (flush_plain) {
+                    float vals[K];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) vals[k] = lds_out[fo_off0[k] + par * fo_dk[k]];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        if constexpr (ABL_NOSTORE) keep(vals[k]);
+                        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vals[k]), rs_out, fo_voff[k], ubase, AUX_OUT_STORE);
+                    }
+                } else {
+                    float vals[K];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) vals[k] = lds_out[fo_off0[k] + par * fo_dk[k]];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const int row = k * RPI + r_l;
+                        const int col = t0 - fo_d[k] + s_l;
+                        const bool ok = (unsigned)col < (unsigned)m && (i0 + row) < n;
+                        const unsigned off = ok ? fo_voff[k] + (unsigned)ubase : OOB;
+                        if constexpr (ABL_NOSTORE) {
+                            unsigned vv = __float_as_uint(vals[k]) ^ off;
+                            keep(vv);
+                        } else {
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vals[k]), rs_out, off, 0, 0);
+                        }
                     }
                 }
             }
@@ -1658,41 +1705,16 @@ __device__ __forceinline__ void sweep(const Params &p)
                 if (lane == PUB_LANE && !(SDP_EXP_BUILD && (p.dbg & 8))) lds_store_i32(prog + 4 * oword, obase + done);
             }
 
-            // ---- flush: one K-column aligned block per row (see fo_* above) ----
-            if constexpr (T::SOUT > 0) {
-                const int ubase = (i0 * ld + t0) * 4;
-                // all K*64 elements are real cells: rows of a full strip, columns t0-K*(64/K-1) .. t0+K-1
-                const bool flush_plain = rows == 64 && t0 >= K * (64 / K - 1) && t0 + K <= m;
-                if (flush_plain) {
-                    float vals[K];
-#pragma unroll
-                    for (int k = 0; k < K; ++k) vals[k] = lds_out[fo_off0[k] + par * fo_dk[k]];
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        if constexpr (ABL_NOSTORE) keep(vals[k]);
-                        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vals[k]), rs_out, fo_voff[k], ubase, AUX_OUT_STORE);
-                    }
-                } else {
-                    float vals[K];
-#pragma unroll
-                    for (int k = 0; k < K; ++k) vals[k] = lds_out[fo_off0[k] + par * fo_dk[k]];
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        const int row = k * RPI + r_l;
-                        const int col = t0 - K * (row / K) + s_l;
-                        const bool ok = (unsigned)col < (unsigned)m && (i0 + row) < n;
-                        const unsigned off = ok ? fo_voff[k] + (unsigned)ubase : OOB;
-                        if constexpr (ABL_NOSTORE) {
-                            unsigned vv = __float_as_uint(vals[k]) ^ off;
-                            keep(vv);
-                        } else {
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vals[k]), rs_out, off, 0, 0);
-                        }
-                    }
-                }
-            }
+            // ---- flush: one memory-aligned K-element block per row (see fo_* above) ----
+            flush_out(t0, par);
 
             if (more) write_block(bb_new);
+        }
+        if constexpr (T::SOUT > 0) {
+            // Rows whose blocks start to the right of the chunk (D_r < 0: only when the row pitch or the plane is not
+            // aligned to K floats) still hold their first columns in the ring after chunk 0: one more flush at
+            // t0 = -K (every element of it that exists was produced in chunk 0, "the previously processed one").
+            if (fo_need_tail) flush_out(-K, 1);
         }
         if constexpr (!REV) {
             if (t_final >= 0) {

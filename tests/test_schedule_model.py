@@ -106,25 +106,37 @@ def test_input_ring_holds_exactly_the_needed_blocks(M, K, rev, lines):
 
 
 @pytest.mark.parametrize("K", [16, 32])
-@pytest.mark.parametrize("N,M", [(64, 64), (64, 100), (40, 7), (64, 513)])
-def test_aligned_flush_covers_every_cell_once(N, M, K):
-    """Reverse sweep: after chunk t0 row r flushes the K-column block starting at t0 - K*floor(r/K); element e
-    comes from step offset s = (r mod K) + e: this chunk's half of the ring if s < K, else the half written by
-    the previously processed chunk (t0 + K).  Model the ring literally and check values and coverage."""
+@pytest.mark.parametrize("beta", [0, 5])
+@pytest.mark.parametrize("N,M", [(64, 64), (64, 100), (40, 7), (64, 513), (64, 516), (64, 500), (33, 129)])
+def test_aligned_flush_covers_every_cell_once(N, M, K, beta):
+    """Reverse sweep: after chunk t0 row r flushes the K-element block starting at column t0 - D_r, D_r = r - rho_r,
+    rho_r = (r (1 - M) - beta) mod K, so that the block starts on a multiple of K floats in MEMORY (beta = misalignment
+    of the plane); element e comes from step offset s = rho_r + e: this chunk's half of the ring if s < K, else the half
+    written by the previously processed chunk (t0 + K).  Model the ring literally and check values, coverage and the
+    alignment of every block.  (M a multiple of K, beta = 0: rho_r = r mod K, the column-aligned blocks of round 1.)"""
     nchunks = ceil_div(M + 63, K)
     PO = 2 * K + 1
     rows = min(N, 64)
     ring = np.full((64, PO), -1, dtype=np.int64)             # holds "column index" of the cell written there
     seen = np.zeros((rows, M), dtype=np.int64)
-    for c in range(nchunks - 1, -1, -1):
+    need_tail = beta != 0 or M % K != 0
+    for c in range(nchunks - 1, -2, -1):   # c = -1: the tail flush (t0 = -K) for rows whose blocks start right of t0
         t0, par = c * K, c & 1
-        for k in range(K - 1, -1, -1):
-            for lane in range(64):
-                ring[lane, par * K + k] = t0 + k - lane      # the value E[lane, t0+k-lane] (any int stands in)
+        if c >= 0:
+            for k in range(K - 1, -1, -1):
+                for lane in range(64):
+                    ring[lane, par * K + k] = t0 + k - lane      # the value E[lane, t0+k-lane] (any int stands in)
+        elif not need_tail:
+            continue
         for r in range(64):
-            blk0 = t0 - K * (r // K)
+            rho = (r * (1 - M) - beta) % K
+            d = r - rho
+            blk0 = t0 - d
+            assert (beta + r * M + blk0) % K == 0                    # starts on a K-float boundary in memory
+            if M % K == 0 and beta == 0:
+                assert rho == r % K and d == K * (r // K)
             for e in range(K):
-                s = (r % K) + e
+                s = rho + e
                 prev = s >= K
                 off0 = (s - K if prev else s) + (K if prev else 0)   # fo_off0 without the row term
                 dk = -K if prev else K
@@ -134,4 +146,3 @@ def test_aligned_flush_covers_every_cell_once(N, M, K):
                     assert ring[r, idx] == col, (c, r, e)
                     seen[r, col] += 1
     assert (seen == 1).all()
-

@@ -12,6 +12,9 @@ eng = get_engine()
 B = 256
 lens = datagen.lengths(2, B, 64, 1024)
 N, M = int(lens[:, 0].max()), int(lens[:, 1].max())
+if "align" in sys.argv:   # pad the column count to a multiple of 32: rows start on 128-byte lines
+    M = (M + 31) // 32 * 32
+print("padded shape", (B, N, M), flush=True)
 th, A = datagen.theta_A(2, B, N, M)
 th, A = torch.from_numpy(th).cuda(), torch.from_numpy(A).cuda()
 et = torch.ones(B, device="cuda")
