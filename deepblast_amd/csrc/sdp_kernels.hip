@@ -669,6 +669,11 @@ __device__ __forceinline__ void sweep(const Params &p)
         // whole 128-byte lines (a shifted block straddles two lines, and at one pair per CU the second touch of a
         // line, one chunk later, no longer hits in L2: fabric reads were 1.8x the tensors' size); the (r mod 4)
         // rotation then happens on the way into LDS, as four dword writes per loaded dwordx4.
+        // "Whole lines" means lines of MEMORY: for a row pitch that is not a multiple of K floats (or a plane that
+        // does not start on a line) row r's blocks are moved left by delta_r = (r M + beta) mod K columns, so that
+        // they still start on 128-byte boundaries; q becomes ceil((r - delta_r) / K), the ring positions follow the
+        // columns as before (round 2: forward sweep at M = 516 was 1.5x slower than at 512 without this).
+        bool li_unaligned = false;
         unsigned li_voff[NLD];
         int li_col[NLD];  // first column of this lane's group in block set 0 (non-plain path: skip groups outside the row)
         int li_w[NLD][LINES ? 4 : 1];
@@ -677,12 +682,15 @@ __device__ __forceinline__ void sweep(const Params &p)
             for (int i = 0; i < NLD; ++i) {
                 const int r = i * RPL + r4_l;
                 if constexpr (LINES) {
-                    const int q = (r + K - 1) / K;
-                    li_voff[i] = (unsigned)((r * ld - K * q + 4 * cg_l) * 4);
-                    li_col[i] = -K * q + 4 * cg_l;
+                    const int beta = (int)(((uintptr_t)(p.sin0 + b_in * plane_elems) >> 2) & (uintptr_t)(K - 1));
+                    li_unaligned = beta != 0 || (ld & (K - 1)) != 0;
+                    const int delta = (r * ld + beta) & (K - 1);   // (i0 * M is a multiple of K: strips are 64 rows)
+                    const int q = (r - delta + K - 1) / K;          // >= 0: delta <= K - 1
+                    li_col[i] = -K * q - delta + 4 * cg_l;
+                    li_voff[i] = (unsigned)((r * ld + li_col[i]) * 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        li_w[i][j] = r * PITCH + ((4 * cg_l + j + K * (q & 1) + r + 4 * ring_pi(r & 7)) & (RING - 1));
+                        li_w[i][j] = r * PITCH + ((4 * cg_l + j - delta + RING + K * (q & 1) + r + 4 * ring_pi(r & 7)) & (RING - 1));
                 } else {
                     const int q = ((r & ~3) + K - 1) / K;
                     li_voff[i] = (unsigned)((r * ld - K * q - (r & 3) + 4 * cg_l) * 4);
@@ -727,7 +735,8 @@ __device__ __forceinline__ void sweep(const Params &p)
 
         // every address of block set bb in range: the uniform part may ride in the scalar offset (no VALU
         // add and no reliance on how the hardware range-checks the scalar offset)
-        auto block_plain = [&](int bb) { return rows == 64 && bb >= QMAX && (bb + 1) * K <= m; };
+        // (blocks moved left by up to K-1 columns: one block set later)
+        auto block_plain = [&](int bb) { return rows == 64 && bb >= QMAX + (li_unaligned ? 1 : 0) && (bb + 1) * K <= m; };
         auto load_block_i = [&](int bb, bool plain, int i) {  // instruction i of block set bb -> registers
             if constexpr (T::SIN > 0) {
                 const int ubase = (i0 * ld + bb * K) * 4;
@@ -735,7 +744,12 @@ __device__ __forceinline__ void sweep(const Params &p)
                 // neighbouring row's data, 19 % of the input traffic at M = 512): send it out of range instead.
                 // Groups that straddle column 0 or M are loaded (the cells outside are never used).
                 const int col = li_col[i] + bb * K;
-                const unsigned off = plain ? li_voff[i] : ((col > -4 && col < m) ? li_voff[i] + (unsigned)ubase : OOB);
+                // plain: the per-lane part must be a non-negative offset on its own (the hardware range-checks it before
+                // the scalar part is added).  With blocks moved left (li_unaligned) it can be as low as -(2K + K - 1)
+                // floats for the first rows, so 3K floats travel from the scalar part to the per-lane part (plain block
+                // sets then have bb >= QMAX + 1 = 3, i.e. a scalar part of at least 3K floats).
+                const int bias = li_unaligned ? 3 * K * 4 : 0;
+                const unsigned off = plain ? li_voff[i] + (unsigned)bias : ((col > -4 && col < m) ? li_voff[i] + (unsigned)ubase : OOB);
 #pragma unroll
                 for (int q = 0; q < T::SIN; ++q) {
                     if constexpr (ABL_NOLOAD) {
@@ -744,7 +758,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                     } else {
                         // each dword is range-checked on its own (tools/ubench/bufx4.hip), and only dword
                         // alignment is needed, so M need not be a multiple of 4
-                        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_in[q], off, plain ? ubase : 0, (LINES && SDP_LINES_NT) ? 2 : AUX_IN_LOAD);
+                        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_in[q], off, plain ? ubase - bias : 0, (LINES && SDP_LINES_NT) ? 2 : AUX_IN_LOAD);
                         const unsigned v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
                         rs[q][4 * i] = __uint_as_float(v0);
                         rs[q][4 * i + 1] = __uint_as_float(v1);

@@ -183,6 +183,25 @@ def test_variable_length_batch_larger_than_the_gpu_runs_longest_first(variant):
         assert np.array_equal(alone[k], got[k][sel]), k
 
 
+@pytest.mark.parametrize("case", [(300, 70, 150, 0, False), (300, 69, 131, 1, False), (300, 130, 150, 0, True), (160, 200, 516, 0, False)],
+                         ids=lambda c: "x".join(str(int(v)) for v in c))
+def test_row_pitch_and_planes_not_aligned_to_cache_lines(case):
+    """Full batches (throughput builds) whose rows and per-pair planes do not start on 128-byte lines: the input
+    blocks and the output blocks are moved so that they are aligned in MEMORY (per-row offsets delta_r / D_r), the
+    results must not notice -- all four sweeps against the oracle, and batch independence bit for bit."""
+    B, N, M, variant, use_lens = case
+    theta, A = datagen.theta_A(4200 + N, B, N, M)
+    Z = datagen.normal(4201 + N, (B, N, M))
+    lens = datagen.lengths(4202, B, 1, min(N, M)) if use_lens else None
+    ref = parity.oracle_lens(theta, A, None, Z, variant, lens) if use_lens else parity.oracle_all(theta, A, None, Z, variant)
+    got = parity.engine_all(theta, A, None, Z, variant, lens=lens)
+    _assert(parity.compare(got, ref), str(case))
+    sel = [1, 7, B - 1]   # odd pair indices: planes at odd offsets
+    alone = parity.engine_all(theta[sel], A[sel], None, Z[sel], variant, lens=None if lens is None else lens[sel])
+    for k in ("Vt", "E", "Ed", "Vtd"):
+        assert np.array_equal(alone[k], got[k][sel]), k
+
+
 def test_headline_config_full_batch():
     """BASELINE.json configs[1]: B=256, N=M=512, whole batch against the oracle, plus
     size-independent properties: batch independence (bit-exact) and linearity in Et."""

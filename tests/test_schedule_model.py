@@ -51,7 +51,7 @@ def ring_pi(x):
 @pytest.mark.parametrize("K", [16, 32])
 @pytest.mark.parametrize("M", [1, 31, 64, 100, 257, 512])
 @pytest.mark.parametrize("rev", [False, True])
-@pytest.mark.parametrize("lines", [False, True])
+@pytest.mark.parametrize("lines", [False, True, "shifted"])
 def test_input_ring_holds_exactly_the_needed_blocks(M, K, rev, lines):
     """Model the staged-input ring literally: lanes load dwordx4 groups of row r's blocks (which start at
     columns K*j - (r mod 4), or at K*j in the line-aligned variant), write each group to one aligned 16-byte slot
@@ -61,6 +61,10 @@ def test_input_ring_holds_exactly_the_needed_blocks(M, K, rev, lines):
     nchunks = ceil_div(M + 63, K)
     RING = 2 * K
     LPR, RPL, NLD = K // 4, 64 // (K // 4), K // 4
+    # "shifted": the line-aligned variant for a plane / row pitch that is not aligned to K floats: row r's blocks move
+    # left by delta_r = (r M + beta) mod K so that they start on K-float boundaries of MEMORY
+    beta = 5 if lines == "shifted" else 0
+    pitch_mod = (M % K) if lines == "shifted" else 0
     order = range(nchunks - 1, -1, -1) if rev else range(nchunks)
     c_first = nchunks - 1 if rev else 0
     ring = np.full((64, RING), -10**9, dtype=np.int64)      # holds the column index stored in each position
@@ -72,10 +76,13 @@ def test_input_ring_holds_exactly_the_needed_blocks(M, K, rev, lines):
                 r4, cg = lane // LPR, lane % LPR
                 r = i * RPL + r4
                 if lines:   # blocks start at multiples of K (whole lines); four dword writes per group
-                    q = ceil_div(r, K)
-                    col0 = K * (bb - q) + 4 * cg
+                    delta = (r * pitch_mod + beta) % K
+                    q = (r - delta + K - 1) // K
+                    assert q >= 0 and K * q + delta >= r and K * q + delta < r + K   # the two live blocks cover the window
+                    col0 = K * (bb - q) - delta + 4 * cg
+                    assert (beta + r * pitch_mod + K * (bb - q) - delta) % K == 0    # block starts on a K-float boundary
                     for j in range(4):
-                        w = ((4 * cg + j + K * (q & 1) + r + 4 * ring_pi(r & 7)) & (RING - 1)) ^ flip
+                        w = ((4 * cg + j - delta + RING + K * (q & 1) + r + 4 * ring_pi(r & 7)) & (RING - 1)) ^ flip
                         assert w == (col0 + j + r + 4 * ring_pi(r & 7)) % RING
                         ring[r, w] = col0 + j
                     continue
