@@ -1,3 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|FAILED|assert" | tail -6
+timeout 300 python tools/gpu_configs.py 2>&1 | grep configs
+timeout 300 python tools/lens_probe.py 2>&1 | grep -E "padded shape|batch order, auto"
