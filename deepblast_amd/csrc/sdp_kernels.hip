@@ -758,6 +758,19 @@ __device__ __forceinline__ void sweep(const Params &p)
                     } else {
                         // each dword is range-checked on its own (tools/ubench/bufx4.hip), and only dword
                         // alignment is needed, so M need not be a multiple of 4
+                        if (LINES && li_unaligned && !plain && i0 == 0 && bb <= QMAX + 1) {
+                            // Blocks moved left by delta_r can straddle the START of the pair's plane (row 0, columns
+                            // -3..-1): the group's byte offset is then negative, and a negative offset fails the range
+                            // check for ALL four dwords (the per-dword check does not wrap), which would lose columns
+                            // 0..2 of row 0.  The first block sets of the first strip therefore load dword by dword,
+                            // each column on its own merits.
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const unsigned offj = ((unsigned)(col + j) < (unsigned)m) ? li_voff[i] + (unsigned)ubase + 4u * j : OOB;
+                                rs[q][4 * i + j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in[q], offj, 0, SDP_LINES_NT ? 2 : AUX_IN_LOAD));
+                            }
+                            continue;
+                        }
                         const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_in[q], off, plain ? ubase - bias : 0, (LINES && SDP_LINES_NT) ? 2 : AUX_IN_LOAD);
                         const unsigned v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
                         rs[q][4 * i] = __uint_as_float(v0);

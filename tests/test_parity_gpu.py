@@ -183,7 +183,9 @@ def test_variable_length_batch_larger_than_the_gpu_runs_longest_first(variant):
         assert np.array_equal(alone[k], got[k][sel]), k
 
 
-@pytest.mark.parametrize("case", [(300, 70, 150, 0, False), (300, 69, 131, 1, False), (300, 130, 150, 0, True), (160, 200, 516, 0, False)],
+@pytest.mark.parametrize("case", [(300, 70, 150, 0, False), (300, 69, 131, 1, False), (300, 130, 150, 0, True), (160, 200, 516, 0, False),
+                                  (217, 9, 6, 0, False), (142, 63, 25, 0, False), (188, 57, 59, 1, False), (237, 15, 10, 0, True),
+                                  (279, 21, 35, 0, False), (130, 3, 1, 0, False), (131, 70, 2, 1, False)],
                          ids=lambda c: "x".join(str(int(v)) for v in c))
 def test_row_pitch_and_planes_not_aligned_to_cache_lines(case):
     """Full batches (throughput builds) whose rows and per-pair planes do not start on 128-byte lines: the input
@@ -192,7 +194,7 @@ def test_row_pitch_and_planes_not_aligned_to_cache_lines(case):
     B, N, M, variant, use_lens = case
     theta, A = datagen.theta_A(4200 + N, B, N, M)
     Z = datagen.normal(4201 + N, (B, N, M))
-    lens = datagen.lengths(4202, B, 1, min(N, M)) if use_lens else None
+    lens = datagen.lengths(4202, B, 1, min(N, M)) if use_lens else None   # (planes at offsets b*N*M floats: any alignment)
     ref = parity.oracle_lens(theta, A, None, Z, variant, lens) if use_lens else parity.oracle_all(theta, A, None, Z, variant)
     got = parity.engine_all(theta, A, None, Z, variant, lens=lens)
     _assert(parity.compare(got, ref), str(case))
@@ -396,3 +398,25 @@ def test_max_cols_is_enforced():
     t = torch.zeros(1, 2, eng.max_cols() + 1, device="cuda")
     with pytest.raises(ValueError):
         eng.forward(t, t, 0)
+
+
+def test_fuzz_many_pairs_small_odd_shapes():
+    """The corner the line-aligned staging of round 2 first got wrong (found by tools/fuzz2.py, not by the suite): full
+    batches (>= 128 pairs: throughput builds) of small matrices whose planes start at arbitrary float offsets (N*M odd),
+    one partial strip, M below a chunk.  60 seeded cases, all four sweeps, NW and SW, with and without lengths."""
+    rng = np.random.default_rng(4242)
+    for it in range(60):
+        B, N, M = int(rng.integers(128, 300)), int(rng.integers(1, 90)), int(rng.integers(1, 90))
+        variant = int(rng.integers(0, 2))
+        theta, A = datagen.theta_A(70000 + it, B, N, M)
+        theta = (theta * float(rng.choice([0.01, 1.0, 8.0]))).astype(np.float32)
+        A = (A * float(rng.choice([0.0, 1.0, 10.0])) + float(rng.choice([0.0, 0.5, -3.0]))).astype(np.float32)
+        Z = datagen.normal(71000 + it, (B, N, M))
+        if rng.integers(0, 3) == 0:
+            lens = np.stack([rng.integers(1, N + 1, B), rng.integers(1, M + 1, B)], axis=1).astype(np.int32)
+            ref = parity.oracle_lens(theta, A, None, Z, variant, lens)
+            got = parity.engine_all(theta, A, None, Z, variant, lens=lens)
+        else:
+            ref = parity.oracle_all(theta, A, None, Z, variant)
+            got = parity.engine_all(theta, A, None, Z, variant)
+        _assert(parity.compare(got, ref), f"case {it}: {(B, N, M, variant)}")
