@@ -15,13 +15,17 @@
 //     row i-1 arrive from lane l-1 through one DPP full-wave shift of the carry (no
 //     LDS, no barrier); the row-i predecessor is the lane's own register;
 //   * strip-to-strip hand-off (bottom row of strip s -> lane 0 of strip s+1) goes
-//     through an 8-byte-slot row buffer in LDS, published K columns at a time with a
-//     monotonic progress word per wave (no s_barrier anywhere in the sweep);
+//     through an 8-byte-slot row buffer in LDS, published K columns at a time (forward
+//     sweep: 16 at a time, see fwd_blocks) with a monotonic progress word per wave (no
+//     s_barrier anywhere in the sweep);
 //   * row-major tensors (theta, A, Ztheta, ZA, E, Ed) cross the skew through LDS:
 //     inputs as K-column blocks loaded four columns per lane into a rotated per-row
 //     ring that the lanes read back with aligned 16-byte reads, prefetched through
 //     registers one chunk ahead; outputs are written to LDS by step and leave as
-//     aligned blocks;
+//     blocks; output blocks (and the input blocks of the throughput forward build) are
+//     aligned to 128-byte lines of MEMORY whatever the row pitch is (per-row offsets);
+//   * the forward sweep computes in blocks of 16 steps inside a K-step chunk: inputs,
+//     boundary values and published values live in 16-entry arrays (fwd_blocks);
 //   * the saved state (reference: Q, (B,N+2,M+2,3) fp32) is private to this library,
 //     so it is stored ALREADY SKEWED, [pair][strip][t][lane]: packed to 6 bytes per
 //     cell for the backward sweep (two steps per dwordx3), or float2 for the adjoint
