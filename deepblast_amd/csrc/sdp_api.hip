@@ -78,6 +78,14 @@ Variant variant(int id)
     case 8: return {(const void *)sdp_bwd_x_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 8};
     case 9: return {(const void *)sdp_fwd_x_tp_kernel, SDP_K_FWD, SDP_MAXW_FWD, 9};
     case 10: return {(const void *)sdp_adj_fwd_loss_kernel, SDP_K_AFWD, 4, 10};  // adj-fwd with the loss seed formed in the kernel
+    // general-pitch instantiations (staged blocks aligned to lines of memory through run-time per-row offsets): id + 11
+    case 11: return {(const void *)sdp_fwd_g_kernel, SDP_K_FWD, SDP_MAXW_FWD, 11};
+    case 12: return {(const void *)sdp_bwd_g_kernel, SDP_K_BWD, SDP_MAXW_BWD, 12};
+    case 14: return {(const void *)sdp_adj_bwd_g_kernel, SDP_K_ABWD, SDP_MAXW_ABWD, 14};
+    case 15: return {(const void *)sdp_bwd_lat_g_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 15};
+    case 18: return {(const void *)sdp_bwd_x_g_kernel, SDP_K_BWD, SDP_MAXW_BWD, 18};
+    case 19: return {(const void *)sdp_bwd_x_lat_g_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 19};
+    case 20: return {(const void *)sdp_fwd_x_tp_g_kernel, SDP_K_FWD, SDP_MAXW_FWD, 20};
     default: return {(const void *)sdp_bwd_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 4};
     }
 }
@@ -118,7 +126,24 @@ struct Plan {
     size_t lds, stage_off;
 };
 
-Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cus, int forced_waves, bool fused_seed = false)
+// kernel id -> its general-pitch instantiation (or itself if it has none: builds whose staged blocks keep the
+// column-aligned geometry -- latency forward builds, the adjoint forward)
+int general_id(int id)
+{
+    switch (id) {
+    case 0: return 11;
+    case 1: return 12;
+    case 3: return 14;
+    case 4: return 15;
+    case 7: return 18;
+    case 8: return 19;
+    case 9: return 20;
+    default: return id;
+    }
+}
+
+Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cus, int forced_waves, bool fused_seed = false,
+          bool general_pitch = false)
 {
     const int nstrips = sdp::state_nstrips(N);
     const int mcap = (M + 63) / 64 * 64;
@@ -148,6 +173,7 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
     if (pass == sdp::PASS_BWD && exact_state) v = variant(v.id == 1 ? 7 : 8);
     const int nin = (pass == sdp::PASS_AFWD && fused_seed) ? 3 : 0;   // three staged planes (ref, pred, G)
     if (nin) v = variant(10);
+    if (general_pitch) v = variant(general_id(v.id));
     if (W > v.maxw) W = v.maxw;
     if (W > nstrips) W = nstrips;
     size_t off = 0, lds = 0;
@@ -217,14 +243,19 @@ int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state 
 #else
     p.dbg = 0;
 #endif
-    const Plan pl = plan(pass, p.B, p.N, p.M, p.lens != nullptr, exact_state, num_cus(device), forced_waves, fused_seed);
+    // rows and planes of the staged tensors on 128-byte lines?  (M a multiple of 32 makes every plane offset b*N*M a
+    // multiple of 32 floats too; the tensors themselves come from an allocator that aligns far beyond 128 bytes, but a
+    // caller may pass a view)
+    auto misaligned = [](const void *ptr) { return ptr != nullptr && ((uintptr_t)ptr & 127u) != 0; };
+    const bool general_pitch = (p.M & 31) != 0 || misaligned(p.sin0) || misaligned(p.sin1) || misaligned(p.sin2) || misaligned(p.sout);
+    const Plan pl = plan(pass, p.B, p.N, p.M, p.lens != nullptr, exact_state, num_cus(device), forced_waves, fused_seed, general_pitch);
     const Variant v = pl.v;
     const int W = pl.W;
     const size_t lds = pl.lds, off = pl.stage_off;
     p.stage_off = (int)off;
     // raise the dynamic-LDS limit once per (thread, device, kernel) -- it is sticky, and the value is the
     // 160 KiB the hardware has, so concurrent callers cannot disagree
-    static thread_local unsigned long long lds_raised[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // bit d = done on device d
+    static thread_local unsigned long long lds_raised[21] = {0};  // per kernel id: bit d = done on device d
     if (device >= 64 || !(lds_raised[v.id] >> device & 1ull)) {
         e = hipFuncSetAttribute(v.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");

@@ -156,6 +156,13 @@ __global__ void sdp_bwd_x_lat_kernel(const sdp::Params p);
 __global__ void sdp_adj_fwd_kernel(const sdp::Params p);
 __global__ void sdp_adj_fwd_loss_kernel(const sdp::Params p);
 __global__ void sdp_adj_bwd_kernel(const sdp::Params p);
+__global__ void sdp_fwd_g_kernel(const sdp::Params p);
+__global__ void sdp_fwd_x_tp_g_kernel(const sdp::Params p);
+__global__ void sdp_bwd_g_kernel(const sdp::Params p);
+__global__ void sdp_bwd_lat_g_kernel(const sdp::Params p);
+__global__ void sdp_bwd_x_g_kernel(const sdp::Params p);
+__global__ void sdp_bwd_x_lat_g_kernel(const sdp::Params p);
+__global__ void sdp_adj_bwd_g_kernel(const sdp::Params p);
 __global__ void sdp_selftest_kernel(int *out);
 __global__ void sdp_loss_fwd_kernel(const float *ref, const float *pred, const float *G, const int *lens, double *acc, int *cnt, int N, int M, int kind);
 __global__ void sdp_loss_bwd_kernel(const float *ref, const float *pred, const float *G, const int *lens, const float *scale, float *grad, int N, int M, int kind);

@@ -365,7 +365,12 @@ __device__ __forceinline__ float loss_dterm(float r, float y, float sc, int kind
 // ----------------------------------------------------------------------------------
 // the sweep
 // ----------------------------------------------------------------------------------
-template <int PASS, int K, bool QX = false, bool LINES = false>
+// GEN: the "general pitch" instantiation -- staged blocks are aligned to 128-byte lines of MEMORY through per-row offsets
+// computed at run time (any row pitch, any plane offset).  GEN = false is the instantiation for rows and planes that
+// start on K-float boundaries (M a multiple of 32, 128-byte aligned tensors): the same formulas with the offsets
+// folded to constants -- the host picks per launch (sdp_api.hip), and the headline shape pays nothing for generality
+// (with one instantiation for both, the forward kernel measured +5 % and the backward +3 % at M = 512).
+template <int PASS, int K, bool QX = false, bool LINES = false, bool GEN = false>
 __device__ __forceinline__ void sweep(const Params &p)
 {
     using T = Traits<PASS, QX>;
@@ -686,9 +691,15 @@ __device__ __forceinline__ void sweep(const Params &p)
             for (int i = 0; i < NLD; ++i) {
                 const int r = i * RPL + r4_l;
                 if constexpr (LINES) {
-                    const int beta = (int)(((uintptr_t)(p.sin0 + b_in * plane_elems) >> 2) & (uintptr_t)(K - 1));
-                    li_unaligned = beta != 0 || (ld & (K - 1)) != 0;
-                    const int delta = (r * ld + beta) & (K - 1);   // (i0 * M is a multiple of K: strips are 64 rows)
+                    const int beta = GEN ? (int)(((uintptr_t)(p.sin0 + b_in * plane_elems) >> 2) & (uintptr_t)(K - 1)) : 0;
+                    li_unaligned = GEN && (beta != 0 || (ld & (K - 1)) != 0);
+                    int delta = GEN ? ((r * ld + beta) & (K - 1)) : 0;   // (i0 * M is a multiple of K: strips are 64 rows)
+                    // A group must not straddle the START of the pair's plane: its byte offset would be negative, and a
+                    // negative offset fails the range check for all four dwords (the per-dword check does not wrap) -- the
+                    // first columns of row 0 would read as zeros.  The few rows that begin within 3 floats of the plane
+                    // start therefore move by a multiple of 4 columns only (their groups then start at column <= -4 or
+                    // >= 0); their blocks begin up to 3 floats off a line boundary, which costs nothing measurable.
+                    if ((i0 + r) * ld < 4) delta &= ~3;
                     const int q = (r - delta + K - 1) / K;          // >= 0: delta <= K - 1
                     li_col[i] = -K * q - delta + 4 * cg_l;
                     li_voff[i] = (unsigned)((r * ld + li_col[i]) * 4);
@@ -713,24 +724,22 @@ __device__ __forceinline__ void sweep(const Params &p)
         // this is rho_r = r mod K, D_r = K floor(r/K): blocks aligned to K columns.  (With blocks aligned to columns
         // only, a row pitch that is not a multiple of 32 floats made every 128-byte store straddle two lines: the
         // backward sweep ran 2.1-2.4x slower at M = 516 than at M = 512.)  fo_off0 is the LDS index when the current
-        // chunk has parity 0, fo_dk the change when it has parity 1, fo_voff the global byte offset (row i0, t0 = 0),
-        // fo_d the D_r of the row each element belongs to.
-        int fo_off0[K], fo_dk[K], fo_d[K];
+        // chunk has parity 0, fo_dk the change when it has parity 1, fo_voff the global byte offset (row i0, t0 = 0).
+        int fo_off0[K], fo_dk[K];
         unsigned fo_voff[K];
         bool fo_need_tail = false;
         if constexpr (T::SOUT > 0) {
-            const int beta = (int)(((uintptr_t)(p.sout + b_out * plane_elems) >> 2) & (uintptr_t)(K - 1));
-            fo_need_tail = beta != 0 || (ld & (K - 1)) != 0;
+            const int beta = GEN ? (int)(((uintptr_t)(p.sout + b_out * plane_elems) >> 2) & (uintptr_t)(K - 1)) : 0;
+            fo_need_tail = GEN && (beta != 0 || (ld & (K - 1)) != 0);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int r = k * RPI + r_l;
-                const int rho = (r * (1 - ld) - beta) & (K - 1);   // (i0 * M is a multiple of K: strips are 64 rows)
+                const int rho = GEN ? ((r * (1 - ld) - beta) & (K - 1)) : (r & (K - 1));   // (i0 * M is a multiple of K: strips are 64 rows)
                 const int sfull = rho + s_l;
                 const bool prev = sfull >= K;
                 fo_off0[k] = r * PO + (prev ? sfull - K : sfull) + (prev ? K : 0);
                 fo_dk[k] = prev ? -K : K;
-                fo_d[k] = r - rho;
-                fo_voff[k] = (unsigned)((r * ld - fo_d[k] + s_l) * 4);
+                fo_voff[k] = (unsigned)((r * ld - (r - rho) + s_l) * 4);   // column s_l - D_r of row r
             }
         }
 
@@ -762,19 +771,6 @@ __device__ __forceinline__ void sweep(const Params &p)
                     } else {
                         // each dword is range-checked on its own (tools/ubench/bufx4.hip), and only dword
                         // alignment is needed, so M need not be a multiple of 4
-                        if (LINES && li_unaligned && !plain && i0 == 0 && bb <= QMAX + 1) {
-                            // Blocks moved left by delta_r can straddle the START of the pair's plane (row 0, columns
-                            // -3..-1): the group's byte offset is then negative, and a negative offset fails the range
-                            // check for ALL four dwords (the per-dword check does not wrap), which would lose columns
-                            // 0..2 of row 0.  The first block sets of the first strip therefore load dword by dword,
-                            // each column on its own merits.
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const unsigned offj = ((unsigned)(col + j) < (unsigned)m) ? li_voff[i] + (unsigned)ubase + 4u * j : OOB;
-                                rs[q][4 * i + j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in[q], offj, 0, SDP_LINES_NT ? 2 : AUX_IN_LOAD));
-                            }
-                            continue;
-                        }
                         const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_in[q], off, plain ? ubase - bias : 0, (LINES && SDP_LINES_NT) ? 2 : AUX_IN_LOAD);
                         const unsigned v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
                         rs[q][4 * i] = __uint_as_float(v0);
@@ -1190,7 +1186,7 @@ __device__ __forceinline__ void sweep(const Params &p)
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         const int row = k * RPI + r_l;
-                        const int col = t0 - fo_d[k] + s_l;
+                        const int col = t0 + (int)(fo_voff[k] >> 2) - row * ld;   // t0 - D_row + s_l (fo_voff >= 0: D_r <= r)
                         const bool ok = (unsigned)col < (unsigned)m && (i0 + row) < n;
                         const unsigned off = ok ? fo_voff[k] + (unsigned)ubase : OOB;
                         if constexpr (ABL_NOSTORE) {
@@ -1204,7 +1200,21 @@ __device__ __forceinline__ void sweep(const Params &p)
             }
         };
 
-        for (int ci = 0; ci < nchunks; ++ci) {
+        // Reverse sweeps flush the output blocks of a chunk at the top of the NEXT iteration (still before that chunk's
+        // steps overwrite the ring half the flush reads), so that the flush code exists once: the loop runs one extra
+        // iteration for the last chunk's flush, and one more for the tail flush at t0 = -K when the row pitch or the
+        // plane is not aligned to K floats (rows whose blocks start to the right of chunk 0 still hold their first
+        // columns in the ring; every element of that flush that exists was produced in chunk 0).
+        const int nflush = T::SOUT > 0 ? (fo_need_tail ? 2 : 1) : 0;
+        int pf_t0 = 0, pf_par = 0;
+        for (int ci = 0; ci < nchunks + nflush; ++ci) {
+            if constexpr (T::SOUT > 0) {
+                if (ci > 0) flush_out(pf_t0, pf_par);
+                if (ci >= nchunks) {
+                    pf_t0 = -K, pf_par = 1;
+                    continue;
+                }
+            }
             const int c = REV ? nchunks - 1 - ci : ci;
             const int t0 = c * K;
             const bool more = ci + 1 < nchunks;
@@ -1737,15 +1747,9 @@ __device__ __forceinline__ void sweep(const Params &p)
             }
 
             // ---- flush: one memory-aligned K-element block per row (see fo_* above) ----
-            flush_out(t0, par);
+            pf_t0 = t0, pf_par = par;
 
             if (more) write_block(bb_new);
-        }
-        if constexpr (T::SOUT > 0) {
-            // Rows whose blocks start to the right of the chunk (D_r < 0: only when the row pitch or the plane is not
-            // aligned to K floats) still hold their first columns in the ring after chunk 0: one more flush at
-            // t0 = -K (every element of it that exists was produced in chunk 0, "the previously processed one").
-            if (fo_need_tail) flush_out(-K, 1);
         }
         if constexpr (!REV) {
             if (t_final >= 0) {
@@ -1784,6 +1788,14 @@ SDP_KERNEL(sdp_bwd_x_lat_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT,
 SDP_KERNEL(sdp_adj_fwd_kernel, sdp::PASS_AFWD, SDP_K_AFWD, SDP_MAXW_AFWD)
 SDP_KERNEL(sdp_adj_fwd_loss_kernel, sdp::PASS_AFWD, SDP_K_AFWD, 4, true)
 SDP_KERNEL(sdp_adj_bwd_kernel, sdp::PASS_ABWD, SDP_K_ABWD, SDP_MAXW_ABWD)
+// general-pitch instantiations (GEN = true) of the kernels that stage outputs, and of the line-aligned forward builds
+SDP_KERNEL(sdp_fwd_g_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LINES != 0, true)
+SDP_KERNEL(sdp_fwd_x_tp_g_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, SDP_LINES != 0, true)
+SDP_KERNEL(sdp_bwd_g_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, false, false, true)
+SDP_KERNEL(sdp_bwd_lat_g_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, false, false, true)
+SDP_KERNEL(sdp_bwd_x_g_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, true, false, true)
+SDP_KERNEL(sdp_bwd_x_lat_g_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, true, false, true)
+SDP_KERNEL(sdp_adj_bwd_g_kernel, sdp::PASS_ABWD, SDP_K_ABWD, SDP_MAXW_ABWD, false, false, true)
 
 // ----------------------------------------------------------------------------------
 // launch order for variable-length batches: order[r] = the pair with the r-th largest n*m (ties: lower index first).

@@ -183,7 +183,8 @@ int sdp_device_status(int device, int32_t info[4]);
  * units -- kernel build (0 fwd throughput, 1 bwd throughput, 2 adj-fwd, 3 adj-bwd, 4 bwd latency, 5 fwd exact
  * state (latency), 6 fwd latency, 7 / 8 bwd reading the exact state (throughput / latency), 9 fwd exact state
  * (throughput)), chunk length, waves per pair,
- * dynamic LDS bytes.  Pure function, needs no device. */
+ * dynamic LDS bytes.  Pure function, needs no device.  (Reported for tensors whose rows and planes start on 128-byte
+ * lines -- M a multiple of 32; other launches use the "general pitch" instantiations of the same builds, ids 11-20.) */
 int sdp_plan(int pass, int B, int N, int M, int has_lens, int exact_state, int cus, int *kernel_id, int *chunk,
              int *waves, size_t *lds);
 
