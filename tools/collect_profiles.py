@@ -39,7 +39,7 @@ for name, pattern in (("kernel_stats.csv", "prof/**/*kernel_stats.csv"), ("train
                       ("pmc_train_fetch_size.csv", "pmc_train_FETCH_SIZE/**/*counter_collection.csv"),
                       ("pmc_train_write_size.csv", "pmc_train_WRITE_SIZE/**/*counter_collection.csv"),
                       ("bench.json", "bench.json"), ("bench_train.json", "bench_train.json"),
-                      ("pytest_gpu.txt", "pytest_gpu.txt"), ("smoke.txt", "smoke.txt")):
+                      ("pytest_gpu.txt", "pytest_gpu.txt"), ("smoke.txt", "smoke.txt"), ("fuzz2.txt", "fuzz2.txt")):
     f = first(pattern)
     if f:
         out = os.path.join(dst, f"{tag}_{name}")

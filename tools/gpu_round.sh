@@ -13,6 +13,9 @@ python tools/source_stamp.py > $OUT/stamp.json
 if [ "$2" != "quick" ]; then
   timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $OUT/pytest_gpu.txt
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee $OUT/smoke.txt
+  # the harsher fuzz (steep / flat scores, forbidden gaps, tiny and thin shapes, many pairs, per-pair lengths): the
+  # suite did not catch the one kernel bug of round 2, this did
+  timeout 900 python tools/fuzz2.py 300 2>&1 | tail -3 | tee $OUT/fuzz2.txt
 fi
 timeout 600 python bench.py --steps 20 --warmup 3 2> $OUT/bench.err | tee $OUT/bench.json
 timeout 600 python bench.py --steps 20 --warmup 3 --mode train --no-cpu-baseline 2>> $OUT/bench.err | tee $OUT/bench_train.json
