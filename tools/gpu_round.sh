@@ -17,14 +17,17 @@ if [ "$2" != "quick" ]; then
   # suite did not catch the one kernel bug of round 2, this did
   timeout 900 python tools/fuzz2.py 300 2>&1 | tail -3 | tee $OUT/fuzz2.txt
 fi
-timeout 600 python bench.py --steps 20 --warmup 3 2> $OUT/bench.err | tee $OUT/bench.json
-timeout 600 python bench.py --steps 20 --warmup 3 --mode train --no-cpu-baseline 2>> $OUT/bench.err | tee $OUT/bench_train.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o fwdbwd -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/rocprof.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o train -- python bench.py --steps 10 --warmup 2 --mode train --no-cpu-baseline > $OUT/bench_prof_train.json 2>> $OUT/rocprof.err
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o fwdbwd -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$C.err
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_train_$C -o train -- python bench.py --steps 3 --warmup 1 --mode train --no-cpu-baseline > /dev/null 2>> $OUT/pmc_$C.err
 done
+# the bench lines LAST, after profiles/traffic.json has been rebuilt (on this box's copy) from the counter passes of this
+# very visit: their roofline.traffic then is the figure measured minutes earlier on the same sources
+python tools/collect_profiles.py $TAG > $OUT/collect.txt 2>&1
+timeout 600 python bench.py --steps 20 --warmup 3 2> $OUT/bench.err | tee $OUT/bench.json
+timeout 600 python bench.py --steps 20 --warmup 3 --mode train --no-cpu-baseline 2>> $OUT/bench.err | tee $OUT/bench_train.json
 # keep what is merged back small: the per-dispatch traces are large, the stats and counter CSVs are not
 find $OUT -name "*kernel_trace.csv" -size +4M -delete
 for f in $(find $OUT/prof $OUT/prof_train -name "*kernel_stats.csv"); do echo "== $f"; head -8 $f; done
