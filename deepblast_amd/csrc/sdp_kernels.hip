@@ -242,6 +242,19 @@ __device__ __forceinline__ float2 q_unpack(const unsigned *w, int second)
 // 0: on long, peaked alignments it reached 1e-3 of Ed.  The small weights carry the same relative error, so the
 // complement is accurate to 1e-7 * (1 - q).  When the match weight qm is the largest nothing has to be done: the
 // readers form qm = 1 - qx - qy anyway.
+typedef float f32x2 __attribute__((ext_vector_type(2)));  // operand of the packed fp32 instructions (v_pk_mul / v_pk_fma)
+
+// 2^(theta log2e) = 2^tt * (1 + c) where tt = fl(theta * fl(log2e)) is what v_exp_f32 was given and
+// c = ln2 * (theta * log2e - tt), the rounding of the product recovered exactly (fma) plus the low part of log2(e).
+// |c| <= |tt| 2^-24: the second-order term is below 1e-12.
+__device__ __forceinline__ f32x2 exp2_residual(f32x2 theta, f32x2 tt)
+{
+    constexpr float L_HI = 1.44269502162933349609375f, L_LO = 1.92596299112661746e-8f, LN2 = 0.69314718055994530942f;
+    f32x2 d = __builtin_elementwise_fma(theta, (f32x2){L_HI, L_HI}, -tt);
+    d = __builtin_elementwise_fma(theta, (f32x2){L_LO, L_LO}, d);
+    return d * (f32x2){LN2, LN2};
+}
+
 __device__ __forceinline__ void q_sharpen(float &wx, float &wy, float wm)
 {
     const float big = __builtin_fmaxf(wx, wy), small = __builtin_fminf(wx, wy);
@@ -285,7 +298,6 @@ struct Kind {
 };
 
 typedef unsigned long long u64;  // one boundary slot (LDS) / one edge value in registers
-typedef float f32x2 __attribute__((ext_vector_type(2)));  // operand of the packed fp32 instructions (v_pk_mul / v_pk_fma)
 
 __device__ __forceinline__ u64 pack2(unsigned lo, unsigned hi) { return ((u64)hi << 32) | lo; }
 __device__ __forceinline__ unsigned lo32(u64 x) { return (unsigned)x; }
@@ -983,6 +995,11 @@ __device__ __forceinline__ void sweep(const Params &p)
                             const f32x2 ta = (f32x2){in1[j], in1[j + 1]} * (f32x2){1.44269504088896340736f, 1.44269504088896340736f};
                             ctv[j] = __builtin_amdgcn_exp2f(tt[0]), ctv[j + 1] = __builtin_amdgcn_exp2f(tt[1]);
                             cav[j] = __builtin_amdgcn_exp2f(ta[0]), cav[j + 1] = __builtin_amdgcn_exp2f(ta[1]);
+                            if constexpr (QX) {
+                                const f32x2 c = exp2_residual((f32x2){in0[j], in0[j + 1]}, tt);
+                                const f32x2 e = __builtin_elementwise_fma((f32x2){ctv[j], ctv[j + 1]}, c, (f32x2){ctv[j], ctv[j + 1]});
+                                ctv[j] = e[0], ctv[j + 1] = e[1];
+                            }
                             mcf = __builtin_fmaxf(__builtin_fmaxf(mcf, __builtin_fabsf(tt[0])), __builtin_fabsf(tt[1]));
                             mcf = __builtin_fmaxf(__builtin_fmaxf(mcf, ta[0]), ta[1]);
                         }
@@ -1059,10 +1076,34 @@ __device__ __forceinline__ void sweep(const Params &p)
                             const float ta = __builtin_amdgcn_fmed3f(in1[j] * 1.44269504088896340736f, -1048576.f, 1048576.f);
                             // Moderate exponents take mantissa and exponent of the SAME 2^tt the windowed form multiplies
                             // with, so that both forms produce identical bits
-                            const float et2 = __builtin_amdgcn_exp2f(tt), ea2 = __builtin_amdgcn_exp2f(ta);
+                            float et2 = __builtin_amdgcn_exp2f(tt);
+                            const float ea2 = __builtin_amdgcn_exp2f(ta);
+                            if constexpr (QX) {   // the same corrected 2^theta as the windowed form, bit for bit
+                                const f32x2 c = exp2_residual((f32x2){in0[j], in0[j]}, (f32x2){tt, tt});
+                                const f32x2 e = __builtin_elementwise_fma((f32x2){et2, et2}, c, (f32x2){et2, et2});
+                                et2 = e[0];
+                            }
                             const float kt = __builtin_floorf(tt), ka = __builtin_floorf(ta);
-                            const float st = __builtin_amdgcn_exp2f(tt - kt), sa = __builtin_amdgcn_exp2f(ta - ka);
-                            const bool mt = __builtin_fabsf(tt) <= 120.f, ma = __builtin_fabsf(ta) <= 120.f;
+                            float st, sa;
+                            bool mt, ma;
+                            if constexpr (QX) {
+                                // Exact-state build (second-order results): the product theta * log2(e), rounded to fp32,
+                                // is off by up to |tt| 2^-24 bits -- 9e-6 at |theta| = 100 -- and the weights of the three
+                                // cells that read this V inherit it; over a few hundred soft cells that reaches 1e-4 in
+                                // Vtd.  Beyond the windowed form's range (|tt| > 12; below it the two forms must agree
+                                // bit for bit) the fraction is formed from the exact product: log2(e) as hi + lo, the
+                                // integer part taken out inside the fma.  -inf (a forbidden gap) ends at the clamp: 2^0
+                                // with the exponent -2^20, as before.
+                                constexpr float L_HI = 1.44269502162933349609375f, L_LO = 1.92596299112661746e-8f;
+                                const float ft = __builtin_fmaf(in0[j], L_LO, __builtin_fmaf(in0[j], L_HI, -kt));
+                                const float fa2 = __builtin_fmaf(in1[j], L_LO, __builtin_fmaf(in1[j], L_HI, -ka));
+                                st = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(ft, -0.5f, 1.5f));
+                                sa = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(fa2, -0.5f, 1.5f));
+                                mt = __builtin_fabsf(tt) <= 12.f, ma = __builtin_fabsf(ta) <= 12.f;
+                            } else {
+                                st = __builtin_amdgcn_exp2f(tt - kt), sa = __builtin_amdgcn_exp2f(ta - ka);
+                                mt = __builtin_fabsf(tt) <= 120.f, ma = __builtin_fabsf(ta) <= 120.f;
+                            }
                             const float ct = mt ? __builtin_amdgcn_frexp_mantf(et2) : st;
                             const int kti = mt ? __builtin_amdgcn_frexp_expf(et2) : (int)kt;
                             const float ca = ma ? __builtin_amdgcn_frexp_mantf(ea2) : sa;

@@ -6,12 +6,15 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, datagen, parity
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 777
+MODE = sys.argv[3] if len(sys.argv) > 3 else "mixed"   # "full": only full batches of mid-size odd shapes
+REPORT = float(os.environ.get("FUZZ_REPORT", "1"))   # also list cases above this error (to see which regime is closest to the bound)
 rng = np.random.default_rng(seed)
 worst1 = worst2 = 0.0
 nf1 = nf2 = 0
 for it in range(n):
-    kind = rng.integers(0, 5)
-    if kind == 0: B, N, M = int(rng.integers(1, 4)), int(rng.integers(1, 8)), int(rng.integers(1, 2049))
+    kind = rng.integers(0, 5) if MODE == "mixed" else 9
+    if kind == 9: B, N, M = int(rng.integers(128, 200)), int(rng.integers(40, 400)), int(rng.integers(40, 400))   # full batches: throughput builds
+    elif kind == 0: B, N, M = int(rng.integers(1, 4)), int(rng.integers(1, 8)), int(rng.integers(1, 2049))
     elif kind == 1: B, N, M = int(rng.integers(1, 4)), int(rng.integers(1, 1500)), int(rng.integers(1, 8))
     elif kind == 2: B, N, M = int(rng.integers(1, 300)), int(rng.integers(1, 90)), int(rng.integers(1, 90))
     else: B, N, M = int(rng.integers(1, 4)), int(rng.integers(1, 700)), int(rng.integers(1, 900))
@@ -36,7 +39,7 @@ for it in range(n):
     e1 = max(e["Vt"], e["E"]); e2 = max(e["Ed"], e["Vtd"])
     e1 = e1 if np.isfinite(e1) else 9e9; e2 = e2 if np.isfinite(e2) else 9e9
     worst1, worst2 = max(worst1, e1), max(worst2, e2)
-    if e1 > parity.TOL or e2 > parity.TOL:
+    if e1 > parity.TOL or e2 > parity.TOL or max(e1, e2) > REPORT:
         nf1 += e1 > parity.TOL; nf2 += e2 > parity.TOL
         print(f"it={it} {(B, N, M, variant, use_lens)} theta*{ts} A*{as_}+{ao}: " + " ".join(f"{k}={v:.2e}" for k, v in e.items()), flush=True)
 print(f"{n} cases: first-order worst {worst1:.3e} ({nf1} over 1e-4), second-order worst {worst2:.3e} ({nf2} over 1e-4)")

@@ -1,3 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 600 python tools/lens_probe.py 2>&1 | grep -E "padded shape|batch order|sorted"
+timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -8
