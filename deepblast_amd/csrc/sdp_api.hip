@@ -220,6 +220,14 @@ struct VariantBits {
     int variant, waves;
     bool exact;
 };
+// The packed state keeps two 24-bit weights per cell; a saturated weight that the forward sweep leaves one step
+// below 1 costs 1.7e-8 of E on average, which stays inside the 1e-4 parity bound up to ~5000 steps of a fully
+// saturated path (measured: 7.5e-5 at N = M = 2048, 2.7e-4 at N = 20000).  Longer problems therefore always use
+// the exact (float2) state, whose largest weight is the complement of the other two (q_sharpen): <= 1e-5 at
+// N = 60000.  sdp_state_bytes covers either layout; forward and backward apply the same rule.
+constexpr int PACKED_MAX_PATH = 4096;
+inline bool exact_for(bool flag, int N, int M) { return flag || N + M > PACKED_MAX_PATH; }
+
 VariantBits split_variant(int variant)
 {
     VariantBits v;
@@ -281,7 +289,8 @@ size_t sdp_state_bytes(int B, int N, int M)
 {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
     // 2 x 23 bits per cell, 3 dwords per 2 cells (a 768-byte record row per pair of steps); + the launch order of a
-    // variable-length batch
+    // variable-length batch.  Problems longer than PACKED_MAX_PATH keep the exact state (see exact_for).
+    if (exact_for(false, N, M)) return sdp_state_d_bytes(B, N, M);
     return packed_body_bytes(B, N, M) + sdp::state_order_bytes(B);
 }
 
@@ -297,7 +306,8 @@ int sdp_plan(int pass, int B, int N, int M, int has_lens, int exact_state, int c
     if (pass < 0 || pass > 3) return fail(SDP_E_VARIANT, "sdp_plan: pass must be 0..3");
     if (int rc = check_shape(B, N, M, SDP_NW)) return rc;
     if (cus <= 0) return fail(SDP_E_SHAPE, "sdp_plan: cus must be positive");
-    const Plan pl = plan(pass, B, N, M, has_lens != 0, exact_state != 0, cus, 0);
+    const bool exact = (pass == sdp::PASS_FWD || pass == sdp::PASS_BWD) ? exact_for(exact_state != 0, N, M) : exact_state != 0;
+    const Plan pl = plan(pass, B, N, M, has_lens != 0, exact, cus, 0);
     if (kernel_id) *kernel_id = pl.v.id;
     if (chunk) *chunk = pl.v.K;
     if (waves) *waves = pl.W;
@@ -328,7 +338,7 @@ int sdp_forward_f32(const float *theta, const float *A, float *state, float *Vt,
 {
     if (!theta || !A || !state || !Vt) return fail(SDP_E_NULLPTR, "sdp_forward_f32: null pointer");
     const VariantBits vb = split_variant(variant);
-    const bool exact = vb.exact;
+    const bool exact = exact_for(vb.exact, N, M);
     variant = vb.variant;
     if (int rc = check_shape(B, N, M, variant)) return rc;
     sdp::Params p = {};
@@ -355,7 +365,7 @@ int sdp_backward_f32(const float *Et, const float *state, float *E, int B, int N
 {
     if (!Et || !state || !E) return fail(SDP_E_NULLPTR, "sdp_backward_f32: null pointer");
     const VariantBits vb = split_variant(variant);
-    const bool exact = vb.exact;
+    const bool exact = exact_for(vb.exact, N, M);
     variant = vb.variant;
     if (int rc = check_shape(B, N, M, variant)) return rc;
     sdp::Params p = {};

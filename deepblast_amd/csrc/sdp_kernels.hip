@@ -521,7 +521,7 @@ __device__ __forceinline__ void sweep(const Params &p)
         u64 *bnd_out = bnd + (size_t)oslot * p.mcap;
         const int *frm_in = frm + pslot * FRAME_CAP;
         int *frm_out = frm + oslot * FRAME_CAP;
-        int wf_skip = 0;  // chunks to leave to the normalised form after a failed windowed attempt
+        int wf_skip = 0;  // blocks to leave to the normalised form after a failed windowed attempt
         // chunks in which every lane sits on a real, non-special cell need no masking at all
         // (the terminal cell of the last strip is met at t >= m-1, which interior chunks never contain)
         const bool plain_strip = rows == 64 && !(sw && s == 0);
@@ -1084,26 +1084,18 @@ __device__ __forceinline__ void sweep(const Params &p)
                                 et2 = e[0];
                             }
                             const float kt = __builtin_floorf(tt), ka = __builtin_floorf(ta);
-                            float st, sa;
-                            bool mt, ma;
-                            if constexpr (QX) {
-                                // Exact-state build (second-order results): the product theta * log2(e), rounded to fp32,
-                                // is off by up to |tt| 2^-24 bits -- 9e-6 at |theta| = 100 -- and the weights of the three
-                                // cells that read this V inherit it; over a few hundred soft cells that reaches 1e-4 in
-                                // Vtd.  Beyond the windowed form's range (|tt| > 12; below it the two forms must agree
-                                // bit for bit) the fraction is formed from the exact product: log2(e) as hi + lo, the
-                                // integer part taken out inside the fma.  -inf (a forbidden gap) ends at the clamp: 2^0
-                                // with the exponent -2^20, as before.
-                                constexpr float L_HI = 1.44269502162933349609375f, L_LO = 1.92596299112661746e-8f;
-                                const float ft = __builtin_fmaf(in0[j], L_LO, __builtin_fmaf(in0[j], L_HI, -kt));
-                                const float fa2 = __builtin_fmaf(in1[j], L_LO, __builtin_fmaf(in1[j], L_HI, -ka));
-                                st = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(ft, -0.5f, 1.5f));
-                                sa = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(fa2, -0.5f, 1.5f));
-                                mt = __builtin_fabsf(tt) <= 12.f, ma = __builtin_fabsf(ta) <= 12.f;
-                            } else {
-                                st = __builtin_amdgcn_exp2f(tt - kt), sa = __builtin_amdgcn_exp2f(ta - ka);
-                                mt = __builtin_fabsf(tt) <= 120.f, ma = __builtin_fabsf(ta) <= 120.f;
-                            }
+                            // The product theta * log2(e), rounded to fp32, is off by up to |tt| 2^-24 bits -- 9e-6 at
+                            // |theta| = 100 -- and the weights of the three cells that read this V inherit it; over a few
+                            // hundred soft cells that reaches 1e-4 in Vtd (and 4e-5 in E).  Beyond the windowed form's
+                            // range (|tt| > 12; below it the two forms must agree bit for bit) the fraction is formed
+                            // from the exact product: log2(e) as hi + lo, the integer part taken out inside the fma.
+                            // -inf (a forbidden gap) ends at the clamp: 2^0 with the exponent -2^20.
+                            constexpr float L_HI = 1.44269502162933349609375f, L_LO = 1.92596299112661746e-8f;
+                            const float ft = __builtin_fmaf(in0[j], L_LO, __builtin_fmaf(in0[j], L_HI, -kt));
+                            const float fa2 = __builtin_fmaf(in1[j], L_LO, __builtin_fmaf(in1[j], L_HI, -ka));
+                            const float st = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(ft, -0.5f, 1.5f));
+                            const float sa = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(fa2, -0.5f, 1.5f));
+                            const bool mt = __builtin_fabsf(tt) <= 12.f, ma = __builtin_fabsf(ta) <= 12.f;
                             const float ct = mt ? __builtin_amdgcn_frexp_mantf(et2) : st;
                             const int kti = mt ? __builtin_amdgcn_frexp_expf(et2) : (int)kt;
                             const float ca = ma ? __builtin_amdgcn_frexp_mantf(ea2) : sa;
@@ -1121,7 +1113,12 @@ __device__ __forceinline__ void sweep(const Params &p)
                             {
                                 float2 qq = make_float2(tq * u, tq * l);
                                 const bool cell_in = !EDGE || (unsigned)col < (unsigned)m;
-                                if constexpr (QX) q_sharpen(qq.x, qq.y, d * rinv);
+                                // every build sharpens here: a block lands in this form when its scores are steep, and
+                                // steep scores are where paths saturate -- a packed weight left at 1 - 2^-23 instead of 1
+                                // loses 1.7e-8 of E per step on average (7e-5 over the 4096 steps of a 2048 x 2048
+                                // problem).  Which blocks run this form does not depend on the build (wf_skip counts
+                                // blocks, not chunks), so results stay bit-identical across wave counts.
+                                q_sharpen(qq.x, qq.y, d * rinv);
                                 if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); }
                                 else if constexpr (QX) store_state(tb, j, qq, cell_in);
                                 else store_state_bits(tb, j, __float_as_uint(__builtin_fmaf(qq.x, Q_SCALE, 1.0f)),
@@ -1169,7 +1166,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         const int rc = use_pred ? (blk_interior ? wf_block(std::false_type{}, std::true_type{}) : wf_block(std::true_type{}, std::true_type{}))
                                                 : (blk_interior ? wf_block(std::false_type{}, std::false_type{}) : wf_block(std::true_type{}, std::false_type{}));
                         done = rc > 0;
-                        if (rc < 0) wf_skip = K / WB;  // values move too fast for one frame per block here: try again a chunk later
+                        if (rc < 0) wf_skip = 2;  // values move too fast for one frame per block here: try again two blocks later (the same in every build)
                     } else {
                         --wf_skip;
                     }

@@ -34,6 +34,10 @@
  *     directional derivatives of any size and need them at full fp32 precision:
  *     run sdp_forward_f32 with SDP_EXACT_STATE for them (float2 per cell, the
  *     size of Qd); sdp_backward_f32 reads that format too when given the flag.
+ *     Problems with N + M > 4096 always use the float2 form (a saturated packed
+ *     weight costs ~1.7e-8 of E per step; beyond ~5000 steps of a fully saturated
+ *     path that would pass 1e-4): sdp_state_bytes accounts for it, and forward
+ *     and backward apply the same rule, so callers need not care.
  *   - `lens` is NULL (reference semantics: every pair uses the full padded N x M)
  *     or a DEVICE pointer to B x 2 int32 (n_b, m_b): pair b is aligned over its
  *     top-left n_b x m_b block, terminal cell (n_b, m_b); E/Ed outside the block

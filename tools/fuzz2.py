@@ -32,7 +32,10 @@ for it in range(n):
             lens = np.stack([rng.integers(1, N + 1, B), rng.integers(1, M + 1, B)], axis=1).astype(np.int32)
             ref = parity.oracle_lens(theta, A, None, Z, variant, lens); got = parity.engine_all(theta, A, None, Z, variant, lens=lens)
         else:
-            ref = parity.oracle_all(theta, A, None, Z, variant); got = parity.engine_all(theta, A, None, Z, variant)
+            # a third of the padded cases also seed the gap scores' direction (ZA) and a random upstream factor Et
+            ZA = datagen.normal(70000 + it, (B, N, M)) if rng.integers(0, 3) == 0 else None
+            Et = rng.normal(size=B).astype(np.float32) if rng.integers(0, 3) == 0 else None
+            ref = parity.oracle_all(theta, A, Et, Z, variant, ZA=ZA); got = parity.engine_all(theta, A, Et, Z, variant, ZA=ZA)
         e = parity.compare(got, ref)
     except Exception as ex:
         print("EXCEPTION", it, (B, N, M, variant, use_lens), ex, flush=True); nf1 += 1; continue
