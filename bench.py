@@ -42,13 +42,13 @@ def parse():
     ap.add_argument("--N", type=int, default=512)
     ap.add_argument("--M", type=int, default=512)
     ap.add_argument("--variant", choices=["nw", "sw"], default="nw")
-    ap.add_argument("--mode", choices=["fwdbwd", "train", "scores+dp", "train-mce", "train-mce-fused"], default="fwdbwd",
+    ap.add_argument("--mode", choices=["fwdbwd", "align+traceback", "train", "scores+dp", "train-mce", "train-mce-fused"], default="fwdbwd",
                     help="fwdbwd: headline; train: decode -> loss -> backward (adds the adjoint pair); scores+dp: theta/A "
                          "from (B,N,D) embeddings on the matrix cores (alignment.py:122-123), then the headline step; "
                          "train-mce: decode -> MatrixCrossEntropy (the reference's training loss, trainer.py:154-171) -> backward; "
                          "train-mce-fused: the same as one op, the loss gradient seeding the adjoint sweep inside the kernel")
     ap.add_argument("--D", type=int, default=512, help="embedding width of --mode scores+dp (reference default n_embed)")
-    ap.add_argument("--gather", choices=["vt", "e", "none"], default="vt")
+    ap.add_argument("--gather", choices=["vt", "e", "paths", "none"], default="vt")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs in the CPU-baseline sample")
     return ap.parse_args()
@@ -221,6 +221,9 @@ def main():
         if args.mode == "fwdbwd":
             out = aligner.align(theta, A)      # Vt = dec(theta, A); dVt.sum()/dtheta; all-gather Vt
             return out["E_local"]
+        if args.mode == "align+traceback":     # inference: the alignment matrix and its arg-max walk (alignment.py:165-170, batched)
+            out = aligner.align(theta, A)
+            return out["paths"] if out.get("paths") is not None else eng.traceback(out["E_local"])
         t = theta.detach().requires_grad_(True)
         a = A.detach().requires_grad_(True)    # decode() differentiates w.r.t. (theta, A) like the reference
         aln = dec.decode(t, a)                 # forward + backward kernels (create_graph)
@@ -265,6 +268,14 @@ def main():
         dt_e, _ = timed(min(args.steps, 5))
         aligner.gather = args.gather
         e_gather = dt_e / min(args.steps, 5)
+    # ... and with the tracebacks gathered instead (device walk + (N+M+2) int32 per pair over the wire)
+    paths_gather = None
+    if world > 1 and args.mode == "fwdbwd" and args.gather != "paths":
+        aligner.gather = "paths"
+        step()
+        dt_p, _ = timed(min(args.steps, 5))
+        aligner.gather = args.gather
+        paths_gather = dt_p / min(args.steps, 5)
 
     cells = B * N * M if args.variant == "nw" else B * (N - 1) * (M - 1)
     per_step_updates = (4 if args.mode.startswith("train") else 2) * cells
@@ -292,7 +303,7 @@ def main():
             except (OSError, ValueError, ImportError):
                 traffic = None
         line = {
-            "metric": {"fwdbwd": "DP cell-updates/sec (fwd+bwd)", "train": "DP cell-updates/sec (train: fwd+bwd+adjoint pair)",
+            "metric": {"fwdbwd": "DP cell-updates/sec (fwd+bwd)", "align+traceback": "DP cell-updates/sec (fwd+bwd + batched traceback)", "train": "DP cell-updates/sec (train: fwd+bwd+adjoint pair)",
                        "scores+dp": "DP cell-updates/sec (scores from embeddings + fwd+bwd)",
                        "train-mce": "DP cell-updates/sec (train: decode + MatrixCrossEntropy + backward)",
                        "train-mce-fused": "DP cell-updates/sec (train: fused decode + MatrixCrossEntropy + backward)"}[args.mode],
@@ -300,7 +311,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": float(np.median(per_step_ms)),
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.variant.upper()} soft-DP " + {"fwdbwd": "fwd+bwd", "train": "decode+loss.backward",
+            "config": {"workload": f"{args.variant.upper()} soft-DP " + {"fwdbwd": "fwd+bwd", "align+traceback": "fwd+bwd+traceback", "train": "decode+loss.backward",
                                                                         "scores+dp": f"scores(D={args.D})+fwd+bwd", "train-mce": "decode+MatrixCrossEntropy.backward",
                                                                         "train-mce-fused": "fused decode+MatrixCrossEntropy.backward"}[args.mode] +
                                    f", B={B} per GPU, N={N}, M={M}, random theta/A "
@@ -326,6 +337,11 @@ def main():
         if e_gather is not None:
             line["with_e_gather"] = {"ms_per_step": e_gather * 1e3, "value": world * per_step_updates / e_gather,
                                      "bytes_into_each_gpu": (world - 1) * B * N * M * 4}
+        if paths_gather is not None:
+            line["with_paths_gather"] = {"ms_per_step": paths_gather * 1e3, "value": world * per_step_updates / paths_gather,
+                                         "bytes_into_each_gpu": (world - 1) * B * (N + M + 4) * 4}
+        if "sdp_traceback_kernel" in ms:
+            line["traceback_ms"] = ms["sdp_traceback_kernel"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
             line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

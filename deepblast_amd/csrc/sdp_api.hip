@@ -474,7 +474,7 @@ int sdp_traceback_i32(const float *grad, int32_t *states, int32_t *counts, int B
     if (B <= 0 || N <= 0 || M <= 0) return fail(SDP_E_SHAPE, "B, N and M must be positive");
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
-    hipLaunchKernelGGL(sdp_traceback_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, grad, states, counts,
+    hipLaunchKernelGGL(sdp_traceback_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, grad, states, counts,
                        lens, B, N, M, sdp_traceback_capacity(N, M));
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "sdp_traceback_kernel");

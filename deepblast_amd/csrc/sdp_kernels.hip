@@ -99,6 +99,9 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #else
 #define SDP_EXP_BUILD 0  // default library: Params::dbg is ignored, no wrong-results switch is reachable
 #endif
+#ifndef SDP_TB_WINDOW
+#define SDP_TB_WINDOW 32  // traceback: edge of the LDS window of E (32 or 64 cells)
+#endif
 #ifndef SDP_PREPASS
 #define SDP_PREPASS 1
 #endif
@@ -1860,82 +1863,185 @@ extern "C" __global__ void __launch_bounds__(256) sdp_order_kernel(const int *le
 
 // ----------------------------------------------------------------------------------
 // batched traceback: the reference's greedy arg-max walk (deepblast/nw.py:401-444,
-// sw.py:328-371), one pair per lane.  Integer work, bit-identical to the host version in
-// deepblast_amd/_dp.py::traceback, including Python's negative-index wrap when exactly one of
-// (i, j) is 0; a walk that leaves the matrix (the reference raises IndexError) sets count = -1.
-// Latency-bound by construction (<= N+M dependent 3-load steps per pair); pairs run in parallel.
+// sw.py:328-371).  Integer work, bit-identical to the host version in deepblast_amd/_dp.py::traceback,
+// including Python's negative-index wrap when exactly one of (i, j) is 0; a walk that leaves the matrix
+// (the reference raises IndexError) sets count = -1.
+//
+// One wavefront per pair.  The walk is a chain of <= N+M dependent steps, each reading three neighbours of the
+// current cell; one lane per pair with three global loads per step (round 1) paid a full memory latency per step --
+// 0.9 ms at 256 x 512 x 512, more than twice the two sweeps that produce E.  Here the wave keeps the 32 x 32 window
+// of E whose bottom-right corner is the current cell in LDS (16 coalesced loads per lane, all in flight together);
+// the walk only moves up and left, so it stays inside for 31 ... 62 steps, each three LDS broadcasts and a few scalar
+// compares, before the window is re-centred.  Steps are collected one per lane and written 64 at a time from the END
+// of the pair's buffer backwards (the reference returns the walk reversed; its length is not known in advance), then
+// the wave moves them to the front.  The window is filled through python's index wrap, so the top row / left column
+// (floor values, reads that wrap to the opposite edge) and already-wrapped walks use the same loop.
 // ----------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(64) sdp_traceback_kernel(const float *grad, int *states, int *counts,
                                                                       const int *lens, int B, int N, int M, int cap)
 {
-    const int b = blockIdx.x * 64 + threadIdx.x;
+    constexpr int TW = SDP_TB_WINDOW, TWL = TW == 64 ? 6 : 5;   // window edge (32 or 64 cells)
+    __shared__ float tile[TW * TW];
+    const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= B) return;
     int n = N, m = M;
     if (lens) {
-        n = lens[2 * b];
-        m = lens[2 * b + 1];
+        n = __builtin_amdgcn_readfirstlane(lens[2 * b]);
+        m = __builtin_amdgcn_readfirstlane(lens[2 * b + 1]);
         n = n < 1 ? 1 : (n > N ? N : n);
         m = m < 1 ? 1 : (m > M ? M : m);
     }
     const float *g = grad + (size_t)b * N * M;
     int *out = states + (size_t)b * cap * 3;
     const float floor_v = -100000.f;
-    auto at = [&](int i, int j, bool &bad) -> float {  // python indexing into the (n, m) block
-        if (i < 0) i += n;
-        if (j < 0) j += m;
-        if (i < 0 || i >= n || j < 0 || j >= m) {
-            bad = true;
-            return 0.f;
-        }
-        return g[(size_t)i * M + j];
-    };
-    int i = n - 1, j = m - 1, cnt = 0;
+    // A walk has at most n + m - 1 steps: every step lowers i or j, a step that lowers only i needs i > 0, and j never
+    // goes below 0.  The API passes cap = N + M + 2.
+    if (cap < n + m) {
+        if (lane == 0) counts[b] = -1;
+        return;
+    }
     bool bad = false;
-    out[0] = i, out[1] = j, out[2] = 1;
-    cnt = 1;
-    while (!bad) {
-        const float left = i <= 0 ? floor_v : at(i - 1, j, bad);
-        const float diag = (i <= 0 && j <= 0) ? floor_v : at(i - 1, j - 1, bad);
-        const float upper = j <= 0 ? floor_v : at(i, j - 1, bad);
-        if (bad || (left == floor_v && diag == floor_v && upper == floor_v)) break;
-        int best = 0;
-        float bv = left;
-        if (diag > bv) best = 1, bv = diag;
-        if (upper > bv) best = 2, bv = upper;
-        if (best == 0) i -= 1;
-        else if (best == 1) i -= 1, j -= 1;
-        else j -= 1;
-        if (cnt >= cap) {
-            bad = true;
-            break;
+    // every value the walk branches on is the same in all 64 lanes, but a load (LDS or global) is a divergent source to
+    // the compiler: these keep the control flow scalar
+    auto uni = [](float v) -> float { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+    auto all = [](bool c) -> bool { return __builtin_amdgcn_ballot_w64(c) != 0; };   // c is uniform: any lane == all lanes
+    // Steps are recorded as their state only, one per lane; a step moves by (state != 2, state != 0), so the positions
+    // of a group of 64 follow from the position before the group and two prefix counts (the first record, state 1 at
+    // (n-1, m-1), is "a diagonal step from (n, m)").  Groups go to the END of the pair's buffer, last step first.
+    int cnt = 0, my_s = 0;
+    int base_i = n, base_j = m;   // position before the first step of the current group
+    auto flush = [&](int first, int count, int now_i, int now_j) {  // steps first .. first+count-1 -> positions cap-1-step
+        const bool mine = lane < count;
+        const unsigned long long mi = __builtin_amdgcn_ballot_w64(mine && my_s != 2), mj = __builtin_amdgcn_ballot_w64(mine && my_s != 0);
+        const int pi = __builtin_amdgcn_mbcnt_hi((unsigned)(mi >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mi, 0)) + (int)((mi >> lane) & 1);
+        const int pj = __builtin_amdgcn_mbcnt_hi((unsigned)(mj >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mj, 0)) + (int)((mj >> lane) & 1);
+        if (mine) {
+            int *o = out + 3 * (size_t)(cap - 1 - (first + lane));
+            o[0] = base_i - pi, o[1] = base_j - pj, o[2] = my_s;
         }
-        out[3 * cnt] = i, out[3 * cnt + 1] = j, out[3 * cnt + 2] = best;
+        base_i = now_i, base_j = now_j;
+    };
+    auto record = [&](int st, int now_i, int now_j) {  // now = the position after this step
+        if (lane == (cnt & 63)) my_s = st;
         ++cnt;
+        if ((cnt & 63) == 0) flush(cnt - 64, 64, now_i, now_j);
+    };
+
+    // The walk in "virtual" coordinates: i and j only decrease and may go below 0, where python's indexing wraps them
+    // to the other edge (nw.py:423 reads grad[i-1, j-1] with i = 0 or j = 0) -- at most once (below -n / -m the
+    // reference raises IndexError: bad).  left is off the matrix for i <= 0, upper for j <= 0, all three for both.
+    // The window is filled through the same wrap, so one loop serves the interior, the edges and the wrapped walk.
+    int i = n - 1, j = m - 1;
+    record(1, i, j);
+    while (true) {
+        if (i <= 0 && j <= 0) break;   // all three are the floor value: the reference's stop rule
+        const int r0 = i - (TW - 1), c0 = j - (TW - 1);
+        __syncthreads();  // one wave: orders the LDS reads of the old window before these writes
+        {
+            float v[TW * TW / 64];
+            int vj = c0 + (lane & (TW - 1));
+            vj += vj < 0 ? m : 0;
+            const bool okj = vj >= 0;
+#pragma unroll
+            for (int k = 0; k < TW * TW / 64; ++k) {
+                int vi = r0 + (lane >> TWL) + (64 / TW) * k;
+                vi += vi < 0 ? n : 0;
+                // rows / columns below -n / -m are never read (see `bad` below): clamped address, so that all loads
+                // are in flight together
+                v[k] = __builtin_nontemporal_load(g + (size_t)max(vi, 0) * M + (okj ? vj : 0));
+            }
+#pragma unroll
+            for (int k = 0; k < TW * TW / 64; ++k) tile[((lane >> TWL) + (64 / TW) * k) * TW + (lane & (TW - 1))] = v[k];
+        }
+        __syncthreads();
+        int ti = TW - 1, tj = TW - 1;   // the current cell; the walk stays in the window while both are >= 1
+        bool stop = false;
+        if (r0 >= 0 && c0 >= 0) {
+            // ---- the whole window is inside the matrix: no floor values, no wrap ----
+            while (ti >= 1 && tj >= 1) {
+                const float *p = tile + ti * TW + tj;
+                const float left = p[-TW], diag = p[-TW - 1], upper = p[-1];
+                const bool c1 = all(diag > left);
+                const float bv1 = c1 ? diag : left;
+                const bool c2 = all(upper > bv1);
+                const float bv = c2 ? upper : bv1;
+                if (all(bv == floor_v)) {   // only then can all three be the floor value
+                    if (all(left == floor_v && diag == floor_v && upper == floor_v)) {
+                        stop = true;
+                        break;
+                    }
+                }
+                ti -= c2 ? 0 : 1;
+                tj -= (c1 || c2) ? 1 : 0;
+                record(c2 ? 2 : (c1 ? 1 : 0), r0 + ti, c0 + tj);
+            }
+        } else {
+            while (ti >= 1 && tj >= 1) {
+                const int vi = r0 + ti, vj = c0 + tj;
+                const bool fl = vi <= 0, fu = vj <= 0;
+                if (fl && fu) {
+                    stop = true;
+                    break;
+                }
+                if (vi - 1 < -n || vj - 1 < -m) {   // the diagonal read would wrap twice: IndexError in the reference
+                    bad = true;
+                    break;
+                }
+                const float *p = tile + ti * TW + tj;
+                const float t0 = p[-TW], t1 = p[-TW - 1], t2 = p[-1];
+                const float left = fl ? floor_v : uni(t0), diag = uni(t1), upper = fu ? floor_v : uni(t2);
+                if (left == floor_v && diag == floor_v && upper == floor_v) {
+                    stop = true;
+                    break;
+                }
+                int best = 0;
+                float bv = left;
+                if (diag > bv) best = 1, bv = diag;
+                if (upper > bv) best = 2, bv = upper;
+                ti -= best == 2 ? 0 : 1;
+                tj -= best == 0 ? 0 : 1;
+                record(best, r0 + ti, c0 + tj);
+            }
+        }
+        i = r0 + ti, j = c0 + tj;
+        if (stop || bad) break;
     }
     while (!bad && i > 0) {
         i -= 1;
-        if (cnt >= cap) { bad = true; break; }
-        out[3 * cnt] = i, out[3 * cnt + 1] = j, out[3 * cnt + 2] = 0;
-        ++cnt;
+        record(0, i, j);
     }
     while (!bad && j > 0) {
         j -= 1;
-        if (cnt >= cap) { bad = true; break; }
-        out[3 * cnt] = i, out[3 * cnt + 1] = j, out[3 * cnt + 2] = 2;
-        ++cnt;
+        record(2, i, j);
     }
     if (bad) {
-        counts[b] = -1;
+        if (lane == 0) counts[b] = -1;
         return;
     }
-    for (int a = 0, z = cnt - 1; a < z; ++a, --z) {  // the reference returns the walk reversed
-        for (int q = 0; q < 3; ++q) {
-            const int tmp = out[3 * a + q];
-            out[3 * a + q] = out[3 * z + q];
-            out[3 * z + q] = tmp;
+    flush(cnt & ~63, cnt & 63, i, j);
+    // the wave reads back what its own lanes stored: workgroup scope is enough (an agent-scope fence writes back and
+    // invalidates the L2 on this chip -- tens of microseconds each)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    // steps sit reversed at out[cap-cnt .. cap): move them to the front (ascending groups of 64 never write where a
+    // later group still has to read: the source is always at or above the destination)
+    const int shift = cap - cnt;
+    if (shift > 0) {
+        for (int k0 = 0; k0 < cnt; k0 += 64) {
+            const int k = k0 + lane;
+            int v0 = 0, v1 = 0, v2 = 0;
+            if (k < cnt) {
+                const int *src = out + 3 * (size_t)(shift + k);
+                v0 = __builtin_nontemporal_load(src), v1 = __builtin_nontemporal_load(src + 1), v2 = __builtin_nontemporal_load(src + 2);
+            }
+            __syncthreads();
+            if (k < cnt) {
+                int *dst = out + 3 * (size_t)k;
+                dst[0] = v0, dst[1] = v1, dst[2] = v2;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         }
     }
-    counts[b] = cnt;
+    if (lane == 0) counts[b] = cnt;
 }
 
 // ----------------------------------------------------------------------------------

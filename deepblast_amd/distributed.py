@@ -114,7 +114,10 @@ class ShardedAligner:
     """Align this rank's shard and collect results from all ranks.
 
     decoder : NeedlemanWunschDecoder / SmithWatermanDecoder
-    gather  : "vt" (default) collect terminal scores only; "e" also collect E; "none" nothing.
+    gather  : "vt" (default) collect terminal scores only; "e" also collect E; "paths" also collect the
+              tracebacks of E -- the device walk (sdp_traceback_i32) on each rank's own E, one int32 per step
+              (i, j, state packed), (N+M+2) x 4 bytes per pair instead of N x M x 4: 130x less than E at 512 x 512,
+              so the gather all but disappears ("compact tracebacks"); "none" nothing.
               Gathering E moves (G-1) x B/G x N x M x 4 bytes INTO every GPU over xGMI -- at
               B/G=256, N=M=512 that is 1.9 GB per rank and takes several times longer than
               computing it, so it is opt-in.
@@ -124,8 +127,8 @@ class ShardedAligner:
     """
 
     def __init__(self, decoder, group=None, gather="vt", async_e=False):
-        if gather not in ("vt", "e", "none"):
-            raise ValueError("gather must be 'vt', 'e' or 'none'")
+        if gather not in ("vt", "e", "paths", "none"):
+            raise ValueError("gather must be 'vt', 'e', 'paths' or 'none'")
         self.decoder = decoder
         self.group = group
         self.gather = gather
@@ -143,7 +146,9 @@ class ShardedAligner:
         plan    : a BalancedPlan; theta/A/lengths are then this rank's `plan.indices(rank)` pairs (in that order),
                   and the gathered results come back in the ORIGINAL batch order.
 
-        -> dict(Vt_local, E_local, Vt (B,) or None, E (B,N,M) | PendingGather | None)."""
+        -> dict(Vt_local, E_local, Vt (B,) or None, E (B,N,M) | PendingGather | None,
+                paths (gather="paths"): (states (B, N+M+2, 3) int32, counts (B,) int32) as Decoder.traceback_batch
+                reads them -- pair b's walk is states[b, :counts[b]]; counts < 0: the walk left the matrix)."""
         n_real = theta.shape[0]
         if plan is not None:
             if lengths is None:
@@ -162,13 +167,49 @@ class ShardedAligner:
             # backward sweep computes E
             pending = _all_gather_cat(Vt.detach(), self.group, async_op=True)
         (E,) = torch.autograd.grad(Vt, theta, grad_outputs=self._ones)
-        out = {"Vt_local": Vt.detach()[:n_real], "E_local": E[:n_real], "Vt": None, "E": None}
+        out = {"Vt_local": Vt.detach()[:n_real], "E_local": E[:n_real], "Vt": None, "E": None, "paths": None}
         if gathering:
+            if self.gather == "paths":
+                from . import _engine
+                states, counts = _engine.get_engine().traceback(E, lengths)
+                packed = pack_paths(states, counts, theta.shape[2])
+                got = PendingGather(*_all_gather_cat(packed, self.group, async_op=True), plan=plan)
             out["Vt"] = PendingGather(*pending, plan=plan).wait()
+            if self.gather == "paths":
+                out["paths"] = unpack_paths(got.wait())
             if self.gather == "e":
                 e_pending = PendingGather(*_all_gather_cat(E, self.group, async_op=True), plan=plan)
                 out["E"] = e_pending if self.async_e else e_pending.wait()
         return out
+
+
+# One traceback step in one int32 for the gather: state in bits 0-1, j above it in ceil(log2 M) bits, i in the rest
+# (31 - 2 - 12 = 17 bits at M = 2048, and N * M <= 2^28 keeps N within them).  Two header columns carry the
+# pair's step count (negative: the walk left the matrix) and the width of the j field.
+def _j_bits(M):
+    return max(1, int(M - 1).bit_length())
+
+
+def pack_paths(states, counts, M):
+    """(B, cap, 3) int32 triples + (B,) counts -> (B, cap + 2) int32."""
+    jb = _j_bits(M)
+    s = states.to(torch.int64)
+    valid = torch.arange(s.shape[1], device=s.device)[None, :] < counts.to(torch.int64)[:, None]
+    s = torch.where(valid[..., None], s, torch.zeros_like(s))   # rows past the count are uninitialised memory
+    if s.numel() and int(s[..., 0].max()) >= 1 << (31 - jb - 2):
+        raise ValueError("traceback row index does not fit the packed word")
+    word = (s[..., 0] << (jb + 2)) | (s[..., 1] << 2) | s[..., 2]
+    head = torch.stack([counts.to(torch.int64), torch.full_like(counts, jb, dtype=torch.int64)], dim=1)
+    return torch.cat([head, word], dim=1).to(torch.int32)
+
+
+def unpack_paths(packed):
+    """Inverse of pack_paths -> (states (B, cap, 3) int32, counts (B,) int32)."""
+    counts = packed[:, 0].contiguous()
+    jb = int(packed[0, 1]) if packed.shape[0] else 1
+    word = packed[:, 2:].to(torch.int64)
+    states = torch.stack([word >> (jb + 2), (word >> 2) & ((1 << jb) - 1), word & 3], dim=2).to(torch.int32)
+    return states, counts
 
 
 def pad_shard(theta, A, lengths, count):

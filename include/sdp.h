@@ -131,7 +131,8 @@ int sdp_scores_f32(const float *zx, const float *zy, const float *gx, const floa
 /* Batched traceback (reference: Decoder.traceback, deepblast/nw.py:401-444, called once per pair by
  * NeuralAligner.traceback, alignment.py:165-170).  grad is (B,N,M); states receives, per pair, up to
  * sdp_traceback_capacity(N,M) triples (i, j, state) in the reference's order (start of the alignment first),
- * counts[b] the number of triples, or -1 where the reference's walk would raise IndexError. */
+ * counts[b] the number of triples, or -1 where the reference's walk would raise IndexError.  Rows of `states`
+ * past counts[b] are left as they were (scratch). */
 int sdp_traceback_capacity(int N, int M);
 int sdp_traceback_i32(const float *grad, int32_t *states, int32_t *counts, int B, int N, int M,
                       const int32_t *lens, int device, void *stream);

@@ -81,3 +81,21 @@ class OracleEngine:
             ed = oracle.adjoint_backward(e, q, qd)
             Ed[b, :n, :m] = ed[0, 1:-1, 1:-1]
         return torch.from_numpy(Ed)
+
+    def traceback(self, grad, lens=None):
+        """Per-pair host walks (deepblast_amd/_dp.py::traceback) in the device kernel's output format."""
+        from deepblast_amd._dp import traceback
+        g = self._np(grad)
+        B, N, M = g.shape
+        cap = N + M + 2
+        states = np.zeros((B, cap, 3), np.int32)
+        counts = np.zeros(B, np.int32)
+        for b, (n, m) in enumerate(self._slices(B, N, M, lens)):
+            try:
+                path = traceback(g[b, :n, :m])
+            except IndexError:
+                counts[b] = -1
+                continue
+            counts[b] = len(path)
+            states[b, :len(path)] = np.asarray(path, np.int32)
+        return torch.from_numpy(states), torch.from_numpy(counts)

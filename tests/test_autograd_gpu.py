@@ -140,7 +140,7 @@ def test_padded_batch_reference_semantics_and_lengths_extension():
 
 
 def test_batched_device_traceback_matches_host(golden_dir):
-    """sdp_traceback_i32 (one pair per lane) is integer-identical to the per-pair host walk
+    """sdp_traceback_i32 (one wavefront per pair) is integer-identical to the per-pair host walk
     (nw.py:401-444), on real expected-alignment matrices, with per-pair lengths, and on the reference's
     traceback fixtures including the walks that raise IndexError."""
     import time
@@ -200,3 +200,39 @@ def test_batched_device_traceback_matches_host(golden_dir):
     for b in range(8):
         assert [tuple(r) for r in st[b, :ct[b]].tolist()] == host[b]
     print(f"traceback B={B} {N}x{M}: device {t_dev * 1e3:.2f} ms, host loop (extrapolated) {t_host * 1e3:.0f} ms")
+
+
+def test_device_traceback_on_arbitrary_matrices_matches_host_walk():
+    """The windowed walk against the host walk on matrices that are NOT alignment matrices: random values send the walk
+    along edges, through python's index wrap (nw.py:423) and off the matrix (IndexError -> count -1); entries equal to
+    the reference's floor value (-100000) trigger its stop rule anywhere.  Shapes around the 32-cell window."""
+    import torch
+    from deepblast_amd._dp import traceback as host_traceback
+    from deepblast_amd._engine import get_engine
+    rng = np.random.default_rng(11)
+    shapes = [(1, 1), (1, 9), (9, 1), (2, 2), (31, 33), (32, 32), (33, 31), (64, 65), (5, 200), (200, 5), (150, 97), (70, 300)]
+    n_bad = n_wrap = 0
+    for (N, M) in shapes:
+        B = 24
+        g = rng.normal(size=(B, N, M)).astype(np.float32)
+        g[B // 3: 2 * B // 3] = np.abs(g[B // 3: 2 * B // 3])                      # positive: no early stop
+        g[2 * B // 3:][rng.random((B - 2 * B // 3, N, M)) < 0.3] = -100000.0        # floor values inside the matrix
+        for b in range(0, B, 4):                                                     # a bright diagonal band: long interior walks
+            for k in range(min(N, M)):
+                g[b, N - 1 - k, M - 1 - k] += 5.0
+        lens = np.stack([rng.integers(1, N + 1, B), rng.integers(1, M + 1, B)], axis=1).astype(np.int32)
+        for ln in (None, lens):
+            states, counts = get_engine().traceback(torch.from_numpy(g).cuda(), None if ln is None else torch.from_numpy(ln).cuda())
+            states, counts = states.cpu().numpy(), counts.cpu().numpy()
+            for b in range(B):
+                n, m = (N, M) if ln is None else ln[b]
+                try:
+                    want = host_traceback(g[b, :n, :m])
+                except IndexError:
+                    assert counts[b] == -1, (N, M, b)
+                    n_bad += 1
+                    continue
+                assert counts[b] == len(want), (N, M, b, counts[b], len(want))
+                assert [tuple(int(v) for v in r) for r in states[b, :counts[b]]] == want, (N, M, b)
+                n_wrap += any(i < 0 or j < 0 for i, j, _ in want)
+    assert n_bad > 0 and n_wrap > 0, (n_bad, n_wrap)   # the fuzz reaches both quirks

@@ -107,6 +107,66 @@ def test_balanced_plan_world2_restores_batch_order(tmp_path):
     assert sorted(seen) == list(range(7))
 
 
+def _worker_paths(rank, world, port, outdir):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deepblast_amd import _engine, NeedlemanWunschDecoder
+    from deepblast_amd.distributed import BalancedPlan, ShardedAligner
+    from fake_engine import OracleEngine
+    _engine._ENGINE = OracleEngine()
+    B, N, M = 7, 30, 26
+    theta, A = datagen.theta_A(45, B, N, M)
+    theta = (theta * 6).astype(np.float32)   # peaked alignments: the walk follows a real path
+    lens = datagen.lengths(46, B, 3, 26)
+    plan = BalancedPlan(lens, world)
+    mine = plan.indices(rank)
+    al = ShardedAligner(NeedlemanWunschDecoder("softmax"), gather="paths")
+    out = al.align(torch.from_numpy(theta[mine]), torch.from_numpy(A[mine]), torch.from_numpy(lens[mine]), plan=plan)
+    states, counts = out["paths"]
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), states=states.numpy(), counts=counts.numpy(), Vt=out["Vt"].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gathered_paths_world2_match_per_pair_tracebacks(tmp_path):
+    """gather="paths": every rank ends up with the traceback of every pair, in batch order, equal to the reference's
+    per-item decode + traceback (alignment.py:165-170) -- (N+M+2) int32 per pair over the wire instead of N x M floats."""
+    import parity
+    from deepblast_amd._dp import traceback
+    world = 2
+    mp.spawn(_worker_paths, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    theta, A = datagen.theta_A(45, 7, 30, 26)
+    theta = (theta * 6).astype(np.float32)
+    lens = datagen.lengths(46, 7, 3, 26)
+    ref = parity.oracle_lens(theta, A, None, None, 0, lens)
+    for r in range(world):
+        d = np.load(tmp_path / f"r{r}.npz")
+        assert d["states"].shape == (7, 30 + 26 + 2, 3) and np.array_equal(d["Vt"], ref["Vt"])
+        for b in range(7):
+            n, m = lens[b]
+            want = traceback(ref["E"][b, :n, :m])
+            assert d["counts"][b] == len(want)
+            assert [tuple(int(v) for v in row) for row in d["states"][b, :len(want)]] == want
+
+
+def test_pack_paths_round_trip_at_the_largest_shapes():
+    from deepblast_amd.distributed import pack_paths, unpack_paths
+    rng = np.random.default_rng(5)
+    for N, M in ((131072, 2048), (7, 1), (1, 1), (513, 512)):
+        cap = 40
+        states = np.stack([rng.integers(0, N, (3, cap)), rng.integers(0, M, (3, cap)), rng.integers(0, 3, (3, cap))], axis=2).astype(np.int32)
+        counts = np.array([cap, 5, -1], np.int32)
+        s2, c2 = unpack_paths(pack_paths(torch.from_numpy(states), torch.from_numpy(counts), M))
+        assert np.array_equal(c2.numpy(), counts)
+        assert np.array_equal(s2.numpy()[0], states[0]) and np.array_equal(s2.numpy()[1, :5], states[1, :5])
+        assert not s2.numpy()[2].any() and not s2.numpy()[1, 5:].any()   # rows past the count are zeroed
+
+
 def test_balanced_plan_balances_work():
     from deepblast_amd.distributed import BalancedPlan
     lens = datagen.lengths(2, 2048, 64, 1024)

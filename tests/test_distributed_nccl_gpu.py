@@ -81,6 +81,68 @@ def test_sharded_align_two_ranks_rccl(tmp_path, mode):
         assert parity.abs_err(d["E"], ref["E"]) <= parity.TOL
 
 
+def _worker_paths(rank, world, port, backend, outdir):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    idx = rank if backend == "nccl" else 0   # gloo: both ranks share GPU 0 (what a 1-GPU box can check)
+    torch.cuda.set_device(idx)
+    dev = torch.device("cuda", idx)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deepblast_amd import NeedlemanWunschDecoder
+    from deepblast_amd.distributed import BalancedPlan, ShardedAligner
+    B, N, M = 9, 150, 130
+    theta, A = datagen.theta_A(47, B, N, M)
+    theta = (theta * 6).astype(np.float32)
+    lens = datagen.lengths(48, B, 5, 130)
+    plan = BalancedPlan(lens, world)
+    mine = plan.indices(rank)
+    al = ShardedAligner(NeedlemanWunschDecoder("softmax"), gather="paths")
+    out = al.align(torch.from_numpy(theta[mine]).to(dev), torch.from_numpy(A[mine]).to(dev),
+                   torch.from_numpy(lens[mine]).to(dev), plan=plan)
+    states, counts = out["paths"]
+    torch.cuda.synchronize()
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), states=states.cpu().numpy(), counts=counts.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _check_paths(tmp_path, world):
+    import parity
+    from deepblast_amd._dp import traceback
+    theta, A = datagen.theta_A(47, 9, 150, 130)
+    theta = (theta * 6).astype(np.float32)
+    lens = datagen.lengths(48, 9, 5, 130)
+    ref = parity.oracle_lens(theta, A, None, None, 0, lens)
+    for r in range(world):
+        d = np.load(tmp_path / f"r{r}.npz")
+        for b in range(9):
+            n, m = lens[b]
+            want = traceback(ref["E"][b, :n, :m])
+            assert d["counts"][b] == len(want), (r, b)
+            assert [tuple(int(v) for v in row) for row in d["states"][b, :len(want)]] == want, (r, b)
+
+
+def test_gathered_paths_two_ranks_share_one_gpu(tmp_path):
+    """gather="paths" with the HIP engine and the device traceback kernel, two ranks on GPU 0 over gloo: every rank holds
+    every pair's traceback, in batch order, equal to the per-pair host walk over the oracle's E."""
+    mp.spawn(_worker_paths, args=(2, _free_port(), "gloo", str(tmp_path)), nprocs=2, join=True)
+    _check_paths(tmp_path, 2)
+
+
+@needs2
+def test_gathered_paths_two_ranks_rccl(tmp_path):
+    mp.spawn(_worker_paths, args=(2, _free_port(), "nccl", str(tmp_path)), nprocs=2, join=True)
+    _check_paths(tmp_path, 2)
+
+
 def test_bench_refuses_more_gpus_than_present():
     """`python bench.py --gpus N` creates its own ranks and must fail loudly -- not time fewer GPUs -- when the node
     has fewer than N devices."""
@@ -113,4 +175,5 @@ def test_bench_two_ranks_flow_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["global_batch"] == 48 and d["config"]["gather"] == "vt"
     assert d["value"] > 0 and d["with_e_gather"]["value"] > 0 and "cpu_baseline" not in d
+    assert d["with_paths_gather"]["value"] > 0 and d["with_paths_gather"]["bytes_into_each_gpu"] < d["with_e_gather"]["bytes_into_each_gpu"] / 50
     assert d["scaling"] == "weak" and "test mode" in d["config"]["backend"]

@@ -1,4 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error|Error|assert" | tail -8
-for i in 1 2 3 4; do python bench.py --steps 100 --warmup 10 2>/dev/null | tail -1 | cut -c1-150; done
+timeout 900 python -m pytest tests/test_distributed_nccl_gpu.py tests/test_autograd_gpu.py -m gpu -x -q < /dev/null 2>&1 | tail -4
+timeout 300 python bench.py --mode align+traceback --steps 50 --warmup 5 --no-cpu-baseline < /dev/null 2>/dev/null | tail -1 | python -c "
+import sys, json; d = json.loads(sys.stdin.read()); print(d['metric'], d['value'], d['ms_per_step'], d.get('traceback_ms'))"
