@@ -10,7 +10,8 @@ MODE = sys.argv[3] if len(sys.argv) > 3 else "mixed"   # "full": only full batch
 REPORT = float(os.environ.get("FUZZ_REPORT", "1"))   # also list cases above this error (to see which regime is closest to the bound)
 rng = np.random.default_rng(seed)
 worst1 = worst2 = 0.0
-nf1 = nf2 = 0
+nf1 = nf2 = nref = 0   # nref: second-order cases over the bound where the engine matches the float64 reference to 2e-5 and
+                       # the fp32 reference is off by the same amount from its own float64 run
 for it in range(n):
     kind = rng.integers(0, 5) if MODE == "mixed" else 9
     if kind == 9: B, N, M = int(rng.integers(128, 200)), int(rng.integers(40, 400)), int(rng.integers(40, 400))   # full batches: throughput builds
@@ -45,4 +46,15 @@ for it in range(n):
     if e1 > parity.TOL or e2 > parity.TOL or max(e1, e2) > REPORT:
         nf1 += e1 > parity.TOL; nf2 += e2 > parity.TOL
         print(f"it={it} {(B, N, M, variant, use_lens)} theta*{ts} A*{as_}+{ao}: " + " ".join(f"{k}={v:.2e}" for k, v in e.items()), flush=True)
-print(f"{n} cases: first-order worst {worst1:.3e} ({nf1} over 1e-4), second-order worst {worst2:.3e} ({nf2} over 1e-4)")
+        if e2 > parity.TOL and not use_lens:
+            # second order over the bound: is it the engine, or the reference's own fp32 rounding?  The same
+            # case against the oracle in float64, and the oracle's fp32 run against its float64 run
+            f8 = lambda x: None if x is None else x.astype(np.float64)
+            r64 = parity.oracle_all(f8(theta), f8(A), f8(Et), f8(Z), variant, ZA=f8(ZA))
+            e64, noise = parity.compare(got, r64), parity.compare(ref, r64)
+            print("      engine vs float64 reference: " + " ".join(f"{k}={v:.2e}" for k, v in e64.items() if k in ("Ed", "Vtd")) +
+                  "   fp32 vs float64 reference: " + " ".join(f"{k}={v:.2e}" for k, v in noise.items() if k in ("Ed", "Vtd")), flush=True)
+            if max(e64["Ed"], e64["Vtd"]) <= 0.2 * parity.TOL and max(noise["Ed"], noise["Vtd"]) >= 0.9 * e2:
+                nf2 -= 1; nref += 1
+print(f"{n} cases: first-order worst {worst1:.3e} ({nf1} over 1e-4), second-order worst {worst2:.3e} ({nf2} over 1e-4"
+      + (f"; {nref} more where the fp32 reference itself is off by that much from float64 and the engine is within 2e-5 of float64" if nref else "") + ")")
