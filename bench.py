@@ -262,20 +262,26 @@ def main():
     # N > 1: the same job with the expected-alignment matrices gathered as well (report scaling with
     # and without the E gather); a secondary figure, never `value`
     e_gather = None
-    if world > 1 and args.mode == "fwdbwd" and args.gather != "e":
-        aligner.gather = "e"
-        step()
-        dt_e, _ = timed(min(args.steps, 5))
-        aligner.gather = args.gather
-        e_gather = dt_e / min(args.steps, 5)
-    # ... and with the tracebacks gathered instead (device walk + (N+M+2) int32 per pair over the wire)
+    # (a secondary figure must not cost the primary one: an error here -- the same on every rank, e.g. out of memory for
+    # the gathered E -- is reported on stderr and the line goes out without that field)
+    def secondary(kind):
+        try:
+            aligner.gather = kind
+            step()
+            dt_s, _ = timed(min(args.steps, 5))
+            return dt_s / min(args.steps, 5)
+        except Exception as ex:   # noqa: BLE001
+            print(f"[bench] rank {rank}: secondary measurement gather={kind!r} failed: {ex}", file=sys.stderr, flush=True)
+            return None
+        finally:
+            aligner.gather = args.gather
+
+    if world > 1 and args.mode == "fwdbwd" and args.gather != "e" and not os.environ.get("BENCH_NO_SECONDARY"):
+        e_gather = secondary("e")
+    # ... and with the tracebacks gathered instead (device walk + (N+M+4) int32 per pair over the wire)
     paths_gather = None
-    if world > 1 and args.mode == "fwdbwd" and args.gather != "paths":
-        aligner.gather = "paths"
-        step()
-        dt_p, _ = timed(min(args.steps, 5))
-        aligner.gather = args.gather
-        paths_gather = dt_p / min(args.steps, 5)
+    if world > 1 and args.mode == "fwdbwd" and args.gather != "paths" and not os.environ.get("BENCH_NO_SECONDARY"):
+        paths_gather = secondary("paths")
 
     cells = B * N * M if args.variant == "nw" else B * (N - 1) * (M - 1)
     per_step_updates = (4 if args.mode.startswith("train") else 2) * cells

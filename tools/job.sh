@@ -1,3 +1,3 @@
 #!/bin/bash
-mkdir -p gpurun_out/round_r02; export TMPDIR=/tmp
-timeout 1200 python tools/fuzz2.py 300 < /dev/null 2>&1 | grep -v amdgpu.ids | tail -4 | tee gpurun_out/round_r02/fuzz2.txt
+mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_distributed_nccl_gpu.py -m gpu -x -q < /dev/null 2>&1 | tail -3
