@@ -177,6 +177,21 @@ def test_long_steep_problems_keep_first_order_parity(case):
     assert errs["E"] <= 2e-5, errs
 
 
+def test_long_problems_with_lengths_and_launch_order():
+    """N + M > 4096 (exact state chosen by the library) together with per-pair lengths on more pairs than CUs (the
+    launch order lives in the tail of the state buffer, whose offset depends on the state format): all four passes."""
+    B, N, M = 260, 4100, 24
+    theta, A = datagen.theta_A(85000, B, N, M)
+    theta = (theta * 4.0).astype(np.float32)
+    Z = datagen.normal(85001, (B, N, M))
+    lens = datagen.lengths(85002, B, 1, 4100)
+    lens[:, 1] = np.minimum(lens[:, 1], M)
+    lens[0] = (N, M)
+    ref = parity.oracle_lens(theta, A, None, Z, 0, lens)
+    got = parity.engine_all(theta, A, None, Z, 0, lens=lens)
+    _assert(parity.compare(got, ref), "long + lengths")
+
+
 def test_where_the_fp32_reference_is_the_noisy_one():
     """2048 x 2048 Smith-Waterman, theta x30, A x10: Ed differs from the reference's fp32 result by 2e-4 -- and from the
     reference run in float64 by 1e-6.  The reference forms the Hessian product and the Qd*E products in the storage

@@ -1,3 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 300 python tools/waves_probe.py < /dev/null 2>&1 | grep -v amdgpu.ids | tail -16
+timeout 900 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k "long" < /dev/null 2>&1 | tail -6
