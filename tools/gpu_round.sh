@@ -15,7 +15,7 @@ if [ "$2" != "quick" ]; then
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee $OUT/smoke.txt
   # the harsher fuzz (steep / flat scores, forbidden gaps, tiny and thin shapes, many pairs, per-pair lengths): the
   # suite did not catch the one kernel bug of round 2, this did
-  timeout 900 python tools/fuzz2.py 300 2>&1 | tail -3 | tee $OUT/fuzz2.txt
+  timeout 900 python tools/fuzz2.py 300 2>&1 | tail -4 | tee $OUT/fuzz2.txt
 fi
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o fwdbwd -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/rocprof.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o train -- python bench.py --steps 10 --warmup 2 --mode train --no-cpu-baseline > $OUT/bench_prof_train.json 2>> $OUT/rocprof.err
