@@ -1,5 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 600 python tools/ab.py 256x512x512 adj < /dev/null 2>&1 | grep -v amdgpu.ids | tail -4
-SDP_LIB_PATH=$PWD/build_variants/libsdp_abwd32.so FUZZ_REPORT=4e-5 timeout 900 python tools/fuzz2.py 150 4242 < /dev/null 2>&1 | grep -v amdgpu.ids | tail -6
-SDP_LIB_PATH=$PWD/build_variants/libsdp_abwd32.so timeout 600 python tools/steep_probe.py < /dev/null 2>&1 | grep -A2 "^(" | grep -v "^--" | head -20
+( echo "== tools/fuzz2.py 1000 2026 (mixed)"; FUZZ_REPORT=6e-5 timeout 2400 python tools/fuzz2.py 1000 2026 < /dev/null 2>&1 | grep -v amdgpu.ids | tail -12
+  echo "== tools/fuzz2.py 250 5 full (full batches of mid-size odd shapes)"; FUZZ_REPORT=6e-5 timeout 1500 python tools/fuzz2.py 250 5 full < /dev/null 2>&1 | grep -v amdgpu.ids | tail -8 ) | tee gpurun_out/fuzz_extended.txt | tail -24
