@@ -181,7 +181,7 @@ class _Decoder(nn.Module):
         return traceback(grad)
 
     def traceback_batch(self, grad, lengths=None):
-        """Extension: the same walk for a whole (B, N, M) batch on the device, one pair per lane,
+        """Extension: the same walk for a whole (B, N, M) batch on the device, one wavefront per pair,
         instead of one host walk per pair (alignment.py:165-170).  -> list of B lists of (i, j, state);
         raises IndexError if any walk leaves its matrix, like the per-pair version."""
         states, counts = _engine.get_engine().traceback(grad, lengths)
