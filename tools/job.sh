@@ -1,4 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-( echo "== tools/fuzz2.py 1000 2026 (mixed)"; FUZZ_REPORT=6e-5 timeout 2400 python tools/fuzz2.py 1000 2026 < /dev/null 2>&1 | grep -v amdgpu.ids | tail -12
-  echo "== tools/fuzz2.py 250 5 full (full batches of mid-size odd shapes)"; FUZZ_REPORT=6e-5 timeout 1500 python tools/fuzz2.py 250 5 full < /dev/null 2>&1 | grep -v amdgpu.ids | tail -8 ) | tee gpurun_out/fuzz_extended.txt | tail -24
+for i in 1 2 3; do timeout 300 python bench.py --mode train --steps 40 --warmup 5 --no-cpu-baseline < /dev/null 2>/dev/null | tail -1 | python -c "
+import sys, json; d = json.loads(sys.stdin.read()); print('%.4g' % d['value'], '%.4f ms' % d['ms_per_step'], {k: round(v, 3) for k, v in d['kernel_ms'].items()})"; done
