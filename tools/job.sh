@@ -1,4 +1,6 @@
 #!/bin/bash
-mkdir -p gpurun_out; export TMPDIR=/tmp
-for i in 1 2 3; do timeout 300 python bench.py --mode train --steps 40 --warmup 5 --no-cpu-baseline < /dev/null 2>/dev/null | tail -1 | python -c "
-import sys, json; d = json.loads(sys.stdin.read()); print('%.4g' % d['value'], '%.4f ms' % d['ms_per_step'], {k: round(v, 3) for k, v in d['kernel_ms'].items()})"; done
+OUT=gpurun_out/round_r02x; mkdir -p $OUT; export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_tb -o tb -- python bench.py --mode align+traceback --steps 10 --warmup 2 --no-cpu-baseline < /dev/null > $OUT/bench_tb.json 2> $OUT/tb.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_sc -o sc -- python bench.py --mode scores+dp --steps 10 --warmup 2 --no-cpu-baseline < /dev/null > $OUT/bench_sc.json 2> $OUT/sc.err
+for f in $(find $OUT -name "*kernel_stats.csv"); do echo "== $f"; head -5 $f | cut -c1-160; cp $f $OUT/$(basename $f); done
+tail -1 $OUT/bench_tb.json | cut -c1-200; tail -1 $OUT/bench_sc.json | cut -c1-200
