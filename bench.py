@@ -336,12 +336,22 @@ def main():
                          "launch_ms": dom_ms,
                          "whole_step_frac": (per_step_updates * ALGO_BYTES_PER_CELL_UPDATE * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9)},
         }
-        if args.mode == "scores+dp" and "sdp_scores_kernel" in ms:
+        if args.mode == "scores+dp" and ("sdp_scores_kernel" in ms or "sdp_scores_x6_kernel" in ms):
             flops = 2.0 * 2.0 * B * N * M * args.D          # two (N,D) x (D,M) products per pair
-            tf = flops / (ms["sdp_scores_kernel"] * 1e-3) / 1e12
-            line["scores_roofline"] = {"bound": "mfma", "kernel": "sdp_scores_kernel", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s",
-                                       "frac": tf / 157.3, "dtype": "f32 (v_mfma_f32_32x32x2_f32)", "D": args.D,
-                                       "launch_ms": ms["sdp_scores_kernel"], "flops_per_launch": flops}
+            if "sdp_scores_x6_kernel" in ms:
+                # three exact bf16 pieces per operand, six piece products per k: the pipe executes 6x the algorithmic
+                # flops; `achieved` / `peak` are what ran on the bf16 pipe, `algorithmic` the fp32-equivalent rate
+                t_ms = ms["sdp_scores_x6_kernel"]
+                tf = 6.0 * flops / (t_ms * 1e-3) / 1e12
+                line["scores_roofline"] = {"bound": "mfma", "kernel": "sdp_scores_x6_kernel", "achieved": tf, "peak": 2516.6, "unit": "TFLOP/s",
+                                           "frac": tf / 2516.6, "dtype": "bf16 x 6 piece products (v_mfma_f32_32x32x16_bf16), f32 accumulate",
+                                           "algorithmic": flops / (t_ms * 1e-3) / 1e12, "algorithmic_vs_f32_mfma_peak": flops / (t_ms * 1e-3) / 1e12 / 157.3,
+                                           "D": args.D, "launch_ms": t_ms, "flops_per_launch": flops}
+            else:
+                tf = flops / (ms["sdp_scores_kernel"] * 1e-3) / 1e12
+                line["scores_roofline"] = {"bound": "mfma", "kernel": "sdp_scores_kernel", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s",
+                                           "frac": tf / 157.3, "dtype": "f32 (v_mfma_f32_32x32x2_f32)", "D": args.D,
+                                           "launch_ms": ms["sdp_scores_kernel"], "flops_per_launch": flops}
         if e_gather is not None:
             line["with_e_gather"] = {"ms_per_step": e_gather * 1e3, "value": world * per_step_updates / e_gather,
                                      "bytes_into_each_gpu": (world - 1) * B * N * M * 4}

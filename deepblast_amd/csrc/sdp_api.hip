@@ -440,6 +440,15 @@ int sdp_adjoint_backward_f32(const float *E, const float *state, const float *st
     return launch(sdp::PASS_ABWD, p, device, stream, false, vb.waves);
 }
 
+static bool scores_force_f32()
+{
+#ifdef SDP_EXPERIMENTS
+    return (g_dbg.load() & 16) != 0;   // sdp_set_debug(16): the f32-input MFMA kernel for every shape (A/B timing, parity)
+#else
+    return false;
+#endif
+}
+
 int sdp_scores_f32(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
                    int M, int D, int device, void *stream)
 {
@@ -456,12 +465,21 @@ int sdp_scores_f32(const float *zx, const float *zy, const float *gx, const floa
     if (device >= 64 || !(raised >> device & 1ull)) {
         e = hipFuncSetAttribute((const void *)sdp_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sdp::SCORES_LDS_BYTES);
         if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(sdp_scores_kernel)");
+        e = hipFuncSetAttribute((const void *)sdp_scores_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sdp::SCORES_X6_LDS_BYTES);
+        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(sdp_scores_x6_kernel)");
         if (device < 64) raised |= 1ull << device;
     }
-    hipLaunchKernelGGL(sdp_scores_kernel, dim3((M + 127) / 128, (N + 127) / 128, (unsigned)nz), dim3(256), sdp::SCORES_LDS_BYTES,
-                       (hipStream_t)stream, zx, zy, gx, gy, theta, A, B, N, M, D);
+    // whole 16-deep slabs of 16-byte aligned rows: the three-piece bf16 product (sdp_scores.hip); anything else: the
+    // f32-input MFMA kernel, which takes ragged D and unaligned rows
+    auto aligned16 = [](const void *q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool x6 = D % 16 == 0 && aligned16(zx) && aligned16(zy) && aligned16(gx) && aligned16(gy) && !scores_force_f32();
+    const dim3 grid((M + 127) / 128, (N + 127) / 128, (unsigned)nz);
+    if (x6)
+        hipLaunchKernelGGL(sdp_scores_x6_kernel, grid, dim3(256), sdp::SCORES_X6_LDS_BYTES, (hipStream_t)stream, zx, zy, gx, gy, theta, A, B, N, M, D);
+    else
+        hipLaunchKernelGGL(sdp_scores_kernel, grid, dim3(256), sdp::SCORES_LDS_BYTES, (hipStream_t)stream, zx, zy, gx, gy, theta, A, B, N, M, D);
     e = hipGetLastError();
-    if (e != hipSuccess) return fail_hip(e, "sdp_scores_kernel");
+    if (e != hipSuccess) return fail_hip(e, x6 ? "sdp_scores_x6_kernel" : "sdp_scores_kernel");
     return 0;
 }
 

@@ -141,6 +141,7 @@ __host__ __device__ inline int state_tpad(int M) { return (M + 63 + 63) / 64 * 6
 #define SDP_SC_BK 16
 #endif
 constexpr int SCORES_LDS_BYTES = 2 * 2 * 128 * (SDP_SC_BK + 4) * 4;  // sdp_scores_kernel: [buffer][operand][128 rows][BK + 4 floats]
+constexpr int SCORES_X6_LDS_BYTES = 2 * 2 * 3 * 128 * 32;            // sdp_scores_x6_kernel: [buffer][operand][piece][128 rows][32 bytes]
 
 }  // namespace sdp
 
@@ -168,6 +169,8 @@ __global__ void sdp_loss_fwd_kernel(const float *ref, const float *pred, const f
 __global__ void sdp_loss_bwd_kernel(const float *ref, const float *pred, const float *G, const int *lens, const float *scale, float *grad, int N, int M, int kind);
 __global__ void sdp_scores_kernel(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
                                   int M, int D);
+__global__ void sdp_scores_x6_kernel(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
+                                     int M, int D);
 __global__ void sdp_order_kernel(const int *lens, int *order, int B, int N, int M);
 __global__ void sdp_traceback_kernel(const float *grad, int *states, int *counts, const int *lens, int B, int N, int M, int cap);
 }

@@ -13,6 +13,7 @@
 // of summation order only (<= ~1e-7 * sum|a*b|).  It runs at the fp32 vector rate (64 FLOP/clk/SIMD, 157 TFLOP/s
 // peak), 1/16 of the bf16 matrix rate; a bf16x3 split would be ~5x faster but leaves 2^-16-relative errors per
 // product -- 3e-4 absolute on theta at D = 512 -- which does not meet the 1e-4 parity bound, so it is not used.
+// (sdp_scores_x6_kernel below does use the bf16 pipe: three exact pieces per operand, six products -- fp32 accuracy.)
 //
 // Tiling: one workgroup (4 waves) per 128 x 128 tile of one (pair, tensor); a wave owns 64 x 64 = 2 x 2 MFMA
 // blocks (64 accumulator VGPRs).  Operands are staged through LDS in 32-deep K slabs (rows padded to 36 floats:
@@ -60,6 +61,35 @@ __device__ __forceinline__ float softplus_f(float x)
 __device__ __forceinline__ float logsigmoid_f(float x)
 {
     return __builtin_fminf(x, 0.0f) - log1p_exp_neg_abs(x);
+}
+
+// C/D layout of the 32x32 MFMA forms (the same for every input type on gfx950): col = lane & 31,
+// row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5).  For a fixed v the 32 lanes of a half-wave write 32 consecutive
+// columns (128 bytes) of one row.  The activation is applied here, so each output tensor is written exactly once.
+__device__ __forceinline__ void scores_epilogue(const f32x16 (&acc)[2][2], float *C, int N, int M, int i0, int j0, int wr, int wc,
+                                                int lane, int kind)
+{
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(C, 0, N * M * 4, 0x00020000);
+    // logsigmoid(x) = -softplus(-x): one branch-free formula for both tensors, y = sg * (max(sg * x, 0) + log1p(exp(-|x|)))
+    // with sg = -1 for A (a per-element `kind ? :` compiled to a branch per element)
+    const float sg = kind ? -1.0f : 1.0f;
+    const int row0 = i0 + wr + 4 * (lane >> 5);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = j0 + wc + 32 * c + (lane & 31);
+            // byte offset of (row0, col); a column outside the matrix: out of range whatever is added (N * M * 4 <= 2^30)
+            const unsigned base = col < M ? (unsigned)(row0 * M + col) * 4u : 0x80000000u;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int dr = 32 * a + (v & 3) + 8 * (v >> 2);   // compile-time row step: dr * M * 4 is one scalar product
+                const float x = acc[a][c][v];
+                const float y = sg * (__builtin_fmaxf(sg * x, 0.0f) + log1p_exp_neg_abs(x));
+                const unsigned off = row0 + dr < N ? base + (unsigned)(dr * M) * 4u : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rc, off, 0, 0);
+            }
+        }
 }
 
 }  // namespace sdp
@@ -173,21 +203,184 @@ sdp_scores_kernel(const float *zx, const float *zy, const float *gx, const float
         __syncthreads();
     }
 
-    // epilogue: C/D layout of the 32x32 forms: col = lane & 31, row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5).
-    // For a fixed v the 32 lanes of a half-wave write 32 consecutive columns (128 bytes) of one row.
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(C, 0, N * M * 4, 0x00020000);
+    scores_epilogue(acc, C, N, M, i0, j0, wr, wc, lane, kind);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// The same product on the bf16 matrix pipe, 16x the rate of the f32-input MFMA, without giving up fp32 accuracy:
+// every operand element is cut into three bf16 pieces x = x0 + x1 + x2 -- by TRUNCATION, so the cut is exact: 8 + 8 + 8
+// significant bits, residuals formed with exact fp32 subtractions -- and the product uses the six piece pairs whose
+// weight is at least 2^-16 of the leading one:
+//     x y ~= x0 y0 + (x0 y1 + x1 y0) + (x1 y1 + x0 y2 + x2 y0)
+// The three dropped pairs are below 2^-23 |x y| together (x1 y2, x2 y1 <= 2^-24 each, x2 y2 <= 2^-32) -- the size of the rounding of
+// an fp32 product -- and the accumulation is the MFMA's own fp32 accumulation in both kernels.  (The two-piece
+// "bf16x3" split leaves 2^-16 per product and misses the 1e-4 bound at D = 512; see the header.)  Six MFMAs of
+// 32x32x16 bf16 replace eight of 32x32x2 f32 per 16 k: 6 x 32 instead of 8 x 64 cycles per SIMD.
+//
+// One workgroup (4 waves) per 128 x 128 tile, a wave owns 64 x 64, slabs of 16 k (one MFMA step).  The fp32 operands
+// are loaded as before (one float4 per lane, row and slab) and cut into pieces on their way into LDS, which holds
+// [buffer][operand][piece][row][16 bf16]: a lane's ds_read_b128 is the 8 k of its half of the step (lanes 0-31: k 0-7,
+// lanes 32-63: k 8-15 -- the same map for both operands, and the order of a sum does not matter); the two halves of
+// a row are swapped in rows 8-15 of every 16, so the 16 rows of a read phase fall on 16 different bank quads.
+// Used when D is a multiple of 16 and the embeddings are 16-byte aligned; otherwise sdp_scores_kernel.
+// ----------------------------------------------------------------------------------------------------------------
+#ifndef SDP_X6_ABL
+#define SDP_X6_ABL 0   // timing experiments: 1 = no MFMAs, 2 = pieces not cut (raw halves stored), 4 = no epilogue stores
+#endif
+namespace sdp {
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr int X6_BK = 16;
+#ifndef SDP_X6_AHEAD
+#define SDP_X6_AHEAD 4
+#endif
+constexpr int X6_AHEAD = SDP_X6_AHEAD;             // slabs the global loads run ahead of the MFMAs (registers)
+constexpr int X6_PITCH = 32;                       // bytes per (row, piece): 16 bf16, the two 16-byte halves swapped in rows 8-15 of every 16
+constexpr int X6_PLANE = SC_TILE * X6_PITCH;       // bytes per (operand, piece)
+constexpr int X6_BUF = 2 * 3 * X6_PLANE;           // bytes per buffer
+static_assert(2 * X6_BUF == SCORES_X6_LDS_BYTES, "sdp_kernels.h: SCORES_X6_LDS_BYTES");
+
+// four consecutive k of one row -> the three pieces, each as two dwords of two bf16
+__device__ __forceinline__ void cut3(const f32x4 v, u32x2 (&piece)[3])
+{
+    unsigned h0[4], h1[4], h2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h0[e] = __float_as_uint(v[e]);
+        const float r1 = v[e] - __uint_as_float(h0[e] & 0xffff0000u);   // exact
+        h1[e] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(h1[e] & 0xffff0000u);     // exact, <= 8 significant bits
+        h2[e] = __float_as_uint(r2);
+    }
+    // bytes 2, 3 of each word are its bf16 (truncated)
+    piece[0][0] = __builtin_amdgcn_perm(h0[1], h0[0], 0x07060302u), piece[0][1] = __builtin_amdgcn_perm(h0[3], h0[2], 0x07060302u);
+    piece[1][0] = __builtin_amdgcn_perm(h1[1], h1[0], 0x07060302u), piece[1][1] = __builtin_amdgcn_perm(h1[3], h1[2], 0x07060302u);
+    piece[2][0] = __builtin_amdgcn_perm(h2[1], h2[0], 0x07060302u), piece[2][1] = __builtin_amdgcn_perm(h2[3], h2[2], 0x07060302u);
+}
+}  // namespace sdp
+
+extern "C" __global__ void __launch_bounds__(256, 3)
+sdp_scores_x6_kernel(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
+                     int M, int D)
+{
+    using namespace sdp;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_x6[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kind = blockIdx.z >= (unsigned)B;
+    const int b = kind ? blockIdx.z - B : blockIdx.z;
+    const float *X = (kind ? gx : zx) + (size_t)b * N * D;
+    const float *Y = (kind ? gy : zy) + (size_t)b * M * D;
+    float *C = (kind ? A : theta) + (size_t)b * N * M;
+    const int i0 = blockIdx.y * SC_TILE, j0 = blockIdx.x * SC_TILE;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, N * D * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Y), 0, M * D * 4, 0x00020000);
+
+    // staging: a slab is 128 rows x 16 k per operand = 512 float4; thread t moves rows t / 4 and t / 4 + 64, k = 4 (t % 4)
+    const int ld_row = tid >> 2, ld_k = (tid & 3) * 4;
+    // LDS column of this thread's four k within its row: the 16-byte half ld_k / 8, swapped in rows 8-15 of every 16 so
+    // that the 16 rows of a read phase (stride 32 bytes) fall on 16 different bank quads without padding
+    const int st_col = (((ld_k >> 3) ^ ((ld_row >> 3) & 1)) << 4) + ((ld_k & 4) << 1);
+    unsigned row_off[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int op = 0; op < 2; ++op) {
+            const int row = (op ? j0 : i0) + ld_row + 64 * q;
+            row_off[op][q] = row < (op ? M : N) ? (unsigned)((size_t)row * D + ld_k) * 4u : 0x80000000u;   // outside: zeros
+        }
+    // A slab's MFMAs take ~0.3 us per wave, a global load ~2 us: the loads run four slabs ahead of the MFMAs, in
+    // registers (4 x 4 float4 per lane), and are issued unconditionally -- a slab past the end of the rows reads through
+    // an out-of-range offset (zeros, no traffic) -- so that the compiler's vmcnt bookkeeping stays exact.
+    constexpr int AHEAD = X6_AHEAD;
+    f32x4 stage[AHEAD][2][2];
+    auto load_slab = [&](int k0, f32x4 (&st)[2][2]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int op = 0; op < 2; ++op) {
+                const auto w = __builtin_amdgcn_raw_buffer_load_b128(op ? ry : rx, k0 < D ? row_off[op][q] : 0x80000000u, k0 * 4, 0);
+                f32x4 v;
+                v[0] = __uint_as_float(w[0]), v[1] = __uint_as_float(w[1]), v[2] = __uint_as_float(w[2]), v[3] = __uint_as_float(w[3]);
+                st[op][q] = v;
+            }
+    };
+    auto store_slab = [&](int buf, const f32x4 (&st)[2][2]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int op = 0; op < 2; ++op) {
+                u32x2 piece[3];
+                if constexpr (SDP_X6_ABL & 2) {
+                    piece[0][0] = __float_as_uint(st[op][q][0]), piece[0][1] = __float_as_uint(st[op][q][1]);
+                    piece[1][0] = __float_as_uint(st[op][q][2]), piece[1][1] = __float_as_uint(st[op][q][3]);
+                    piece[2] = piece[0];
+                } else {
+                    cut3(st[op][q], piece);
+                }
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    *reinterpret_cast<u32x2 *>(lds_x6 + buf * X6_BUF + (op * 3 + pc) * X6_PLANE + (ld_row + 64 * q) * X6_PITCH + st_col) = piece[pc];
+            }
+    };
+
+    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+    const int fr = lane & 31, fkb = ((lane >> 5) ^ ((lane >> 3) & 1)) * 16;   // this lane's row within a 32-row block, byte offset of its 8 k (swizzled)
+    f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int col = j0 + wc + 32 * c + (lane & 31);
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int row = i0 + wr + 32 * a + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
-                const float x = acc[a][c][v];
-                const float y = kind ? logsigmoid_f(x) : softplus_f(x);
-                const unsigned off = (row < N && col < M) ? (unsigned)((size_t)row * M + col) * 4u : 0x80000000u;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rc, off, 0, 0);
+            for (int v = 0; v < 16; ++v) acc[a][c][v] = 0.f;
+
+    const int nslab = D / X6_BK;
+#pragma unroll
+    for (int u = 0; u < AHEAD; ++u) load_slab(u * X6_BK, stage[u]);
+    store_slab(0, stage[0]);
+    __syncthreads();
+    for (int s0 = 0; s0 < nslab; s0 += AHEAD) {
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) {
+            const int s = s0 + u;
+            const int buf = u & 1;   // = s & 1: s0 is a multiple of AHEAD, which is even
+            // slab s went to LDS in the previous iteration: its registers take slab s + AHEAD
+            load_slab((s + AHEAD) * X6_BK, stage[u]);
+            if (s < nslab) {
+                bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+                        fa[a][pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(lds_x6 + buf * X6_BUF + pc * X6_PLANE + (wr + 32 * a + fr) * X6_PITCH + fkb));
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        fb[c][pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(lds_x6 + buf * X6_BUF + (3 + pc) * X6_PLANE + (wc + 32 * c + fr) * X6_PITCH + fkb));
+                }
+                // the six piece pairs, smallest first
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+                        {
+                            if constexpr (SDP_X6_ABL & 1) {
+                                const u32x4 ua = __builtin_bit_cast(u32x4, fa[a][PA[t]]), ub = __builtin_bit_cast(u32x4, fb[c][PB[t]]);
+                                acc[a][c][t] += __uint_as_float(ua[0] ^ ub[1]);
+                            } else {
+                                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[t]], fb[c][PB[t]], acc[a][c], 0, 0, 0);
+                            }
+                        }
+                if (s + 1 < nslab) store_slab(buf ^ 1, stage[(u + 1) % AHEAD]);
             }
+            __syncthreads();
         }
+    }
+    if constexpr (SDP_X6_ABL & 4) {
+        if (acc[0][0][0] == 12345.f) C[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];
+    } else {
+        scores_epilogue(acc, C, N, M, i0, j0, wr, wc, lane, kind);
+    }
 }

@@ -43,7 +43,9 @@ def test_kernel_matches_fixture_and_gradients(golden_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(256, 512, 512, 512), (3, 127, 129, 31), (2, 300, 5, 100), (1, 1, 2048, 7)],
+@pytest.mark.parametrize("shape", [(256, 512, 512, 512), (3, 127, 129, 31), (2, 300, 5, 100), (1, 1, 2048, 7),
+                                   # D a multiple of 16: the three-piece bf16 kernel, ragged tiles in N and M
+                                   (3, 127, 129, 48), (2, 300, 5, 64), (1, 1, 2048, 16), (2, 130, 257, 1024)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_kernel_matches_oracle(shape):
     import torch
@@ -61,6 +63,32 @@ def test_kernel_matches_oracle(shape):
     # a pair's scores do not depend on the batch it is computed in (bit-exact)
     alone_t, alone_a = alignment_scores(*[x[sel[-1]:sel[-1] + 1].contiguous() for x in t])
     assert torch.equal(alone_t[0], theta[sel[-1]]) and torch.equal(alone_a[0], A[sel[-1]])
+
+
+@pytest.mark.gpu
+def test_bf16_piece_kernel_has_fp32_accuracy_and_unaligned_rows_fall_back():
+    """The default kernel for D % 16 == 0 multiplies exact three-piece bf16 operands (six products per k): its error
+    against a float64 einsum must be that of an fp32 product (a two-piece split would show 2^-16 per product: 3e-4 here),
+    also on large scores; embeddings that are not 16-byte aligned take the f32-input kernel and agree to the same bound."""
+    import torch
+    import torch.nn.functional as F
+    from deepblast_amd.scores import alignment_scores
+    B, N, M, D = 6, 200, 333, 512
+    for scale, bound in ((1.0, 1e-6), (8.0, 3e-5)):
+        t = [torch.from_numpy((datagen.normal(700 + i, (B, n, D)) * scale / np.sqrt(D)).astype(np.float32)).cuda() for i, n in enumerate((N, M, N, M))]
+        ref_t = F.softplus(torch.einsum("bid,bjd->bij", t[0].double(), t[1].double()))
+        ref_a = F.logsigmoid(torch.einsum("bid,bjd->bij", t[2].double(), t[3].double()))
+        theta, A = alignment_scores(*t)
+        assert float((theta.double() - ref_t).abs().max()) <= bound and float((A.double() - ref_a).abs().max()) <= bound
+        # the same embeddings at an address that is 4 (not 16) bytes aligned
+        shifted = []
+        for x in t:
+            buf = torch.empty(x.numel() + 1, dtype=torch.float32, device="cuda")
+            buf[1:].copy_(x.reshape(-1))
+            shifted.append(buf[1:].view_as(x))
+            assert shifted[-1].data_ptr() % 16 == 4 and shifted[-1].is_contiguous()
+        theta2, A2 = alignment_scores(*shifted)
+        assert float((theta2.double() - ref_t).abs().max()) <= bound and float((A2.double() - ref_a).abs().max()) <= bound
 
 
 @pytest.mark.gpu
