@@ -33,6 +33,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SC_TILE = 128;   // rows and columns of C per workgroup
+
+// Tile of this workgroup.  The dispatcher places workgroup h (linear id) on XCD h % 8, and each XCD has its own L2: with
+// the plain blockIdx -> tile map the 16 tiles of a 512 x 512 pair land on all eight XCDs and every L2 fetches the pair's
+// embeddings for itself.  Here XCD k takes the k-th eighth of the tile list, in order, so the tiles that share operand
+// rows run on one XCD back to back (a performance choice only: any placement gives the same results).
+struct TileId { int x, y, z; };
+__device__ __forceinline__ TileId xcd_tile()
+{
+    const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+    const unsigned h = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned per = total / 8, body = per * 8;
+    const unsigned t = h < body ? (h % 8) * per + h / 8 : h;   // a tail of < 8 workgroups keeps its own ids
+    return {(int)(t % gx), (int)((t / gx) % gy), (int)(t / (gx * gy))};
+}
 #ifndef SDP_SC_BK
 #define SDP_SC_BK 16
 #endif
@@ -105,12 +119,13 @@ sdp_scores_kernel(const float *zx, const float *zy, const float *gx, const float
     float (*lds)[2][SC_TILE * SC_PITCH] = reinterpret_cast<float (*)[2][SC_TILE * SC_PITCH]>(lds_raw);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kind = blockIdx.z >= (unsigned)B;
-    const int b = kind ? blockIdx.z - B : blockIdx.z;
+    const TileId tile = xcd_tile();
+    const int kind = tile.z >= B;
+    const int b = kind ? tile.z - B : tile.z;
     const float *X = (kind ? gx : zx) + (size_t)b * N * D;
     const float *Y = (kind ? gy : zy) + (size_t)b * M * D;
     float *C = (kind ? A : theta) + (size_t)b * N * M;
-    const int i0 = blockIdx.y * SC_TILE, j0 = blockIdx.x * SC_TILE;
+    const int i0 = tile.y * SC_TILE, j0 = tile.x * SC_TILE;
 
     // raw buffers: rows past the end of a matrix fall outside the descriptor and load as zeros
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, N * D * 4, 0x00020000);
@@ -267,12 +282,13 @@ sdp_scores_x6_kernel(const float *zx, const float *zy, const float *gx, const fl
     using namespace sdp;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_x6[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kind = blockIdx.z >= (unsigned)B;
-    const int b = kind ? blockIdx.z - B : blockIdx.z;
+    const TileId tile = xcd_tile();
+    const int kind = tile.z >= B;
+    const int b = kind ? tile.z - B : tile.z;
     const float *X = (kind ? gx : zx) + (size_t)b * N * D;
     const float *Y = (kind ? gy : zy) + (size_t)b * M * D;
     float *C = (kind ? A : theta) + (size_t)b * N * M;
-    const int i0 = blockIdx.y * SC_TILE, j0 = blockIdx.x * SC_TILE;
+    const int i0 = tile.y * SC_TILE, j0 = tile.x * SC_TILE;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, N * D * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Y), 0, M * D * 4, 0x00020000);
 
