@@ -240,7 +240,8 @@ sdp_scores_kernel(const float *zx, const float *zy, const float *gx, const float
 // Used when D is a multiple of 16 and the embeddings are 16-byte aligned; otherwise sdp_scores_kernel.
 // ----------------------------------------------------------------------------------------------------------------
 #ifndef SDP_X6_ABL
-#define SDP_X6_ABL 0   // timing experiments: 1 = no MFMAs, 2 = pieces not cut (raw halves stored), 4 = no epilogue stores
+#define SDP_X6_ABL 0   // timing experiments: 1 = no MFMAs, 2 = pieces not cut (raw halves stored), 4 = no epilogue stores,
+                       // 8 = no barriers, 16 = no global loads, 32 = no LDS reads, 64 = no LDS writes (results are wrong)
 #endif
 namespace sdp {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -315,9 +316,13 @@ sdp_scores_x6_kernel(const float *zx, const float *zy, const float *gx, const fl
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int op = 0; op < 2; ++op) {
-                const auto w = __builtin_amdgcn_raw_buffer_load_b128(op ? ry : rx, k0 < D ? row_off[op][q] : 0x80000000u, k0 * 4, 0);
                 f32x4 v;
-                v[0] = __uint_as_float(w[0]), v[1] = __uint_as_float(w[1]), v[2] = __uint_as_float(w[2]), v[3] = __uint_as_float(w[3]);
+                if constexpr (SDP_X6_ABL & 16) {
+                    v[0] = v[1] = v[2] = v[3] = (float)(k0 + q + op);
+                } else {
+                    const auto w = __builtin_amdgcn_raw_buffer_load_b128(op ? ry : rx, k0 < D ? row_off[op][q] : 0x80000000u, k0 * 4, 0);
+                    v[0] = __uint_as_float(w[0]), v[1] = __uint_as_float(w[1]), v[2] = __uint_as_float(w[2]), v[3] = __uint_as_float(w[3]);
+                }
                 st[op][q] = v;
             }
     };
@@ -335,8 +340,13 @@ sdp_scores_x6_kernel(const float *zx, const float *zy, const float *gx, const fl
                     cut3(st[op][q], piece);
                 }
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-                    *reinterpret_cast<u32x2 *>(lds_x6 + buf * X6_BUF + (op * 3 + pc) * X6_PLANE + (ld_row + 64 * q) * X6_PITCH + st_col) = piece[pc];
+                for (int pc = 0; pc < 3; ++pc) {
+                    if constexpr (SDP_X6_ABL & 64) {
+                        if (piece[pc][0] == 0x12345u) lds_x6[pc] = 1;
+                    } else {
+                        *reinterpret_cast<u32x2 *>(lds_x6 + buf * X6_BUF + (op * 3 + pc) * X6_PLANE + (ld_row + 64 * q) * X6_PITCH + st_col) = piece[pc];
+                    }
+                }
             }
     };
 
@@ -354,7 +364,7 @@ sdp_scores_x6_kernel(const float *zx, const float *zy, const float *gx, const fl
 #pragma unroll
     for (int u = 0; u < AHEAD; ++u) load_slab(u * X6_BK, stage[u]);
     store_slab(0, stage[0]);
-    __syncthreads();
+    if constexpr (!(SDP_X6_ABL & 8)) __syncthreads();
     for (int s0 = 0; s0 < nslab; s0 += AHEAD) {
 #pragma unroll
         for (int u = 0; u < AHEAD; ++u) {
@@ -367,11 +377,23 @@ sdp_scores_x6_kernel(const float *zx, const float *zy, const float *gx, const fl
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) {
 #pragma unroll
-                    for (int a = 0; a < 2; ++a)
-                        fa[a][pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(lds_x6 + buf * X6_BUF + pc * X6_PLANE + (wr + 32 * a + fr) * X6_PITCH + fkb));
+                    for (int a = 0; a < 2; ++a) {
+                        if constexpr (SDP_X6_ABL & 32) {
+                            const u32x4 cst = {(unsigned)(s + a), (unsigned)pc, (unsigned)lane, 7u};
+                            fa[a][pc] = __builtin_bit_cast(bf16x8, cst);
+                        } else {
+                            fa[a][pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(lds_x6 + buf * X6_BUF + pc * X6_PLANE + (wr + 32 * a + fr) * X6_PITCH + fkb));
+                        }
+                    }
 #pragma unroll
-                    for (int c = 0; c < 2; ++c)
-                        fb[c][pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(lds_x6 + buf * X6_BUF + (3 + pc) * X6_PLANE + (wc + 32 * c + fr) * X6_PITCH + fkb));
+                    for (int c = 0; c < 2; ++c) {
+                        if constexpr (SDP_X6_ABL & 32) {
+                            const u32x4 cst = {(unsigned)(s + c), (unsigned)pc, (unsigned)lane, 9u};
+                            fb[c][pc] = __builtin_bit_cast(bf16x8, cst);
+                        } else {
+                            fb[c][pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(lds_x6 + buf * X6_BUF + (3 + pc) * X6_PLANE + (wc + 32 * c + fr) * X6_PITCH + fkb));
+                        }
+                    }
                 }
                 // the six piece pairs, smallest first
                 constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
@@ -391,7 +413,7 @@ sdp_scores_x6_kernel(const float *zx, const float *zy, const float *gx, const fl
                         }
                 if (s + 1 < nslab) store_slab(buf ^ 1, stage[(u + 1) % AHEAD]);
             }
-            __syncthreads();
+            if constexpr (!(SDP_X6_ABL & 8)) __syncthreads();
         }
     }
     if constexpr (SDP_X6_ABL & 4) {
