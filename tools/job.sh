@@ -1,4 +1,4 @@
 #!/bin/bash
-mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 600 python tools/scores_probe.py < /dev/null 2>&1 | grep -v amdgpu.ids | tail -4
-timeout 600 python -m pytest tests/test_scores.py -m gpu -x -q < /dev/null 2>&1 | tail -2
+OUT=gpurun_out/round_r02x; mkdir -p $OUT; export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_sc -o sc -- python bench.py --mode scores+dp --steps 10 --warmup 2 --no-cpu-baseline < /dev/null > $OUT/bench_sc.json 2> $OUT/sc.err
+head -4 $OUT/prof_sc/sc_kernel_stats.csv | cut -c1-140; tail -1 $OUT/bench_sc.json | cut -c1-160
