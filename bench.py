@@ -8,9 +8,11 @@ before the timed region.  N>1: one process per GPU (torch.distributed.run), ever
 own B pairs (weak scaling, no data-path collective) and the step ends with the RCCL all-gather
 that collects the terminal scores Vt from all ranks (--gather e also gathers E).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (sdp_fwd_kernel): algorithmic
-bytes (12 B per cell-update) over its mean launch duration measured with HIP events
-on the launch stream inside the timed region.  `cpu_baseline` is the CPU oracle (a port of
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the mode (the one with the longest
+mean launch; sdp_fwd_kernel in the headline mode): algorithmic bytes (12 B per cell-update for the forward
+and backward sweeps, 32 B for each adjoint sweep; flops on the matrix pipe when the scores
+GEMM dominates) over its mean launch duration measured with HIP events on the launch stream inside the
+timed region.  `cpu_baseline` is the CPU oracle (a port of
 deepblast/nw.py, oracle/sdp_oracle.c) timed on this box's host cores, rank 0 at N=1 only.
 """
 import argparse
@@ -291,9 +293,15 @@ def main():
     ms = timer.means_ms()
 
     if rank == 0:
-        dom = "sdp_fwd_kernel"
+        # dominant kernel of THIS mode = the sweep / GEMM with the longest mean launch; its algorithmic bytes per cell
+        # follow SURVEY.md 8(d): fwd and bwd 12 B, adjoint fwd (a3) and adjoint bwd (a4) 32 B each (reference layout)
+        def algo_bytes_per_cell(name):
+            return 32 if name.startswith("sdp_adj_") else ALGO_BYTES_PER_CELL_UPDATE
+        cand = {k: v for k, v in ms.items() if k.startswith(("sdp_fwd", "sdp_bwd", "sdp_adj_", "sdp_scores"))}
+        dom = max(cand, key=cand.get) if cand else "sdp_fwd_kernel"
         dom_ms = ms.get(dom, float("nan"))
-        achieved = cells * ALGO_BYTES_PER_CELL_UPDATE / (dom_ms * 1e-3) / 1e9
+        dom_bytes = cells * algo_bytes_per_cell(dom)
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes (profiles/traffic.json, tools/gpu_round.sh): only if that file was
         # measured on exactly these kernel sources -- a stale figure is reported as null, not as a number
         traffic, traffic_stamp = None, None
@@ -332,10 +340,14 @@ def main():
             "kernel_ms": ms,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": cells * ALGO_BYTES_PER_CELL_UPDATE,
+                         "algorithmic_bytes_per_launch": dom_bytes,
                          "launch_ms": dom_ms,
                          "whole_step_frac": (per_step_updates * ALGO_BYTES_PER_CELL_UPDATE * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9)},
         }
+        if dom.startswith("sdp_scores"):
+            # the GEMM dominates this mode: its bound is the matrix pipe (filled in below as scores_roofline); the
+            # HBM figures above then describe nothing and are replaced
+            line["roofline"] = None
         if args.mode == "scores+dp" and ("sdp_scores_kernel" in ms or "sdp_scores_x6_kernel" in ms):
             flops = 2.0 * 2.0 * B * N * M * args.D          # two (N,D) x (D,M) products per pair
             if "sdp_scores_x6_kernel" in ms:
@@ -343,15 +355,17 @@ def main():
                 # flops; `achieved` / `peak` are what ran on the bf16 pipe, `algorithmic` the fp32-equivalent rate
                 t_ms = ms["sdp_scores_x6_kernel"]
                 tf = 6.0 * flops / (t_ms * 1e-3) / 1e12
-                line["scores_roofline"] = {"bound": "mfma", "kernel": "sdp_scores_x6_kernel", "achieved": tf, "peak": 2516.6, "unit": "TFLOP/s",
+                line["scores_roofline"] = {"bound": "mfma", "kernel": "sdp_scores_x6_kernel", "achieved": tf, "peak": 2516.6, "unit": "TFLOP/s", "traffic": None,
                                            "frac": tf / 2516.6, "dtype": "bf16 x 6 piece products (v_mfma_f32_32x32x16_bf16), f32 accumulate",
                                            "algorithmic": flops / (t_ms * 1e-3) / 1e12, "algorithmic_vs_f32_mfma_peak": flops / (t_ms * 1e-3) / 1e12 / 157.3,
                                            "D": args.D, "launch_ms": t_ms, "flops_per_launch": flops}
             else:
                 tf = flops / (ms["sdp_scores_kernel"] * 1e-3) / 1e12
-                line["scores_roofline"] = {"bound": "mfma", "kernel": "sdp_scores_kernel", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s",
+                line["scores_roofline"] = {"bound": "mfma", "kernel": "sdp_scores_kernel", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "traffic": None,
                                            "frac": tf / 157.3, "dtype": "f32 (v_mfma_f32_32x32x2_f32)", "D": args.D,
                                            "launch_ms": ms["sdp_scores_kernel"], "flops_per_launch": flops}
+        if line["roofline"] is None:
+            line["roofline"] = line.get("scores_roofline")
         if e_gather is not None:
             line["with_e_gather"] = {"ms_per_step": e_gather * 1e3, "value": world * per_step_updates / e_gather,
                                      "bytes_into_each_gpu": (world - 1) * B * N * M * 4}

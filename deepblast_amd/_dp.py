@@ -114,8 +114,13 @@ def make_functions(variant, prefix, allow_none_operator=False):
     return Function, FunctionBackward
 
 
-def traceback(grad):
+def traceback(grad, rule="cpu"):
     """Greedy arg-max walk over one (N, M) expected-alignment matrix -> [(i, j, state)].
+
+    rule="cpu" (default, the parity oracle's class) is described below; rule="cuda" is the walk of the reference's
+    GPU classes (deepblast/nw_cuda.py:273-317, sw_cuda.py:283-327), the classes this package replaces: it stops as soon
+    as ANY of the three neighbours is off the matrix (`or` instead of `and`, nw_cuda.py:297) or equals its sentinel
+    -1e10, so it never wraps and never raises; the two differ when a walk reaches row 0 or column 0 early.
 
     Same rule as the reference's CPU decoder (deepblast/nw.py:401-444, sw.py:328-371):
     start at the bottom-right match, repeatedly step to the largest of
@@ -125,17 +130,22 @@ def traceback(grad):
     and can walk off the matrix (IndexError) on inputs that are not alignment matrices;
     both behaviours are preserved.
     """
+    if rule not in ("cpu", "cuda"):
+        raise ValueError(f"traceback rule must be 'cpu' or 'cuda', got {rule!r}")
     x, m, y = 0, 1, 2
     g = grad.detach().cpu().numpy() if isinstance(grad, torch.Tensor) else np.asarray(grad)
     N, M = g.shape
-    floor = -100000
+    floor = -1e10 if rule == "cuda" else -100000
     i, j = N - 1, M - 1
     states = [(i, j, m)]
     while True:
         left = floor if i <= 0 else g[i - 1, j]
         diag = floor if (i <= 0 and j <= 0) else g[i - 1, j - 1]
         upper = floor if j <= 0 else g[i, j - 1]
-        if left == floor and diag == floor and upper == floor:
+        if rule == "cuda":
+            if left == floor or diag == floor or upper == floor:
+                break
+        elif left == floor and diag == floor and upper == floor:
             break
         # the reference compares through torch.Tensor([...]), i.e. in float32, first maximum wins
         cands = (np.float32(left), np.float32(diag), np.float32(upper))
@@ -159,9 +169,14 @@ class _Decoder(nn.Module):
 
     _function = None
 
-    def __init__(self, operator):
+    def __init__(self, operator, traceback_rule="cpu"):
+        """traceback_rule (extension): "cpu" = the walk of the reference's CPU decoders (nw.py:401-444, the parity
+        oracle), "cuda" = the walk of its GPU decoders (nw_cuda.py:273-317), for callers that switch over from those."""
         super().__init__()
+        if traceback_rule not in ("cpu", "cuda"):
+            raise ValueError(f"traceback_rule must be 'cpu' or 'cuda', got {traceback_rule!r}")
         self.operator = operator
+        self.traceback_rule = traceback_rule
 
     def forward(self, theta, A, lengths=None):
         """theta, A: (B, N, M) fp32 on a ROCm device -> Vt (B,) on the same device.
@@ -178,13 +193,13 @@ class _Decoder(nn.Module):
         return self._function.apply(theta, A, self.operator, lengths, True)
 
     def traceback(self, grad):
-        return traceback(grad)
+        return traceback(grad, self.traceback_rule)
 
     def traceback_batch(self, grad, lengths=None):
         """Extension: the same walk for a whole (B, N, M) batch on the device, one wavefront per pair,
         instead of one host walk per pair (alignment.py:165-170).  -> list of B lists of (i, j, state);
         raises IndexError if any walk leaves its matrix, like the per-pair version."""
-        states, counts = _engine.get_engine().traceback(grad, lengths)
+        states, counts = _engine.get_engine().traceback(grad, lengths, self.traceback_rule)
         states, counts = states.cpu().numpy(), counts.cpu().numpy()
         if (counts < 0).any():
             raise IndexError(f"traceback walked off the matrix for pairs {np.nonzero(counts < 0)[0].tolist()}")

@@ -28,6 +28,7 @@ def _ptr(t):
 
 
 EXACT_STATE = 0x100  # include/sdp.h: SDP_EXACT_STATE
+TRACEBACK_RULES = {"cpu": 0, "cuda": 1}  # include/sdp.h: SDP_TRACEBACK_CPU / SDP_TRACEBACK_CUDA
 
 
 class HipEngine:
@@ -189,8 +190,13 @@ class HipEngine:
         _lib.check(rc, "sdp_adjoint_backward_f32")
         return Ed
 
-    def traceback(self, grad, lens=None):
-        """Batched traceback on the device -> (states (B,cap,3) int32, counts (B,) int32)."""
+    def traceback(self, grad, lens=None, rule="cpu"):
+        """Batched traceback on the device -> (states (B,cap,3) int32, counts (B,) int32).
+
+        rule: "cpu" = the CPU classes' walk (nw.py:401-444), "cuda" = the walk of the GPU classes this library
+        replaces (nw_cuda.py:273-317: stops as soon as one neighbour is off the matrix)."""
+        if rule not in TRACEBACK_RULES:
+            raise ValueError(f"traceback rule must be one of {sorted(TRACEBACK_RULES)}, got {rule!r}")
         dev = self._dev(grad)
         grad = grad.detach().to(torch.float32).contiguous()
         B, N, M = grad.shape
@@ -199,10 +205,15 @@ class HipEngine:
         states = torch.empty((B, cap, 3), dtype=torch.int32, device=grad.device)
         counts = torch.empty(B, dtype=torch.int32, device=grad.device)
         with torch.cuda.device(dev), self._bracket("sdp_traceback_kernel"):
-            rc = self.lib.sdp_traceback_i32(_ptr(grad), _ptr(states), _ptr(counts), B, N, M, _ptr(lens), dev,
-                                            self._stream(dev))
-        _lib.check(rc, "sdp_traceback_i32")
+            rc = self.lib.sdp_traceback_rule_i32(_ptr(grad), _ptr(states), _ptr(counts), B, N, M, _ptr(lens),
+                                                 TRACEBACK_RULES[rule], dev, self._stream(dev))
+        _lib.check(rc, "sdp_traceback_rule_i32")
         return states, counts
+
+    def init(self, device=None):
+        """Create the library's per-device state now (include/sdp.h: sdp_init) -- needed only before stream capture."""
+        dev = torch.cuda.current_device() if device is None else device
+        _lib.check(self.lib.sdp_init(dev), "sdp_init")
 
     def selftest(self, device=0):
         _lib.check(self.lib.sdp_selftest(device), "sdp_selftest")

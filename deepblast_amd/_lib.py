@@ -39,6 +39,9 @@ SIGNATURES = {
     "sdp_traceback_capacity": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "sdp_traceback_i32": (ctypes.c_int, [_c_f32p, _c_i32p, _c_i32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i32p,
                                          ctypes.c_int, ctypes.c_void_p]),
+    "sdp_traceback_rule_i32": (ctypes.c_int, [_c_f32p, _c_i32p, _c_i32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i32p,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "sdp_init": (ctypes.c_int, [ctypes.c_int]),
     "sdp_loss_forward_f32": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_i32p, ctypes.c_void_p, _c_i32p, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "sdp_loss_backward_f32": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_i32p, _c_f32p, _c_f32p, ctypes.c_int,

@@ -20,29 +20,36 @@ std::atomic<int> g_dbg{0};
 #endif
 
 // ---- per-device status words (host-pinned, device-visible) ----
+// Published once per device under g_status_mu and read through atomics afterwards: launches from several host threads
+// may race with the first launch on a device.  Created by sdp_init(device) -- or by the first launch there; a caller
+// that captures launches into a hipGraph calls sdp_init first (an allocation inside a capture fails, and the launch
+// would then run without a way to report a hand-off time-out).
 constexpr int MAX_DEV = 64;
 std::mutex g_status_mu;
-int *g_status_host[MAX_DEV] = {nullptr};
-int *g_status_dev[MAX_DEV] = {nullptr};
+std::atomic<int *> g_status_host[MAX_DEV];
+std::atomic<int *> g_status_dev[MAX_DEV];
 std::atomic<int> g_status_seen[MAX_DEV];  // time-outs already reported to the caller
 
 int *status_words(int device)  // device pointer, or nullptr (then kernels cannot report)
 {
     if (device < 0 || device >= MAX_DEV) return nullptr;
+    if (int *d = g_status_dev[device].load(std::memory_order_acquire)) return d;
     std::lock_guard<std::mutex> lk(g_status_mu);
-    if (!g_status_dev[device]) {
-        int *h = nullptr, *d = nullptr;
-        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return nullptr;
-        memset(h, 0, 64);
-        if (hipHostGetDevicePointer((void **)&d, h, 0) != hipSuccess) {
-            (void)hipHostFree(h);
-            return nullptr;
-        }
-        g_status_host[device] = h;
-        g_status_dev[device] = d;
-        g_status_seen[device] = 0;
+    if (int *d = g_status_dev[device].load(std::memory_order_relaxed)) return d;
+    int *h = nullptr, *d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
     }
-    return g_status_dev[device];
+    memset(h, 0, 64);
+    if (hipHostGetDevicePointer((void **)&d, h, 0) != hipSuccess) {
+        (void)hipHostFree(h);
+        return nullptr;
+    }
+    g_status_seen[device].store(0);
+    g_status_host[device].store(h, std::memory_order_release);
+    g_status_dev[device].store(d, std::memory_order_release);
+    return d;
 }
 
 int fail(int code, const char *msg)
@@ -184,15 +191,39 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
     return {v, W, lds, off};
 }
 
+// Where the 32-step units of the skewed state live (sdp_kernels.hip, "Skewed state addressing").  Default: every
+// (pair, strip) is one contiguous stream.  -DSDP_STATE_MARCH=1 ("marching"): unit u of every (pair, strip) in one slab,
+// so that a batch whose pairs advance in lockstep sweeps memory front to back; the unit part of an address travels in a
+// 32-bit scalar offset, so states of 2 GiB and more keep the contiguous streams.  Measured equal (round 3, B=256 512^2,
+// interleaved A/B: fwd 228.9 vs 226.1 us, bwd 163.5 vs 164.9), although a bare read/write stream of the same mix runs 4 %
+// faster that way (tools/ubench/mix2.hip): the sweeps are not bound by the order in which memory is visited.
+// All four sweeps of a problem (B, N, M) derive the same layout from the same three numbers.
+#ifndef SDP_STATE_MARCH
+#define SDP_STATE_MARCH 0
+#endif
+void state_layout(sdp::Params &p)
+{
+    const size_t streams = (size_t)p.B * p.nstrips_max, units = (size_t)p.tpad / sdp::STATE_UNIT_STEPS;
+    const bool march = SDP_STATE_MARCH && streams * units * sdp::STATE2_UNIT_BYTES < ((size_t)1 << 31);
+    p.st_ps = march ? sdp::STATEQ_UNIT_BYTES : units * sdp::STATEQ_UNIT_BYTES;
+    p.st_us = march ? (unsigned)(streams * sdp::STATEQ_UNIT_BYTES) : sdp::STATEQ_UNIT_BYTES;
+    p.st2_ps = march ? sdp::STATE2_UNIT_BYTES : units * sdp::STATE2_UNIT_BYTES;
+    p.st2_us = march ? (unsigned)(streams * sdp::STATE2_UNIT_BYTES) : sdp::STATE2_UNIT_BYTES;
+}
+
 // A kernel of an EARLIER call on this device gave up waiting for a strip hand-off: its results are wrong.  Reported
 // once, by the next call on the device (or by sdp_device_status), as SDP_E_HANDOFF.
 int pending_handoff_error(int device)
 {
-    if (device < 0 || device >= MAX_DEV || !g_status_host[device]) return 0;
-    const volatile int *h = g_status_host[device];
+    if (device < 0 || device >= MAX_DEV) return 0;
+    const volatile int *h = g_status_host[device].load(std::memory_order_acquire);
+    if (!h) return 0;
     const int n = h[0];
-    if (n == g_status_seen[device].load()) return 0;
-    g_status_seen[device] = n;
+    // exactly one caller reports a given count: the one whose exchange moves `seen` to it
+    int seen = g_status_seen[device].load();
+    do {
+        if (n == seen) return 0;
+    } while (!g_status_seen[device].compare_exchange_weak(seen, n));
     snprintf(g_err, sizeof(g_err),
              "a strip hand-off timed out in an earlier launch on device %d (%d so far; first: pair %d, strip %d, chunk %d, "
              "pass %d): the results of that launch are invalid",
@@ -205,7 +236,7 @@ int pending_handoff_error(int device)
 // and must be given the same lengths -- read it from there.
 size_t packed_body_bytes(int B, int N, int M)
 {
-    return SDP_PACKED_DEPAD ? (size_t)B * sdp::stateq_rows(N, M) * 768 : (size_t)B * sdp::state_nstrips(N) * sdp::state_tpad(M) * 64 * 6;
+    return (size_t)B * sdp::state_nstrips(N) * sdp::state_tpad(M) * 64 * 6;
 }
 bool wants_order(int B, const int32_t *lens, int device) { return lens != nullptr && B > num_cus(device); }
 const int *order_in_state(const void *state, int B, int N, int M, bool exact)
@@ -237,6 +268,19 @@ VariantBits split_variant(int variant)
     return v;
 }
 
+// raise the dynamic-LDS limit once per (thread, device, kernel) -- it is sticky, and the value is the
+// 160 KiB the hardware has, so concurrent callers cannot disagree
+int raise_lds_limit(const Variant &v, int device)
+{
+    static thread_local unsigned long long lds_raised[21] = {0};  // per kernel id: bit d = done on device d
+    if (device >= 64 || !(lds_raised[v.id] >> device & 1ull)) {
+        hipError_t e = hipFuncSetAttribute(v.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        if (device < 64) lds_raised[v.id] |= 1ull << device;
+    }
+    return 0;
+}
+
 int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state = false, int forced_waves = 0, bool fused_seed = false)
 {
     hipError_t e = hipSetDevice(device);
@@ -245,6 +289,7 @@ int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state 
     p.nstrips_max = sdp::state_nstrips(p.N);
     p.tpad = sdp::state_tpad(p.M);
     p.mcap = (p.M + 63) / 64 * 64;
+    state_layout(p);
     p.status = status_words(device);
 #ifdef SDP_EXPERIMENTS
     p.dbg = g_dbg.load();
@@ -261,14 +306,7 @@ int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state 
     const int W = pl.W;
     const size_t lds = pl.lds, off = pl.stage_off;
     p.stage_off = (int)off;
-    // raise the dynamic-LDS limit once per (thread, device, kernel) -- it is sticky, and the value is the
-    // 160 KiB the hardware has, so concurrent callers cannot disagree
-    static thread_local unsigned long long lds_raised[21] = {0};  // per kernel id: bit d = done on device d
-    if (device >= 64 || !(lds_raised[v.id] >> device & 1ull)) {
-        e = hipFuncSetAttribute(v.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-        if (device < 64) lds_raised[v.id] |= 1ull << device;
-    }
+    if (int rc = raise_lds_limit(v, device)) return rc;
     void *args[] = {&p};
     e = hipLaunchKernel(v.kernel, dim3(p.B), dim3(64 * W), args, lds, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hipLaunchKernel");
@@ -315,13 +353,26 @@ int sdp_plan(int pass, int B, int N, int M, int has_lens, int exact_state, int c
     return 0;
 }
 
+int sdp_init(int device)
+{
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    if (device >= 0 && device < MAX_DEV && !status_words(device)) return fail(SDP_E_SELFTEST, "sdp_init: could not create the host-pinned status words");
+    for (int id = 0; id <= 20; ++id) {
+        const Variant v = variant(id);
+        if (v.id != id) continue;   // ids without a build of their own map to the default
+        if (int rc = raise_lds_limit(v, device)) return rc;
+    }
+    return 0;
+}
+
 int sdp_device_status(int device, int32_t info[4])
 {
-    if (device < 0 || device >= MAX_DEV || !g_status_host[device]) {
+    const volatile int *h = (device >= 0 && device < MAX_DEV) ? g_status_host[device].load(std::memory_order_acquire) : nullptr;
+    if (!h) {
         if (info) info[0] = info[1] = info[2] = info[3] = 0;
         return 0;
     }
-    const volatile int *h = g_status_host[device];
     if (info) info[0] = h[0], info[1] = h[1], info[2] = h[2], info[3] = h[3];
     return pending_handoff_error(device);
 }
@@ -485,18 +536,29 @@ int sdp_scores_f32(const float *zx, const float *zy, const float *gx, const floa
 
 int sdp_traceback_capacity(int N, int M) { return (N > 0 && M > 0) ? N + M + 2 : 0; }
 
-int sdp_traceback_i32(const float *grad, int32_t *states, int32_t *counts, int B, int N, int M, const int32_t *lens,
-                      int device, void *stream)
+int sdp_traceback_rule_i32(const float *grad, int32_t *states, int32_t *counts, int B, int N, int M, const int32_t *lens,
+                           int rule, int device, void *stream)
 {
     if (!grad || !states || !counts) return fail(SDP_E_NULLPTR, "sdp_traceback_i32: null pointer");
     if (B <= 0 || N <= 0 || M <= 0) return fail(SDP_E_SHAPE, "B, N and M must be positive");
+    if (rule != SDP_TRACEBACK_CPU && rule != SDP_TRACEBACK_CUDA) return fail(SDP_E_VARIANT, "traceback rule must be SDP_TRACEBACK_CPU or SDP_TRACEBACK_CUDA");
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
-    hipLaunchKernelGGL(sdp_traceback_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, grad, states, counts,
-                       lens, B, N, M, sdp_traceback_capacity(N, M));
+    if (rule == SDP_TRACEBACK_CUDA)
+        hipLaunchKernelGGL(sdp_traceback_cuda_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, grad, states, counts,
+                           lens, B, N, M, sdp_traceback_capacity(N, M));
+    else
+        hipLaunchKernelGGL(sdp_traceback_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, grad, states, counts,
+                           lens, B, N, M, sdp_traceback_capacity(N, M));
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "sdp_traceback_kernel");
     return 0;
+}
+
+int sdp_traceback_i32(const float *grad, int32_t *states, int32_t *counts, int B, int N, int M, const int32_t *lens,
+                      int device, void *stream)
+{
+    return sdp_traceback_rule_i32(grad, states, counts, B, N, M, lens, SDP_TRACEBACK_CPU, device, stream);
 }
 
 int sdp_loss_forward_f32(const float *ref, const float *pred, const float *G, const int32_t *lens, double *acc, int32_t *cnt,

@@ -85,6 +85,8 @@ struct Params {
     int B, N, M;
     int nstrips_max;     // ceil(N/64): strips per pair in the state layout
     int tpad;            // state rows (steps) per strip: roundup(M+63, 64)
+    size_t st_ps, st2_ps;      // state layout, bytes: stride between (pair, strip) streams -- packed Q | float2 states
+    unsigned st_us, st2_us;    // ... and between consecutive 32-step units of one stream
     int mcap;            // doubles per boundary row in LDS
     int stage_off;       // byte offset of the per-wave staging area in LDS
     int variant;
@@ -106,32 +108,13 @@ __host__ __device__ constexpr int stage_floats(int pass, int K, int nin_override
 // tail of both state buffers: room for the launch order of a variable-length batch (B ints, 256-byte granules)
 __host__ __device__ inline size_t state_order_bytes(int B) { return ((size_t)B * 4 + 255) / 256 * 256; }
 
-// Packed state without skew padding (see "shared ramp rows" in sdp_kernels.hip): implemented, parity-green, and OFF --
-// measured on one box, B=256 512^2: backward 160.6 -> 156.8 us (11 % less state to read) but forward 207.6 -> 240.4 us:
-// the rows shared by two strips are written in two partial pieces at different times, and partial-line writes cost
-// the memory system more than the padding they save.  (-DSDP_PACKED_DEPAD=1 needs the block-wise forward sweep.)
-#ifndef SDP_PACKED_DEPAD
-#define SDP_PACKED_DEPAD 0
-#endif
-// The same sharing for the float2 states of the training path: also implemented, parity-green, and OFF -- it saves
-// 11 % of their memory but no time (same box: forward with exact state 267.8 -> 271.7 us, adjoint forward 328.2 ->
-// 330.8, adjoint backward 415.6 -> 416.8): every strip still LOADS all 64 lanes of its ramp rows, so the bytes a reader
-// fetches do not change, and the writer pays for partial lines.
-#ifndef SDP_F2_DEPAD
-#define SDP_F2_DEPAD 0
-#endif
-// packed Q: a record row is one pair of steps (64 lanes x 12 B = 768 B); strips lie ceil(M/2) record rows apart
-constexpr int STATEQ_SLACK = 64;
-__host__ __device__ inline int stateq_pitch(int M) { return (M + 1) / 2; }
-__host__ __device__ inline size_t stateq_rows(int N, int M) { return (size_t)((N + 63) / 64) * stateq_pitch(M) + STATEQ_SLACK; }
-
-// float2 states (exact Q, Qd): strips lie M rows apart (no skew padding, see sdp_kernels.hip); a pair owns
-// nstrips * M rows plus room for the last strip's tail ramp and the chunk rounding of the last prefetch
-constexpr int STATE2_SLACK = 64 + 64;
-__host__ __device__ inline size_t state_rows2(int N, int M)
-{
-    return SDP_F2_DEPAD ? (size_t)((N + 63) / 64) * M + STATE2_SLACK : (size_t)((N + 63) / 64) * ((M + 63 + 63) / 64 * 64);
-}
+// State layout: the state of a (pair, strip) is a sequence of units of 32 steps (packed Q: 12288 B, float2: 16384 B);
+// unit u of (pair b, strip s) starts at (b * nstrips + s) * ps + u * us.  See "Skewed state addressing" in sdp_kernels.hip.
+constexpr int STATE_UNIT_STEPS = 32;
+constexpr unsigned STATEQ_UNIT_BYTES = 16 * 768, STATE2_UNIT_BYTES = 32 * 512;
+// (Sharing the ramp rows of neighbouring strips -- no skew padding -- was implemented in round 2 for both formats, measured
+// slower (partial-line writes) and removed in round 3; see DESIGN.md.)
+__host__ __device__ inline size_t state_rows2(int N, int M) { return (size_t)((N + 63) / 64) * ((M + 63 + 63) / 64 * 64); }
 
 // state geometry (shared by host and device)
 __host__ __device__ inline int state_nstrips(int N) { return (N + 63) / 64; }
@@ -173,6 +156,7 @@ __global__ void sdp_scores_x6_kernel(const float *zx, const float *zy, const flo
                                      int M, int D);
 __global__ void sdp_order_kernel(const int *lens, int *order, int B, int N, int M);
 __global__ void sdp_traceback_kernel(const float *grad, int *states, int *counts, const int *lens, int B, int N, int M, int cap);
+__global__ void sdp_traceback_cuda_kernel(const float *grad, int *states, int *counts, const int *lens, int B, int N, int M, int cap);
 }
 
 #endif  // SDP_KERNELS_H_

@@ -128,7 +128,13 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #ifndef SDP_NT
 #define SDP_NT 10
 #endif
-constexpr int AUX_ST_STORE = (SDP_NT & 1) ? 2 : 0, AUX_ST_LOAD = (SDP_NT & 2) ? 2 : 0;
+#ifndef SDP_AUX_ST_STORE   // explicit policy bits of the state stores (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+#define SDP_AUX_ST_STORE ((SDP_NT & 1) ? 2 : 0)
+#endif
+#ifndef SDP_AUX_ST_LOAD
+#define SDP_AUX_ST_LOAD ((SDP_NT & 2) ? 2 : 0)
+#endif
+constexpr int AUX_ST_STORE = SDP_AUX_ST_STORE, AUX_ST_LOAD = SDP_AUX_ST_LOAD;
 constexpr int AUX_IN_LOAD = (SDP_NT & 4) ? 2 : 0, AUX_OUT_STORE = (SDP_NT & 8) ? 2 : 0;
 constexpr bool ABL_NOSTORE = (SDP_ABL & 1) != 0;
 constexpr bool ABL_NOLOAD = (SDP_ABL & 2) != 0;
@@ -536,36 +542,40 @@ __device__ __forceinline__ void sweep(const Params &p)
         // step at which this lane meets the terminal cell (n-1, m-1) of the pair; -1 if never
         const int t_final = (s == nstrips - 1 && lane == rows - 1) ? (m - 1 + lane) : -1;
 
-        // skewed state addressing: one buffer descriptor per (pair, strip); a row (one step) is 64 x float2
-        // = 512 B, so step t, lane l lives at byte t*512 + l*8.  Step offsets go through the scalar
-        // offset operand, the lane offset is a per-lane constant.
-        // element offset of this (pair, strip) in a state buffer; one step is a row of 64 lanes
-        const size_t st_base = (b_st * p.nstrips_max + s) * p.tpad * 64;
-        // Q: 6 bytes per cell, two steps per lane and access: steps 2j, 2j+1 of lane l are the 12 bytes at
-        // j*768 + l*12, so one dwordx3 per lane moves two steps (768 B per wave access).
-        // Shared ramp rows (SDP_PACKED_DEPAD): like the float2 states the packed state carries no skew padding -- strip
-        // s+1's records start ceil(M/2) record rows after strip s's, so the tail ramp of strip s (steps t >= M, live
-        // lanes l > t - M) and the head ramp of strip s+1 (steps t - M, live lanes l <= t - M) fill complementary lanes
-        // of the same rows.  A record holds TWO steps of a lane, so the lane on the boundary of a row owns only half
-        // of its record (first step from one strip, second from the other): the forward sweep stores records whose
-        // two cells are inside the matrix whole, half-inside ones as 6 bytes (dword + short), others not at all.
-        const size_t stq_base = SDP_PACKED_DEPAD ? ((size_t)b_st * stateq_rows(p.N, p.M) + (size_t)s * stateq_pitch(p.M)) * 192
-                                                 : st_base * 3 / 2;   // in dwords
-        const unsigned q_bytes = SDP_PACKED_DEPAD ? (unsigned)(stateq_pitch(p.M) + STATEQ_SLACK) * 768u : (unsigned)p.tpad * 384u;
+        // Skewed state addressing.  The state of a (pair, strip) is a sequence of UNITS of 32 steps; a unit is contiguous
+        // (packed Q: 16 record rows of 768 B -- a record row holds two steps of every lane, 12 B per lane, so one
+        // dwordx3 per lane moves two steps; float2 states: 32 rows of 512 B, step t, lane l at t*512 + l*8).  Where
+        // unit u of (pair b, strip s) lives is given by two strides the host picks (sdp_api.hip::state_layout):
+        //     byte offset = (b * nstrips + s) * ps + u * us + (offset inside the unit)
+        //   * contiguous strips (default): ps = units per strip * unit bytes, us = unit bytes -- every strip is one stream;
+        //   * "marching" (-DSDP_STATE_MARCH=1): ps = unit bytes, us = B * nstrips * unit bytes -- unit u of ALL strips of
+        //     ALL pairs is one contiguous slab.  The pairs of a full batch advance in lockstep, so the chip as a whole
+        //     then writes (forward) or reads (reverse) one region of memory at a time instead of B * nstrips distant
+        //     streams.  A bare stream of the same read/write mix runs 4 % faster that way (tools/ubench/mix2.hip); the
+        //     sweeps measured no different (sdp_api.hip::state_layout), so it is not the default.
+        // One buffer descriptor per (pair, strip); the unit part of the offset is uniform and rides in the scalar
+        // offset operand (which the hardware does not range-check), the lane offset is a per-lane constant.
+        // (The descriptors' size is the largest one for which the out-of-range offset OOB still is out of range: whether or
+        // not the hardware adds the scalar offset before its range check, every state access below is accepted -- the
+        // host keeps a marching state below 2^31 bytes -- and nothing here relies on the check.)
+        constexpr unsigned ST_RECORDS = 0x7fffffffu;
+        const size_t ps_idx = b_st * p.nstrips_max + s;
         const unsigned q_lane = lane * 12;
-        __amdgpu_buffer_rsrc_t rs_q = make_rsrc(T::QIN == Q_PACKED ? (const void *)(p.qin + stq_base)
-                                                : (T::QOUT == Q_PACKED ? (const void *)(static_cast<uint32_t *>(p.dout) + stq_base) : (const void *)p.vout),
-                                                (T::QIN == Q_PACKED || T::QOUT == Q_PACKED) ? q_bytes : 0u);
+        __amdgpu_buffer_rsrc_t rs_q = make_rsrc(T::QIN == Q_PACKED ? (const void *)(reinterpret_cast<const char *>(p.qin) + ps_idx * p.st_ps)
+                                                : (T::QOUT == Q_PACKED ? (const void *)(static_cast<char *>(p.dout) + ps_idx * p.st_ps) : (const void *)p.vout),
+                                                (T::QIN == Q_PACKED || T::QOUT == Q_PACKED) ? ST_RECORDS : 0u);
+        // scalar offset of record row t_base/2 + g4 (g4 = 0, 4, 8, 12; t_base a multiple of the chunk length)
+        auto q_soff = [&](int t_base, int g4) { return (unsigned)(t_base >> 5) * p.st_us + (unsigned)((((t_base >> 1) & 15) + g4) * 768); };
         typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
         auto load_q = [&](int t_base, int g, unsigned *dst) {  // steps t_base + 2g, + 1
-            const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs_q, q_lane + (g & 3) * 768, (t_base / 2 + (g & ~3)) * 768, AUX_ST_LOAD);
+            const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs_q, q_lane + (g & 3) * 768, q_soff(t_base, g & ~3), AUX_ST_LOAD);
             const unsigned v0 = v[0], v1 = v[1], v2 = v[2];
             dst[0] = v0, dst[1] = v1, dst[2] = v2;
         };
-        auto store_q = [&](int t_base, int g, const unsigned *src, bool ok = true) {
+        auto store_q = [&](int t_base, int g, const unsigned *src) {
             u32x3 v;
             v[0] = src[0], v[1] = src[1], v[2] = src[2];
-            __builtin_amdgcn_raw_buffer_store_b96(v, rs_q, ok ? q_lane + (g & 3) * 768 : OOB, (t_base / 2 + (g & ~3)) * 768, AUX_ST_STORE);
+            __builtin_amdgcn_raw_buffer_store_b96(v, rs_q, q_lane + (g & 3) * 768, q_soff(t_base, g & ~3), AUX_ST_STORE);
             // A VALU instruction that overwrites a data register of a store wider than 64 bits in the very next
             // issue slot corrupts the stored value for part of the wave on gfx950 (seen: lanes 12-15 of every
             // 16).  The compiler only inserts the wait state for stores without a scalar offset register, so it
@@ -573,40 +583,35 @@ __device__ __forceinline__ void sweep(const Params &p)
             // it) and is ordered after the store as a memory operation.
             asm volatile("s_nop 1" : : "v"(v) : "memory");
         };
-        // float2 states (Qd, and Q in its exact form): one step is a 512-byte row: step t, lane l lives at byte
-        // t*512 + l*8.  Step offsets go through the scalar offset operand, the lane offset is a per-lane constant.
-        // The float2 states carry NO skew padding: the rows of strip s start M rows after those of strip s-1, so the
-        // 63 rows of its tail ramp (steps t >= M, where only the lanes l > t - M still sit on real cells) are the rows
-        // of the head ramp of strip s+1 (steps t' = t - M, live lanes l <= t') -- complementary halves of the same
-        // rows.  Cells outside the matrix are therefore never stored (store_f2's `ok`); loading them returns whatever
-        // the other strip put there, which every reader masks (a dead cell's weights are forced to 0).
-        const size_t st_base2 = SDP_F2_DEPAD ? ((size_t)b_st * state_rows2(p.N, p.M) + (size_t)s * p.M) * 64 : st_base;
-        const unsigned st_bytes = SDP_F2_DEPAD ? (unsigned)(p.M + STATE2_SLACK) * 512u : (unsigned)p.tpad * 512u;
+        // float2 states (Qd, and Q in its exact form).  Cells outside the matrix are stored like any other (their
+        // values are never used: every reader masks them).
         const unsigned st_lane = lane * 8;
-        __amdgpu_buffer_rsrc_t rs_d = make_rsrc(T::DIN ? (const void *)(p.din + st_base2)
-                                                       : (T::DOUT ? (const void *)(static_cast<float2 *>(p.dout) + st_base2) : (const void *)p.vout),
-                                                (T::DIN || T::DOUT) ? st_bytes : 0u);
-        __amdgpu_buffer_rsrc_t rs_qx = make_rsrc(T::QIN == Q_EXACT ? (const void *)(reinterpret_cast<const float2 *>(p.qin) + st_base2)
-                                                 : (T::QOUT == Q_EXACT ? (const void *)(static_cast<float2 *>(p.dout) + st_base2) : (const void *)p.vout),
-                                                 (T::QIN == Q_EXACT || T::QOUT == Q_EXACT) ? st_bytes : 0u);
+        __amdgpu_buffer_rsrc_t rs_d = make_rsrc(T::DIN ? (const void *)(reinterpret_cast<const char *>(p.din) + ps_idx * p.st2_ps)
+                                                       : (T::DOUT ? (const void *)(static_cast<char *>(p.dout) + ps_idx * p.st2_ps) : (const void *)p.vout),
+                                                (T::DIN || T::DOUT) ? ST_RECORDS : 0u);
+        __amdgpu_buffer_rsrc_t rs_qx = make_rsrc(T::QIN == Q_EXACT ? (const void *)(reinterpret_cast<const char *>(p.qin) + ps_idx * p.st2_ps)
+                                                 : (T::QOUT == Q_EXACT ? (const void *)(static_cast<char *>(p.dout) + ps_idx * p.st2_ps) : (const void *)p.vout),
+                                                 (T::QIN == Q_EXACT || T::QOUT == Q_EXACT) ? ST_RECORDS : 0u);
+        // scalar offset of row t_base + k8 (k8 = 0, 8, 16, 24)
+        auto f2_soff = [&](int t_base, int k8) { return (unsigned)(t_base >> 5) * p.st2_us + (unsigned)(((t_base & 31) + k8) * 512); };
         auto load_f2 = [&](__amdgpu_buffer_rsrc_t rs, int t_base, int k) {  // row t_base + k
-            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, st_lane + (k & 7) * 512, (t_base + (k & ~7)) * 512, AUX_ST_LOAD);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, st_lane + (k & 7) * 512, f2_soff(t_base, k & ~7), AUX_ST_LOAD);
             // NB: copy the elements to scalars first -- __builtin_bit_cast applied directly to a vector
             // element lvalue (v[1]) reads element 0 with this compiler.
             const unsigned lo = v[0], hi = v[1];
             return make_float2(__uint_as_float(lo), __uint_as_float(hi));
         };
-        auto store_f2 = [&](__amdgpu_buffer_rsrc_t rs, int t_base, int k, float2 qq, bool ok) {
+        auto store_f2 = [&](__amdgpu_buffer_rsrc_t rs, int t_base, int k, float2 qq) {
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             u32x2 v;
             v[0] = __float_as_uint(qq.x);
             v[1] = __float_as_uint(qq.y);
-            __builtin_amdgcn_raw_buffer_store_b64(v, rs, (ok || !SDP_F2_DEPAD) ? st_lane + (k & 7) * 512 : OOB, (t_base + (k & ~7)) * 512, AUX_ST_STORE);
+            __builtin_amdgcn_raw_buffer_store_b64(v, rs, st_lane + (k & 7) * 512, f2_soff(t_base, k & ~7), AUX_ST_STORE);
         };
         auto load_d = [&](int t_base, int k) { return load_f2(rs_d, t_base, k); };
         float2 qhold;  // forward: weights of the even step of the current pair of steps
-        // the state this pass produces, step t_base + k; `ok`: the lane's cell lies inside the matrix (float2 formats only)
-        auto store_state = [&](int t_base, int k, float2 qq, bool ok = true) {
+        // the state this pass produces, step t_base + k
+        auto store_state = [&](int t_base, int k, float2 qq) {
             if constexpr (T::QOUT == Q_PACKED) {
                 if ((k & 1) == 0) {
                     qhold = qq;
@@ -616,51 +621,24 @@ __device__ __forceinline__ void sweep(const Params &p)
                     store_q(t_base, k >> 1, w);
                 }
             } else if constexpr (T::QOUT == Q_EXACT) {
-                store_f2(rs_qx, t_base, k, qq, ok);
+                store_f2(rs_qx, t_base, k, qq);
             } else {
-                store_f2(rs_d, t_base, k, qq, ok);
+                store_f2(rs_d, t_base, k, qq);
             }
         };
 
         // packed state, forward: the two biased fields of a cell (bits of 1 + q * Q_SCALE) arrive per step; every
         // second step three byte-permutes assemble the 12-byte record of the pair and one dwordx3 store moves it
-        // `live`: the step's cell lies inside the matrix (always true in blocks that are wholly inside).  Half-inside
-        // records are remembered -- a lane has at most one that starts and one that ends per strip -- and written by
-        // flush_half_records() at the end of the block.
         unsigned qbits_x = 0, qbits_y = 0;
-        bool qlive0 = true;
-        unsigned half_off[2] = {OOB, OOB}, half_dw[2] = {0u, 0u}, half_sh[2] = {0u, 0u};   // [0] second half, [1] first half
-        auto store_state_bits = [&](int t_base, int k, unsigned fx, unsigned fy, bool live = true) {
+        auto store_state_bits = [&](int t_base, int k, unsigned fx, unsigned fy) {
             if ((k & 1) == 0) {
-                qbits_x = fx, qbits_y = fy, qlive0 = live;
+                qbits_x = fx, qbits_y = fy;
             } else {
                 unsigned w[3];
                 w[0] = __builtin_amdgcn_perm(qbits_y, qbits_x, 0x04020100u);
                 w[1] = __builtin_amdgcn_perm(fx, qbits_y, 0x05040201u);
                 w[2] = __builtin_amdgcn_perm(fy, fx, 0x06050402u);
-                if constexpr (SDP_PACKED_DEPAD) {
-                    store_q(t_base, k >> 1, w, qlive0 && live);
-                    const unsigned rec = q_lane + (unsigned)(k >> 1) * 768u;   // relative to the block's first record row
-                    const bool second = !qlive0 && live, first = qlive0 && !live;
-                    half_off[0] = second ? rec + 6u : half_off[0];   // bytes 6..11: short at +6, dword at +8
-                    half_sh[0] = second ? w[1] >> 16 : half_sh[0];
-                    half_dw[0] = second ? w[2] : half_dw[0];
-                    half_off[1] = first ? rec : half_off[1];         // bytes 0..5: dword at +0, short at +4
-                    half_dw[1] = first ? w[0] : half_dw[1];
-                    half_sh[1] = first ? (w[1] & 0xffffu) : half_sh[1];
-                } else {
-                    store_q(t_base, k >> 1, w);
-                }
-            }
-        };
-        auto flush_half_records = [&](int t_base) {
-            if constexpr (SDP_PACKED_DEPAD && T::QOUT == Q_PACKED) {
-                const int soff = (t_base / 2) * 768;
-                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)half_sh[0], rs_q, half_off[0], soff, AUX_ST_STORE);
-                __builtin_amdgcn_raw_buffer_store_b32(half_dw[0], rs_q, half_off[0] + 2u, soff, AUX_ST_STORE);
-                __builtin_amdgcn_raw_buffer_store_b32(half_dw[1], rs_q, half_off[1], soff, AUX_ST_STORE);
-                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)half_sh[1], rs_q, half_off[1] + 4u, soff, AUX_ST_STORE);
-                half_off[0] = half_off[1] = OOB;
+                store_q(t_base, k >> 1, w);
             }
         };
 
@@ -864,8 +842,6 @@ __device__ __forceinline__ void sweep(const Params &p)
         // Both forms produce identical bits (same 2^theta, exact power-of-two rescaling), so results do not depend on
         // which form a block ran in, on K, or on the batch.
         constexpr bool FWD_SUB = PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_WF && SDP_FWD_SUB;
-        static_assert(!(SDP_PACKED_DEPAD && PASS == PASS_FWD && !QX) || FWD_SUB,
-                      "the packed state without padding needs the block-wise forward sweep: build with -DSDP_PACKED_DEPAD=0");
         auto fwd_blocks = [&](int c, int t0) {
             if constexpr (FWD_SUB) {
                 int thr = lane + (sw ? 1 : 0);  // EDGE: the lane's cell is live at step t iff t >= thr
@@ -1021,13 +997,13 @@ __device__ __forceinline__ void sweep(const Params &p)
                                 float2 qq = make_float2(tq * u, tq * x);
                                 q_sharpen(qq.x, qq.y, d * rinv);
                                 if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); }
-                                else store_state(tb, j, qq, !EDGE || (unsigned)(tb + j - lane) < (unsigned)m);
+                                else store_state(tb, j, qq);
                             } else {
                                 // both weights with one packed multiply, their biased fields with one packed fma
                                 const f32x2 w = (f32x2){u, x} * (f32x2){tq, tq};
                                 const f32x2 f = __builtin_elementwise_fma(w, (f32x2){Q_SCALE, Q_SCALE}, (f32x2){1.0f, 1.0f});
                                 if constexpr (ABL_NOSTORE) { float fx = f[0], fy = f[1]; keep(fx); keep(fy); }
-                                else store_state_bits(tb, j, __float_as_uint(f[0]), __float_as_uint(f[1]), !EDGE || (unsigned)(tb + j - lane) < (unsigned)m);
+                                else store_state_bits(tb, j, __float_as_uint(f[0]), __float_as_uint(f[1]));
                             }
                             d = u;
                             x = ct * ssum;
@@ -1041,7 +1017,6 @@ __device__ __forceinline__ void sweep(const Params &p)
                             mx = max(mx, __float_as_uint(x));
                             hist[j] = pack2(__float_as_uint(x), (unsigned)R);
                         }
-                        if constexpr (EDGE && !QX) flush_half_records(tb);
                         if (__builtin_amdgcn_ballot_w64(mx > WF_HI || mn < WF_LO || mc > WF_FMAX) != 0) return -1;  // carry untouched
                         cy.xa = __builtin_amdgcn_frexp_mantf(x);
                         cy.xe = R + __builtin_amdgcn_frexp_expf(x);
@@ -1115,7 +1090,6 @@ __device__ __forceinline__ void sweep(const Params &p)
                             const float tq = ca * rinv;
                             {
                                 float2 qq = make_float2(tq * u, tq * l);
-                                const bool cell_in = !EDGE || (unsigned)col < (unsigned)m;
                                 // every build sharpens here: a block lands in this form when its scores are steep, and
                                 // steep scores are where paths saturate -- a packed weight left at 1 - 2^-23 instead of 1
                                 // loses 1.7e-8 of E per step on average (7e-5 over the 4096 steps of a 2048 x 2048
@@ -1123,9 +1097,9 @@ __device__ __forceinline__ void sweep(const Params &p)
                                 // blocks, not chunks), so results stay bit-identical across wave counts.
                                 q_sharpen(qq.x, qq.y, d * rinv);
                                 if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); }
-                                else if constexpr (QX) store_state(tb, j, qq, cell_in);
+                                else if constexpr (QX) store_state(tb, j, qq);
                                 else store_state_bits(tb, j, __float_as_uint(__builtin_fmaf(qq.x, Q_SCALE, 1.0f)),
-                                                      __float_as_uint(__builtin_fmaf(qq.y, Q_SCALE, 1.0f)), cell_in);
+                                                      __float_as_uint(__builtin_fmaf(qq.y, Q_SCALE, 1.0f)));
                             }
                             const float an = ct * ssum;
                             float na = __builtin_amdgcn_frexp_mantf(an);
@@ -1142,7 +1116,6 @@ __device__ __forceinline__ void sweep(const Params &p)
                             hist[j] = pack2(__float_as_uint(na), (unsigned)ne);
                             if constexpr (EDGE) vt_keep = (t == t_final) ? hist[j] : vt_keep;
                         }
-                        if constexpr (EDGE && !QX) flush_half_records(tb);
                         // publish in one frame whenever the 16 values fit (exact rescaling to the exponent of the last
                         // one), so that the strip below can use the windowed form; only the publishing lane matters
                         if (has_succ) {
@@ -1416,7 +1389,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                     if constexpr (ABL_NOMATH) {
                         if constexpr (T::QOUT != Q_NONE || T::DOUT) {
                             float2 qq = make_float2(in0[k], T::QIN != Q_NONE ? q0.x + q0.y : in1[k]);
-                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq, inside);
+                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
                         }
                         if constexpr (T::SOUT > 0) lo[k] = q0.x + q0.y + (T::DIN ? q1.x + q1.y : 0.f) + (T::SIN > 0 ? in0[k] : 0.f);
                         hist[k] = 0;
@@ -1447,7 +1420,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         {
                             float2 qq = make_float2(tq * u, tq * l);
                             if constexpr (QX) q_sharpen(qq.x, qq.y, d * rinv);
-                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq, inside);
+                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
                         }
                         const float an = ct * ssum;
                         float na = __builtin_amdgcn_frexp_mantf(an);
@@ -1479,7 +1452,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         const double v = ((double)th + mx) + (double)fast_log(ssum);
                         {
                             float2 qq = make_float2(ex * inv, ey * inv);
-                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq, inside);
+                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
                         }
                         cy.b = up;
                         cy.a = (!EDGE || (col >= 0 && !dead)) ? v : 0.0;
@@ -1510,7 +1483,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         const double vd = (double)zt + tot;
                         {
                             float2 qq = make_float2((float)(qx * (a0 - tot)), (float)(qy * (a2 - tot)));
-                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq, inside);
+                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
                         }
                         cy.b = up;
                         cy.a = inside ? vd : 0.0;
@@ -1663,7 +1636,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         {
                             float2 qq = make_float2(tq * u, tq * x);
                             if constexpr (QX) q_sharpen(qq.x, qq.y, d * rinv);
-                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq, !EDGE || (unsigned)(t0 + k - lane) < (unsigned)m);
+                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
                         }
                         d = u;
                         x = ct * ssum;
@@ -1877,8 +1850,11 @@ extern "C" __global__ void __launch_bounds__(256) sdp_order_kernel(const int *le
 // the wave moves them to the front.  The window is filled through python's index wrap, so the top row / left column
 // (floor values, reads that wrap to the opposite edge) and already-wrapped walks use the same loop.
 // ----------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(64) sdp_traceback_kernel(const float *grad, int *states, int *counts,
-                                                                      const int *lens, int B, int N, int M, int cap)
+// RULE 0: the CPU reference's walk (nw.py:401-444: stop when ALL three neighbours are off the matrix, sentinel -1e5,
+// python's index wrap).  RULE 1: the walk of the reference's GPU classes (nw_cuda.py:273-317, sw_cuda.py:283-327: stop
+// as soon as ANY neighbour is off the matrix -- or holds the sentinel -1e10; no wrap, never an IndexError).
+template <int RULE>
+__device__ __forceinline__ void traceback_walk(const float *grad, int *states, int *counts, const int *lens, int B, int N, int M, int cap)
 {
     constexpr int TW = SDP_TB_WINDOW, TWL = TW == 64 ? 6 : 5;   // window edge (32 or 64 cells)
     __shared__ float tile[TW * TW];
@@ -1893,7 +1869,7 @@ extern "C" __global__ void __launch_bounds__(64) sdp_traceback_kernel(const floa
     }
     const float *g = grad + (size_t)b * N * M;
     int *out = states + (size_t)b * cap * 3;
-    const float floor_v = -100000.f;
+    const float floor_v = RULE ? -1e10f : -100000.f;
     // A walk has at most n + m - 1 steps: every step lowers i or j, a step that lowers only i needs i > 0, and j never
     // goes below 0.  The API passes cap = N + M + 2.
     if (cap < n + m) {
@@ -1934,7 +1910,7 @@ extern "C" __global__ void __launch_bounds__(64) sdp_traceback_kernel(const floa
     int i = n - 1, j = m - 1;
     record(1, i, j);
     while (true) {
-        if (i <= 0 && j <= 0) break;   // all three are the floor value: the reference's stop rule
+        if (RULE ? (i <= 0 || j <= 0) : (i <= 0 && j <= 0)) break;   // the reference's stop rule (all three / any one off the matrix)
         const int r0 = i - (TW - 1), c0 = j - (TW - 1);
         __syncthreads();  // one wave: orders the LDS reads of the old window before these writes
         {
@@ -1965,7 +1941,12 @@ extern "C" __global__ void __launch_bounds__(64) sdp_traceback_kernel(const floa
                 const float bv1 = c1 ? diag : left;
                 const bool c2 = all(upper > bv1);
                 const float bv = c2 ? upper : bv1;
-                if (all(bv == floor_v)) {   // only then can all three be the floor value
+                if constexpr (RULE) {
+                    if (all(left == floor_v || diag == floor_v || upper == floor_v)) {   // a stored value equal to the sentinel stops the walk too
+                        stop = true;
+                        break;
+                    }
+                } else if (all(bv == floor_v)) {   // only then can all three be the floor value
                     if (all(left == floor_v && diag == floor_v && upper == floor_v)) {
                         stop = true;
                         break;
@@ -1979,7 +1960,7 @@ extern "C" __global__ void __launch_bounds__(64) sdp_traceback_kernel(const floa
             while (ti >= 1 && tj >= 1) {
                 const int vi = r0 + ti, vj = c0 + tj;
                 const bool fl = vi <= 0, fu = vj <= 0;
-                if (fl && fu) {
+                if (RULE ? (fl || fu) : (fl && fu)) {
                     stop = true;
                     break;
                 }
@@ -1990,7 +1971,7 @@ extern "C" __global__ void __launch_bounds__(64) sdp_traceback_kernel(const floa
                 const float *p = tile + ti * TW + tj;
                 const float t0 = p[-TW], t1 = p[-TW - 1], t2 = p[-1];
                 const float left = fl ? floor_v : uni(t0), diag = uni(t1), upper = fu ? floor_v : uni(t2);
-                if (left == floor_v && diag == floor_v && upper == floor_v) {
+                if (RULE ? (left == floor_v || diag == floor_v || upper == floor_v) : (left == floor_v && diag == floor_v && upper == floor_v)) {
                     stop = true;
                     break;
                 }
@@ -2042,6 +2023,17 @@ extern "C" __global__ void __launch_bounds__(64) sdp_traceback_kernel(const floa
         }
     }
     if (lane == 0) counts[b] = cnt;
+}
+
+extern "C" __global__ void __launch_bounds__(64) sdp_traceback_kernel(const float *grad, int *states, int *counts,
+                                                                      const int *lens, int B, int N, int M, int cap)
+{
+    traceback_walk<0>(grad, states, counts, lens, B, N, M, cap);
+}
+extern "C" __global__ void __launch_bounds__(64) sdp_traceback_cuda_kernel(const float *grad, int *states, int *counts,
+                                                                           const int *lens, int B, int N, int M, int cap)
+{
+    traceback_walk<1>(grad, states, counts, lens, B, N, M, cap);
 }
 
 // ----------------------------------------------------------------------------------

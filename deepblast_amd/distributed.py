@@ -198,6 +198,11 @@ def pack_paths(states, counts, M):
     s = torch.where(valid[..., None], s, torch.zeros_like(s))   # rows past the count are uninitialised memory
     if s.numel() and int(s[..., 0].max()) >= 1 << (31 - jb - 2):
         raise ValueError("traceback row index does not fit the packed word")
+    if s.numel() and int(s[..., :2].min()) < 0:
+        # the CPU-rule walk reproduces Python's negative-index wrap (nw.py:423) on matrices that are not alignment
+        # matrices; such coordinates have no place in the packed word
+        raise ValueError("a traceback walk wrapped around an edge of its matrix (negative coordinates): gather='paths' "
+                         "cannot carry it -- gather E instead, or use traceback_rule='cuda'")
     word = (s[..., 0] << (jb + 2)) | (s[..., 1] << 2) | s[..., 2]
     head = torch.stack([counts.to(torch.int64), torch.full_like(counts, jb, dtype=torch.int64)], dim=1)
     return torch.cat([head, word], dim=1).to(torch.int32)

@@ -127,19 +127,21 @@ class _DecodeLoss(torch.autograd.Function):
             sign = 1.0 if kind == PATH else -1.0
             scale = torch.where(per_pair > 0, sign / (per_pair * B), torch.zeros_like(per_pair))
         ctx.save_for_backward(Q, E, first, G, lens_loss, scale.to(torch.float32))
-        ctx.others = (kind, variant, lens_dp)
+        ctx.others = (kind, variant, lens_dp, lens_dp is lens_loss)   # (saved tensors come back as new objects: remember the identity)
         ctx.mark_non_differentiable(E)
         return (per_pair.sum() / B).to(torch.float32), E
 
     @staticmethod
     def backward(ctx, gout, _gE):
         Q, E, first, G, lens_loss, scale = ctx.saved_tensors
-        kind, variant, lens_dp = ctx.others
+        kind, variant, lens_dp, same_lens = ctx.others
         eng = get_engine()
         sc = (scale * gout.to(torch.float32)).contiguous()
         # the loss masks with its own lengths; the DP sweeps use theirs (None = full padded matrix, as the reference)
-        if lens_dp is None and lens_loss is not None:
-            # cells outside a pair's block must not seed the sweep: fold the loss's lengths into the mask
+        if lens_loss is not None and not same_lens:
+            # cells outside the LOSS's block must not seed the sweep (the kernel masks with the DP's lengths only): fold
+            # the loss's lengths into the mask -- unless both are the same tensor (decode_loss passes one object when
+            # `lengths` equals (x_len, y_len), the usual case)
             B, N, M = E.shape
             ii = torch.arange(N, device=E.device).view(1, N, 1) < lens_loss[:, 0].view(B, 1, 1)
             jj = torch.arange(M, device=E.device).view(1, 1, M) < lens_loss[:, 1].view(B, 1, 1)
@@ -162,5 +164,12 @@ def decode_loss(decoder, loss, theta, A, first, x_len, y_len, G, lengths=None):
     variant = SW if isinstance(decoder, SmithWatermanDecoder) else NW
     B = theta.shape[0]
     lens_loss = _lens(x_len, y_len, B, theta.device)
-    lens_dp = None if lengths is None else get_engine()._lens(lengths, B, theta.device)
+    lens_dp = None
+    if lengths is not None:
+        same = False
+        if not isinstance(lengths, torch.Tensor) and not isinstance(x_len, torch.Tensor) and not isinstance(y_len, torch.Tensor):
+            import numpy as _np
+            la = _np.asarray(lengths)
+            same = la.shape == (B, 2) and _np.array_equal(la[:, 0], _np.asarray(x_len)) and _np.array_equal(la[:, 1], _np.asarray(y_len))
+        lens_dp = lens_loss if (same and lens_loss is not None) else get_engine()._lens(lengths, B, theta.device)
     return _DecodeLoss.apply(theta, A, first, G, lens_loss, lens_dp, loss.kind, variant)

@@ -49,10 +49,10 @@ class _Scores(torch.autograd.Function):
         zx, zy, gx, gy, theta, A = ctx.saved_tensors
         out = [None, None, None, None]
         if g_theta is not None:
-            ds = g_theta * (1.0 - torch.exp(-theta))          # sigmoid(s) = 1 - exp(-softplus(s))
+            ds = g_theta * (-torch.expm1(-theta))            # sigmoid(s) = 1 - exp(-softplus(s)); expm1: no cancellation for small theta
             out[0], out[1] = torch.bmm(ds, zy), torch.bmm(ds.transpose(1, 2), zx)
         if g_A is not None:
-            ds = g_A * (1.0 - torch.exp(A))                   # 1 - sigmoid(s) = 1 - exp(logsigmoid(s))
+            ds = g_A * (-torch.expm1(A))                      # 1 - sigmoid(s) = 1 - exp(logsigmoid(s))
             out[2], out[3] = torch.bmm(ds, gy), torch.bmm(ds.transpose(1, 2), gx)
         return tuple(out)
 

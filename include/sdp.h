@@ -49,8 +49,8 @@
  *   - Return: 0 ok; negative = SDP_E_* below; positive = hipError_t.  Nothing is
  *     thrown across the boundary.  sdp_last_error_string() is thread-local.
  *   - Re-entrant: calls from several threads / on several streams may overlap.  Process-wide state is limited
- *     to a per-thread error string and one 64-byte block of host-pinned status words per device (created on
- *     the first launch there) through which a kernel reports a strip hand-off that timed out: such a launch's
+ *     to a per-thread error string and one 64-byte block of host-pinned status words per device (created by
+ *     sdp_init or on the first launch there, published under a lock and read through atomics) through which a kernel reports a strip hand-off that timed out: such a launch's
  *     results are invalid, and the NEXT call on that device (or sdp_device_status) returns SDP_E_HANDOFF once.
  *     There is no tuning state: a wave-count override travels with the call (SDP_WAVES).
  */
@@ -64,7 +64,7 @@
 extern "C" {
 #endif
 
-#define SDP_VERSION 100 /* 0.1.0 */
+#define SDP_VERSION 101 /* 0.1.1: + sdp_init, sdp_traceback_rule_i32 */
 
 #define SDP_NW 0
 #define SDP_SW 1
@@ -123,8 +123,12 @@ int sdp_adjoint_backward_f32(const float *E, const float *state, const float *st
 /* The score tensors the DP reads (reference: NeuralAligner.forward / .score, deepblast/alignment.py:122-123, 134-135:
  *   theta = F.softplus(torch.einsum('bid,bjd->bij', zx, zy));  A = F.logsigmoid(torch.einsum('bid,bjd->bij', gx, gy))).
  * zx, gx: (B,N,D); zy, gy: (B,M,D); theta, A: (B,N,M); all fp32, contiguous.  gx, gy and A may be NULL together
- * (theta only).  One launch: batched fp32 GEMM on the matrix cores (f32 MFMA, exact fp32 products and sums) with the
- * activation applied to the accumulators. */
+ * (theta only).  One launch: batched GEMM on the matrix cores with the activation applied to the accumulators.  Two
+ * kernels, chosen per call: D a multiple of 16 and 16-byte aligned embeddings take the bf16 pipe with every fp32 operand
+ * cut into three exact bf16 pieces and six piece products per k (the dropped pairs are <= 2^-23 of a product: fp32
+ * accuracy, measured error vs a float64 einsum 1.9e-7 at D = 512, the same as torch's fp32 einsum); anything else takes
+ * the f32-input MFMA (exact fp32 products and sums).  Accumulation is fp32 in both.  Inputs must be finite: in the
+ * three-piece kernel an Inf operand gives NaN (Inf - Inf in the cut) where the f32 kernel and torch give Inf. */
 int sdp_scores_f32(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
                    int M, int D, int device, void *stream);
 
@@ -136,6 +140,15 @@ int sdp_scores_f32(const float *zx, const float *zy, const float *gx, const floa
 int sdp_traceback_capacity(int N, int M);
 int sdp_traceback_i32(const float *grad, int32_t *states, int32_t *counts, int B, int N, int M,
                       const int32_t *lens, int device, void *stream);
+/* The same with the walk rule chosen: SDP_TRACEBACK_CPU = the CPU classes' walk (deepblast/nw.py:401-444, sw.py:328-371:
+ * stop when ALL three neighbours are off the matrix, sentinel -1e5, Python's negative-index wrap at the edges; what
+ * sdp_traceback_i32 does), SDP_TRACEBACK_CUDA = the walk of the classes this library replaces (deepblast/nw_cuda.py:
+ * 273-317, sw_cuda.py:283-327: stop as soon as ANY neighbour is off the matrix or holds the sentinel -1e10; never
+ * wraps, counts[b] is never -1).  The two differ when a walk reaches row 0 or column 0 before the other. */
+#define SDP_TRACEBACK_CPU 0
+#define SDP_TRACEBACK_CUDA 1
+int sdp_traceback_rule_i32(const float *grad, int32_t *states, int32_t *counts, int B, int N, int M,
+                           const int32_t *lens, int rule, int device, void *stream);
 
 /* Masked alignment losses (reference: deepblast/losses.py -- MatrixCrossEntropy :9-48, SoftPathLoss :51-79,
  * SoftAlignmentLoss :82-118; evaluated there with a Python loop over the batch, trainer.py:154-171).
@@ -174,6 +187,11 @@ int sdp_comm_init(void **comm, const void *id128, int rank, int world, int devic
 int sdp_comm_all_gather_f32(void *comm, const float *send, float *recv, size_t count_per_rank, void *stream);
 int sdp_comm_destroy(void *comm);
 const char *sdp_comm_last_error_string(void);
+
+/* Optional: creates the per-device status words and raises the kernels' dynamic-LDS limit on `device` now instead of
+ * inside the first launch there (both are host-side, once per device / per calling thread).  Call it before capturing
+ * launches into a hipGraph: an allocation is not allowed inside a capture. */
+int sdp_init(int device);
 
 /* Runs a few-microsecond device check of the cross-lane (DPP) and buffer-addressing
  * behaviour the kernels rely on.  Synchronises the device.  0 = ok. */

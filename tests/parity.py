@@ -43,14 +43,16 @@ def oracle_all(theta, A, Et, Z, variant, ZA=None, omp=True):
     return out
 
 
-def oracle_lens(theta, A, Et, Z, variant, lens):
-    """Lengths-aware semantics = per-item sliced calls (deepblast/alignment.py:165-170)."""
+def oracle_lens(theta, A, Et, Z, variant, lens, threads=1):
+    """Lengths-aware semantics = per-item sliced calls (deepblast/alignment.py:165-170).  `threads` > 1 runs the
+    items on a thread pool (the oracle is a C call that releases the GIL): whole config-sized batches in seconds."""
     B, N, M = theta.shape
     out = {"Vt": np.zeros(B, np.float32), "E": np.zeros((B, N, M), np.float32)}
     if Z is not None:
         out["Ed"] = np.zeros((B, N, M), np.float32)
         out["Vtd"] = np.zeros(B, np.float32)
-    for b in range(B):
+
+    def one(b):
         n, m = int(lens[b, 0]), int(lens[b, 1])
         r = oracle_all(np.ascontiguousarray(theta[b:b + 1, :n, :m]), np.ascontiguousarray(A[b:b + 1, :n, :m]),
                        None if Et is None else Et[b:b + 1],
@@ -60,7 +62,25 @@ def oracle_lens(theta, A, Et, Z, variant, lens):
         if Z is not None:
             out["Ed"][b, :n, :m] = r["Ed"][0]
             out["Vtd"][b] = r["Vtd"][0]
+
+    if threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(one, range(B)))
+    else:
+        for b in range(B):
+            one(b)
     return out
+
+
+def oracle_chunked(theta, A, Et, Z, variant, chunk=32):
+    """oracle_all over a large padded batch in chunks of `chunk` pairs (the reference-layout Q of 32 pairs of
+    1024 x 1024 is 400 MB in fp32; the OpenMP oracle spreads a chunk over the host's cores)."""
+    parts = []
+    for lo in range(0, theta.shape[0], chunk):
+        sl = slice(lo, lo + chunk)
+        parts.append(oracle_all(theta[sl], A[sl], None if Et is None else Et[sl], None if Z is None else Z[sl], variant, omp=True))
+    return {k: np.concatenate([p_[k] for p_ in parts]) for k in parts[0]}
 
 
 def engine_all(theta, A, Et, Z, variant, lens=None, ZA=None, device="cuda"):

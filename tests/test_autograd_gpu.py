@@ -202,6 +202,44 @@ def test_batched_device_traceback_matches_host(golden_dir):
     print(f"traceback B={B} {N}x{M}: device {t_dev * 1e3:.2f} ms, host loop (extrapolated) {t_host * 1e3:.0f} ms")
 
 
+def test_device_traceback_cuda_rule(golden_dir):
+    """sdp_traceback_rule_i32(SDP_TRACEBACK_CUDA): the walk of the reference's GPU classes (nw_cuda.py:273-317) on the
+    device -- integer-identical to the fixtures from the real classes, to the host walk on arbitrary matrices (shapes
+    around the 32-cell window, per-pair lengths, sentinel values inside the matrix), and never -1."""
+    import torch
+    from deepblast_amd._dp import traceback as host_traceback
+    from deepblast_amd._engine import get_engine
+    dec = NeedlemanWunschDecoder("softmax", traceback_rule="cuda")
+    d = np.load(os.path.join(golden_dir, "g12_tracebacks_cuda.npz"))
+    for k in range(int(d["count"])):
+        g = torch.from_numpy(d[f"t{k}_grad"].astype(np.float32)).cuda()[None]
+        assert dec.traceback_batch(g)[0] == [tuple(r) for r in d[f"t{k}_nw"].tolist()], k
+    rng = np.random.default_rng(12)
+    n_diff = 0
+    for (N, M) in [(1, 1), (1, 9), (9, 1), (2, 2), (31, 33), (32, 32), (33, 31), (64, 65), (5, 200), (200, 5), (150, 97), (70, 300)]:
+        B = 24
+        g = rng.normal(size=(B, N, M)).astype(np.float32)
+        g[B // 3: 2 * B // 3] = np.abs(g[B // 3: 2 * B // 3])
+        g[2 * B // 3:][rng.random((B - 2 * B // 3, N, M)) < 0.05] = -1e10            # the cuda rule's sentinel inside the matrix
+        for b in range(0, B, 4):
+            for k in range(min(N, M)):
+                g[b, N - 1 - k, M - 1 - k] += 5.0
+        lens = np.stack([rng.integers(1, N + 1, B), rng.integers(1, M + 1, B)], axis=1).astype(np.int32)
+        for ln in (None, lens):
+            states, counts = get_engine().traceback(torch.from_numpy(g).cuda(), None if ln is None else torch.from_numpy(ln).cuda(), rule="cuda")
+            states, counts = states.cpu().numpy(), counts.cpu().numpy()
+            assert (counts > 0).all()
+            for b in range(B):
+                n, m = (N, M) if ln is None else ln[b]
+                want = host_traceback(g[b, :n, :m], "cuda")
+                assert [tuple(int(v) for v in r) for r in states[b, :counts[b]]] == want, (N, M, b)
+                try:
+                    n_diff += want != host_traceback(g[b, :n, :m])
+                except IndexError:
+                    n_diff += 1
+    assert n_diff > 0
+
+
 def test_device_traceback_on_arbitrary_matrices_matches_host_walk():
     """The windowed walk against the host walk on matrices that are NOT alignment matrices: random values send the walk
     along edges, through python's index wrap (nw.py:423) and off the matrix (IndexError -> count -1); entries equal to

@@ -36,6 +36,28 @@ def test_traceback_matches_reference_fixtures(golden_dir):
     assert n_ok >= 15
 
 
+def test_cuda_rule_traceback_matches_the_gpu_classes_fixtures(golden_dir):
+    """traceback_rule="cuda": the walk of the classes this package replaces (deepblast/nw_cuda.py:273-317,
+    sw_cuda.py:283-327 -- stop when ANY neighbour is off the matrix, sentinel -1e10).  Fixtures: what the real
+    classes' traceback returned (oracle/gen_golden_tb_cuda.py)."""
+    d = np.load(os.path.join(golden_dir, "g12_tracebacks_cuda.npz"))
+    n_diff = 0
+    for kind in ("nw", "sw"):
+        dec, cpu = DEC[kind]("softmax", traceback_rule="cuda"), DEC[kind]("softmax")
+        assert cpu.traceback_rule == "cpu"
+        for k in range(int(d["count"])):
+            g = torch.from_numpy(d[f"t{k}_grad"])
+            got = dec.traceback(g)
+            assert np.array_equal(np.array(got).reshape(-1, 3), d[f"t{k}_{kind}"]), (kind, k)
+            try:
+                n_diff += got != cpu.traceback(g)
+            except IndexError:
+                n_diff += 1   # the CPU rule walks off this matrix; the cuda rule never does
+    assert n_diff > 0   # the fixtures do exercise the difference between the two rules
+    with pytest.raises(ValueError):
+        NeedlemanWunschDecoder("softmax", traceback_rule="gpu")
+
+
 @pytest.mark.parametrize("kind", ["nw", "sw"])
 def test_known_answer_traceback(golden_dir, fake, kind):
     """test_nw.py:43-54 / test_sw.py:42-52: decode the 5x4 fixture end to end (fp32 path)."""

@@ -1,4 +1,3 @@
 #!/bin/bash
-OUT=gpurun_out/round_r02x; mkdir -p $OUT; export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_sc -o sc -- python bench.py --mode scores+dp --steps 10 --warmup 2 --no-cpu-baseline < /dev/null > $OUT/bench_sc.json 2> $OUT/sc.err
-head -4 $OUT/prof_sc/sc_kernel_stats.csv | cut -c1-140; tail -1 $OUT/bench_sc.json | cut -c1-160
+OUT=gpurun_out/r03a; mkdir -p $OUT; export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > $OUT/pytest2.txt; cat $OUT/pytest2.txt
