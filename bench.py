@@ -51,6 +51,7 @@ def parse():
                          "train-mce-fused: the same as one op, the loss gradient seeding the adjoint sweep inside the kernel")
     ap.add_argument("--D", type=int, default=512, help="embedding width of --mode scores+dp (reference default n_embed)")
     ap.add_argument("--gather", choices=["vt", "e", "paths", "none"], default="vt")
+    ap.add_argument("--e-chunks", type=int, default=4, help="pieces of the backward sweep / E gather when E is gathered (1 = one collective after the sweep)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs in the CPU-baseline sample")
     return ap.parse_args()
@@ -187,7 +188,7 @@ def main():
     A = torch.from_numpy(A_np).to(dev)
     Zl = torch.from_numpy(datagen.normal(7, (B, N, M))).to(dev) if args.mode == "train" else None
     dec = (NeedlemanWunschDecoder if args.variant == "nw" else SmithWatermanDecoder)("softmax")
-    aligner = ShardedAligner(dec, gather=args.gather if world > 1 else "none")
+    aligner = ShardedAligner(dec, gather=args.gather if world > 1 else "none", e_chunks=args.e_chunks)
     eng = get_engine()
     timer = KernelTimer()
     eng.launch_hook = None if os.environ.get("BENCH_NO_KERNEL_EVENTS") else timer   # (experiment: cost of the event pairs)
@@ -265,12 +266,13 @@ def main():
     timer.enabled = False
     # N > 1: the same job with the expected-alignment matrices gathered as well (report scaling with
     # and without the E gather); a secondary figure, never `value`
-    e_gather = None
+    e_gather = e_gather_one = None
     # (a secondary figure must not cost the primary one: an error here -- the same on every rank, e.g. out of memory for
     # the gathered E -- is reported on stderr and the line goes out without that field)
-    def secondary(kind):
+    def secondary(kind, e_chunks=None):
         try:
             aligner.gather = kind
+            aligner.e_chunks = args.e_chunks if e_chunks is None else e_chunks
             step()
             dt_s, _ = timed(min(args.steps, 5))
             return dt_s / min(args.steps, 5)
@@ -279,9 +281,11 @@ def main():
             return None
         finally:
             aligner.gather = args.gather
+            aligner.e_chunks = args.e_chunks
 
     if world > 1 and args.mode == "fwdbwd" and args.gather != "e" and not os.environ.get("BENCH_NO_SECONDARY"):
-        e_gather = secondary("e")
+        e_gather = secondary("e")                 # backward sweep + gather in --e-chunks pieces
+        e_gather_one = secondary("e", e_chunks=1) if args.e_chunks > 1 else None   # one collective after the sweep
     # ... and with the tracebacks gathered instead (device walk + (N+M+4) int32 per pair over the wire)
     paths_gather = None
     if world > 1 and args.mode == "fwdbwd" and args.gather != "paths" and not os.environ.get("BENCH_NO_SECONDARY"):
@@ -364,11 +368,32 @@ def main():
                 line["scores_roofline"] = {"bound": "mfma", "kernel": "sdp_scores_kernel", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "traffic": None,
                                            "frac": tf / 157.3, "dtype": "f32 (v_mfma_f32_32x32x2_f32)", "D": args.D,
                                            "launch_ms": ms["sdp_scores_kernel"], "flops_per_launch": flops}
+        if args.mode == "scores+dp":
+            # the stated baseline for the scores: the reference's own two lines (alignment.py:122-123) as PyTorch runs
+            # them on this box (rocBLAS/hipBLASLt batched GEMM + elementwise kernels), same inputs, outside the timed region
+            import torch.nn.functional as F
+
+            def ref_scores():
+                return (F.softplus(torch.einsum('bid,bjd->bij', emb[0], emb[1])),
+                        F.logsigmoid(torch.einsum('bid,bjd->bij', emb[2], emb[3])))
+            ref_scores()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                ref_scores()
+            e1.record()
+            torch.cuda.synchronize()
+            line["scores_torch_baseline"] = {"ms": e0.elapsed_time(e1) / 5, "what": "F.softplus(torch.einsum('bid,bjd->bij', zx, zy)), "
+                                             "F.logsigmoid(torch.einsum(...gx, gy)) (deepblast/alignment.py:122-123), fp32, this box"}
         if line["roofline"] is None:
             line["roofline"] = line.get("scores_roofline")
         if e_gather is not None:
             line["with_e_gather"] = {"ms_per_step": e_gather * 1e3, "value": world * per_step_updates / e_gather,
-                                     "bytes_into_each_gpu": (world - 1) * B * N * M * 4}
+                                     "bytes_into_each_gpu": (world - 1) * B * N * M * 4,
+                                     "overlap": "chunked" if args.e_chunks > 1 else "none", "e_chunks": args.e_chunks}
+            if e_gather_one is not None:
+                line["with_e_gather"]["one_collective_ms_per_step"] = e_gather_one * 1e3
         if paths_gather is not None:
             line["with_paths_gather"] = {"ms_per_step": paths_gather * 1e3, "value": world * per_step_updates / paths_gather,
                                          "bytes_into_each_gpu": (world - 1) * B * (N + M + 4) * 4}

@@ -123,22 +123,44 @@ class HipEngine:
         _lib.check(rc, "sdp_forward_f32")
         return Vt, state
 
-    def backward(self, Et, state, shape, variant, lens=None, exact_state=False):
+    def state_pair_bytes(self, N, M, exact_state=False):
+        """Bytes one pair occupies in the (contiguous) state buffer: pair b's records start b times this into it."""
+        f = self.lib.sdp_state_d_bytes if exact_state else self.lib.sdp_state_bytes
+        return f(2, N, M) - f(1, N, M)
+
+    def backward(self, Et, state, shape, variant, lens=None, exact_state=False, pair_range=None, out=None):
         """-> E (B,N,M).  Replaces _backward_pass_kernel (nw_cuda.py:98-102).
 
-        exact_state: `state` came from forward(..., exact_state=True)."""
+        exact_state: `state` came from forward(..., exact_state=True).
+        pair_range=(lo, hi), out=(B,N,M) tensor: sweep only pairs lo..hi-1 of the batch, writing out[lo:hi] (the
+        other rows of `out` are not touched) -- the backward sweep of a batch in pieces, so that a collective on
+        piece k can run under the sweep of piece k+1 (distributed.py).  Needs lens=None (a pair's state is then
+        a fixed-size contiguous record, and there is no launch order in the buffer's tail)."""
         dev = self._dev(state)
         B, N, M = shape
         if Et.device != state.device:
             raise ValueError(f"Et is on {Et.device}, expected {state.device}")
         Et = Et.to(torch.float32).expand(B).contiguous()
         lens = self._lens(lens, B, state.device)
-        E = torch.empty((B, N, M), dtype=torch.float32, device=state.device)
+        E = torch.empty((B, N, M), dtype=torch.float32, device=state.device) if out is None else out
+        if tuple(E.shape) != (B, N, M) or E.dtype != torch.float32 or not E.is_contiguous() or E.device != state.device:
+            raise ValueError("out must be a contiguous float32 (B, N, M) tensor on the state's device")
+        lo, hi = (0, B) if pair_range is None else pair_range
+        if pair_range is not None:
+            if lens is not None:
+                raise ValueError("pair_range needs lens=None")
+            if not (0 <= lo < hi <= B):
+                raise ValueError(f"pair_range {pair_range} outside the batch of {B}")
+        st_ptr = state.data_ptr() + lo * self.state_pair_bytes(N, M, exact_state or self._always_exact(N, M))
         with torch.cuda.device(dev), self._bracket("sdp_bwd_kernel"):
-            rc = self.lib.sdp_backward_f32(_ptr(Et), _ptr(state), _ptr(E), B, N, M, _ptr(lens),
+            rc = self.lib.sdp_backward_f32(Et.data_ptr() + 4 * lo, st_ptr, E.data_ptr() + 4 * lo * N * M, hi - lo, N, M, _ptr(lens),
                                            self._v(1, variant) | (EXACT_STATE if exact_state else 0), dev, self._stream(dev))
         _lib.check(rc, "sdp_backward_f32")
         return E
+
+    def _always_exact(self, N, M):
+        """Problems beyond the packed state's path-length limit use the float2 state whatever the flag (include/sdp.h)."""
+        return self.lib.sdp_state_bytes(1, N, M) == self.lib.sdp_state_d_bytes(1, N, M)
 
     def adjoint_forward(self, state, Ztheta, ZA, variant, lens=None):
         """-> (Vtd (B,), state_d).  Replaces _adjoint_forward_pass_kernel (nw_cuda.py:134-139)."""

@@ -124,15 +124,23 @@ class ShardedAligner:
     async_e : with gather="e", return `out["E"]` as a PendingGather instead of waiting: the collective runs on
               RCCL's stream while the caller launches the next batch's sweeps (the gather is several times
               longer than the compute, so the compute disappears under it).
+    e_chunks: with gather="e" (and no per-pair lengths): the backward sweep is launched in this many pieces of
+              B_local / e_chunks pairs, and each piece's all-gather is issued as soon as the piece is enqueued -- on
+              the backend's own stream, so it runs under the sweep of the next piece ("gather in chunks
+              overlapped with the backward kernel").  Every piece lands directly in its place in the (B, N, M) result.
+              1 = one collective after the whole sweep.  `out["e_overlap"]` says which happened ("chunked" / "none").
     """
 
-    def __init__(self, decoder, group=None, gather="vt", async_e=False):
+    def __init__(self, decoder, group=None, gather="vt", async_e=False, e_chunks=1):
         if gather not in ("vt", "e", "paths", "none"):
             raise ValueError("gather must be 'vt', 'e', 'paths' or 'none'")
+        if int(e_chunks) < 1:
+            raise ValueError("e_chunks must be >= 1")
         self.decoder = decoder
         self.group = group
         self.gather = gather
         self.async_e = async_e
+        self.e_chunks = int(e_chunks)
         self._ones = None
 
     def _world(self):
@@ -154,20 +162,22 @@ class ShardedAligner:
             if lengths is None:
                 raise ValueError("a BalancedPlan needs the per-pair lengths of this rank's pairs")
             theta, A, lengths = pad_shard(theta, A, lengths, plan.per_rank)
+        gathering = self.gather != "none" and dist.is_available() and dist.is_initialized()
+        if gathering and self.gather == "e" and self.e_chunks > 1 and lengths is None and theta.shape[0] >= self.e_chunks:
+            return self._align_chunked_e(theta.detach(), A.detach(), n_real)
         theta = theta.detach().requires_grad_(True)
         Vt = self.decoder(theta, A, lengths) if lengths is not None else self.decoder(theta, A)
         # dVt.sum()/dtheta with the cotangent handed over directly: no reduction kernel and no expand/copy of
         # its gradient on the way to the backward sweep
         if self._ones is None or self._ones.shape != Vt.shape or self._ones.device != Vt.device:
             self._ones = torch.ones_like(Vt)
-        gathering = self.gather != "none" and dist.is_available() and dist.is_initialized()
         pending = None
         if gathering:
             # the scores are final after the forward sweep: their all-gather (RCCL's own stream) runs while the
             # backward sweep computes E
             pending = _all_gather_cat(Vt.detach(), self.group, async_op=True)
         (E,) = torch.autograd.grad(Vt, theta, grad_outputs=self._ones)
-        out = {"Vt_local": Vt.detach()[:n_real], "E_local": E[:n_real], "Vt": None, "E": None, "paths": None}
+        out = {"Vt_local": Vt.detach()[:n_real], "E_local": E[:n_real], "Vt": None, "E": None, "paths": None, "e_overlap": "none"}
         if gathering:
             if self.gather == "paths":
                 from . import _engine
@@ -181,6 +191,49 @@ class ShardedAligner:
                 e_pending = PendingGather(*_all_gather_cat(E, self.group, async_op=True), plan=plan)
                 out["E"] = e_pending if self.async_e else e_pending.wait()
         return out
+
+
+    def _align_chunked_e(self, theta, A, n_real):
+        """gather="e" with e_chunks > 1: backward sweep and E gather in pieces.  The full result is laid out rank-major
+        like the one-collective gather's ((world * B_local, N, M)); this rank's sweep writes its pieces straight into
+        its own rows of that tensor, and each piece's all-gather fills the same rows of the other ranks' blocks (the
+        collective's output list are views of the result: no staging copy on our side)."""
+        from . import _engine
+        from .sw import SmithWatermanDecoder
+        eng = _engine.get_engine()
+        variant = _engine.SW if isinstance(self.decoder, SmithWatermanDecoder) else _engine.NW
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        Bl, N, M = theta.shape
+        if getattr(self.decoder, "operator", "softmax") != "softmax":
+            raise NotImplementedError("only the softmax operator is implemented (as in the reference's batched path)")
+        Vt, state = eng.forward(theta, A, variant)     # the same two sweeps decoder(theta, A) + autograd.grad launch
+        vt_pending = _all_gather_cat(Vt, self.group, async_op=True)
+        if self._ones is None or self._ones.shape != Vt.shape or self._ones.device != Vt.device:
+            self._ones = torch.ones_like(Vt)
+        full = torch.empty((world * Bl, N, M), dtype=torch.float32, device=theta.device)
+        mine = full[rank * Bl:(rank + 1) * Bl]
+        bounds = [shard_bounds(Bl, self.e_chunks, k) for k in range(self.e_chunks)]
+        works = []
+        for lo, hi in bounds:
+            eng.backward(self._ones, state, (Bl, N, M), variant, pair_range=(lo, hi), out=mine)
+            outs = [full[r * Bl + lo:r * Bl + hi] for r in range(world)]
+            works.append(dist.all_gather(outs, mine[lo:hi], group=self.group, async_op=True))
+        e_pending = PendingGather(full, _Works(works))
+        out = {"Vt_local": Vt.detach()[:n_real], "E_local": mine[:n_real], "paths": None, "e_overlap": "chunked",
+               "Vt": PendingGather(*vt_pending).wait(), "E": e_pending if self.async_e else e_pending.wait()}
+        return out
+
+
+class _Works:
+    """Several collectives' handles behind one .wait()."""
+
+    def __init__(self, works):
+        self._works = works
+
+    def wait(self):
+        for w in self._works:
+            if w is not None:
+                w.wait()
 
 
 # One traceback step in one int32 for the gather: state in bits 0-1, j above it in ceil(log2 M) bits, i in the rest

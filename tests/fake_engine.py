@@ -40,18 +40,24 @@ class OracleEngine:
         state._oracle_Q = Qs  # opaque, like the real engine's flat state
         return torch.from_numpy(Vt), state
 
-    def backward(self, Et, state, shape, variant, lens=None, exact_state=False):
+    def backward(self, Et, state, shape, variant, lens=None, exact_state=False, pair_range=None, out=None):
         B, N, M = shape
         et = self._np(Et).astype(np.float32).reshape(-1)
         et = np.broadcast_to(et, (B,)) if et.size == 1 else et
-        E = np.zeros((B, N, M), np.float32)
-        state._oracle_E = []
-        for b, q in enumerate(state._oracle_Q):
+        lo, hi = (0, B) if pair_range is None else pair_range
+        E = np.zeros((hi - lo, N, M), np.float32)
+        if not hasattr(state, "_oracle_E") or pair_range is None:
+            state._oracle_E = [None] * B
+        for b in range(lo, hi):
+            q = state._oracle_Q[b]
             e = oracle.backward(et[b:b + 1], q, variant)
             n, m = q.shape[1] - 2, q.shape[2] - 2
-            E[b, :n, :m] = e[0, 1:-1, 1:-1]
-            state._oracle_E.append(e)
-        return torch.from_numpy(E)
+            E[b - lo, :n, :m] = e[0, 1:-1, 1:-1]
+            state._oracle_E[b] = e
+        if out is None:
+            return torch.from_numpy(E)
+        out[lo:hi] = torch.from_numpy(E)   # like the real engine: only the swept rows are written
+        return out
 
     def adjoint_forward(self, state, Ztheta, ZA, variant, lens=None):
         Z = self._np(Ztheta)

@@ -21,6 +21,52 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _worker_chunked(rank, world, port, outdir):
+    """gather="e" with the backward sweep and the gather in pieces (uneven pieces: 5 pairs per rank in 3 chunks)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deepblast_amd import _engine, SmithWatermanDecoder
+    from deepblast_amd.distributed import ShardedAligner
+    from fake_engine import OracleEngine
+    _engine._ENGINE = OracleEngine()
+    B, N, M = 10, 20, 27
+    theta, A = datagen.theta_A(47, B, N, M)
+    lo, hi = shard_bounds(B, world, rank)
+    res = {}
+    for name, kw in (("chunked", dict(e_chunks=3)), ("async", dict(e_chunks=2, async_e=True)), ("one", dict(e_chunks=1))):
+        al = ShardedAligner(SmithWatermanDecoder("softmax"), gather="e", **kw)
+        out = al.align(torch.from_numpy(theta[lo:hi]), torch.from_numpy(A[lo:hi]))
+        E = out["E"].wait() if kw.get("async_e") else out["E"]
+        res[name + "_E"], res[name + "_Vt"], res[name + "_El"] = E.numpy(), out["Vt"].numpy(), out["E_local"].numpy()
+        res[name + "_overlap"] = out["e_overlap"]
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_chunked_e_gather_world2(tmp_path):
+    """E gathered in pieces under the backward sweep -- every rank ends up with the whole batch in batch
+    order, identical to the one-collective gather; the result says which overlap was used."""
+    import parity
+    world = 2
+    mp.spawn(_worker_chunked, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    theta, A = datagen.theta_A(47, 10, 20, 27)
+    ref = parity.oracle_all(theta, A, None, None, 1, omp=False)
+    for r in range(world):
+        d = np.load(tmp_path / f"r{r}.npz")
+        lo, hi = shard_bounds(10, world, r)
+        for name in ("chunked", "async", "one"):
+            assert np.array_equal(d[name + "_E"], ref["E"]), (r, name)
+            assert np.array_equal(d[name + "_Vt"], ref["Vt"]), (r, name)
+            assert np.array_equal(d[name + "_El"], ref["E"][lo:hi]), (r, name)
+        assert str(d["chunked_overlap"]) == "chunked" and str(d["async_overlap"]) == "chunked" and str(d["one_overlap"]) == "none"
+
+
 def _worker(rank, world, port, gather, outdir):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "tests")):

@@ -46,8 +46,9 @@ def _worker(rank, world, port, mode, outdir):
     from deepblast_amd.distributed import BalancedPlan, ShardedAligner, shard_bounds
     B, N, M = 10, 150, 130
     theta, A = datagen.theta_A(45, B, N, M)
-    al = ShardedAligner(NeedlemanWunschDecoder("softmax"), gather="e", async_e=(mode == "balanced"))
-    if mode == "contiguous":
+    al = ShardedAligner(NeedlemanWunschDecoder("softmax"), gather="e", async_e=(mode == "balanced"),
+                        e_chunks=3 if mode == "chunked" else 1)
+    if mode in ("contiguous", "chunked"):
         lo, hi = shard_bounds(B, world, rank)
         out = al.align(torch.from_numpy(theta[lo:hi]).to(dev), torch.from_numpy(A[lo:hi]).to(dev))
         E = out["E"]
@@ -65,13 +66,13 @@ def _worker(rank, world, port, mode, outdir):
 
 
 @needs2
-@pytest.mark.parametrize("mode", ["contiguous", "balanced"])
+@pytest.mark.parametrize("mode", ["contiguous", "balanced", "chunked"])
 def test_sharded_align_two_ranks_rccl(tmp_path, mode):
     import parity
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
     theta, A = datagen.theta_A(45, 10, 150, 130)
-    if mode == "contiguous":
+    if mode in ("contiguous", "chunked"):
         ref = parity.oracle_all(theta, A, None, None, 0, omp=False)
     else:
         ref = parity.oracle_lens(theta, A, None, None, 0, datagen.lengths(46, 10, 5, 130))
@@ -141,6 +142,27 @@ def test_gathered_paths_two_ranks_share_one_gpu(tmp_path):
 def test_gathered_paths_two_ranks_rccl(tmp_path):
     mp.spawn(_worker_paths, args=(2, _free_port(), "nccl", str(tmp_path)), nprocs=2, join=True)
     _check_paths(tmp_path, 2)
+
+
+def test_backward_sweep_in_pieces_is_bit_identical():
+    """The backward sweep of a batch launched in pieces (HipEngine.backward(pair_range=, out=): what the chunked E
+    gather does) writes exactly what one launch writes, packed and exact state, and leaves the other rows alone."""
+    from deepblast_amd._engine import get_engine
+    eng = get_engine()
+    B, N, M = 37, 130, 200
+    theta, A = datagen.theta_A(49, B, N, M)
+    t, a = torch.from_numpy(theta).cuda(), torch.from_numpy(A).cuda()
+    et = torch.from_numpy((0.5 + datagen.uniform(50, (B,))).astype(np.float32)).cuda()
+    for exact in (False, True):
+        for variant in (0, 1):
+            Vt, Q = eng.forward(t, a, variant, exact_state=exact)
+            whole = eng.backward(et, Q, (B, N, M), variant, exact_state=exact)
+            out = torch.full((B, N, M), -7.0, device="cuda")
+            for lo, hi in ((0, 5), (5, 6), (6, 30)):
+                eng.backward(et, Q, (B, N, M), variant, exact_state=exact, pair_range=(lo, hi), out=out)
+            assert torch.equal(out[:30], whole[:30]) and bool((out[30:] == -7.0).all())
+    with pytest.raises(ValueError):
+        eng.backward(et, Q, (B, N, M), 0, lens=torch.ones(B, 2, dtype=torch.int32, device="cuda"), pair_range=(0, 2), out=out)
 
 
 def test_bench_refuses_more_gpus_than_present():

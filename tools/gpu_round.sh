@@ -17,6 +17,16 @@ if [ "$2" != "quick" ]; then
   # suite did not catch the one kernel bug of round 2, this did
   timeout 900 python tools/fuzz2.py 300 2>&1 | tail -4 | tee $OUT/fuzz2.txt
 fi
+# multi-GPU dry run: the 2-rank RCCL tests and bench.py --gpus 2/4/8 in one go wherever more than one GPU is visible
+NGPU=$(python -c "import torch; print(torch.cuda.device_count())")
+if [ "$NGPU" -ge 2 ]; then
+  timeout 900 python -m pytest tests/test_distributed_nccl_gpu.py tests/test_comm_gpu.py -q 2>&1 | tail -5 | tee $OUT/pytest_multigpu.txt
+  for G in 2 4 8; do
+    [ "$G" -le "$NGPU" ] && timeout 600 python bench.py --gpus $G --steps 10 --warmup 2 2>> $OUT/bench_multi.err | tee $OUT/bench_gpus$G.json
+  done
+else
+  echo "multi-GPU dry run SKIPPED: $NGPU GPU visible (needs >= 2; nothing in this repo has run on more than one GPU yet)" | tee $OUT/multigpu_skipped.txt
+fi
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o fwdbwd -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/rocprof.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o train -- python bench.py --steps 10 --warmup 2 --mode train --no-cpu-baseline > $OUT/bench_prof_train.json 2>> $OUT/rocprof.err
 for C in FETCH_SIZE WRITE_SIZE; do
