@@ -352,14 +352,15 @@ def main():
             # the GEMM dominates this mode: its bound is the matrix pipe (filled in below as scores_roofline); the
             # HBM figures above then describe nothing and are replaced
             line["roofline"] = None
-        if args.mode == "scores+dp" and ("sdp_scores_kernel" in ms or "sdp_scores_x6_kernel" in ms):
+        if args.mode == "scores+dp" and ("sdp_scores_kernel" in ms or "sdp_scores_x6_kernel" in ms or "sdp_scores_x6w_kernel" in ms):
             flops = 2.0 * 2.0 * B * N * M * args.D          # two (N,D) x (D,M) products per pair
-            if "sdp_scores_x6_kernel" in ms:
+            if "sdp_scores_x6_kernel" in ms or "sdp_scores_x6w_kernel" in ms:
                 # three exact bf16 pieces per operand, six piece products per k: the pipe executes 6x the algorithmic
                 # flops; `achieved` / `peak` are what ran on the bf16 pipe, `algorithmic` the fp32-equivalent rate
-                t_ms = ms["sdp_scores_x6_kernel"]
+                x6name = "sdp_scores_x6w_kernel" if "sdp_scores_x6w_kernel" in ms else "sdp_scores_x6_kernel"
+                t_ms = ms[x6name]
                 tf = 6.0 * flops / (t_ms * 1e-3) / 1e12
-                line["scores_roofline"] = {"bound": "mfma", "kernel": "sdp_scores_x6_kernel", "achieved": tf, "peak": 2516.6, "unit": "TFLOP/s", "traffic": None,
+                line["scores_roofline"] = {"bound": "mfma", "kernel": x6name, "achieved": tf, "peak": 2516.6, "unit": "TFLOP/s", "traffic": None,
                                            "frac": tf / 2516.6, "dtype": "bf16 x 6 piece products (v_mfma_f32_32x32x16_bf16), f32 accumulate",
                                            "algorithmic": flops / (t_ms * 1e-3) / 1e12, "algorithmic_vs_f32_mfma_peak": flops / (t_ms * 1e-3) / 1e12 / 157.3,
                                            "D": args.D, "launch_ms": t_ms, "flops_per_launch": flops}

@@ -500,6 +500,15 @@ static bool scores_force_f32()
 #endif
 }
 
+static bool scores_force_narrow()
+{
+#ifdef SDP_EXPERIMENTS
+    return (g_dbg.load() & 32) != 0;   // sdp_set_debug(32): the 128 x 128 tiles for every shape (A/B timing, bit-identity test)
+#else
+    return false;
+#endif
+}
+
 int sdp_scores_f32(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
                    int M, int D, int device, void *stream)
 {
@@ -518,6 +527,8 @@ int sdp_scores_f32(const float *zx, const float *zy, const float *gx, const floa
         if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(sdp_scores_kernel)");
         e = hipFuncSetAttribute((const void *)sdp_scores_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sdp::SCORES_X6_LDS_BYTES);
         if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(sdp_scores_x6_kernel)");
+        e = hipFuncSetAttribute((const void *)sdp_scores_x6w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sdp::SCORES_X6W_LDS_BYTES);
+        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(sdp_scores_x6w_kernel)");
         if (device < 64) raised |= 1ull << device;
     }
     // whole 16-deep slabs of 16-byte aligned rows: the three-piece bf16 product (sdp_scores.hip); anything else: the
@@ -525,7 +536,16 @@ int sdp_scores_f32(const float *zx, const float *zy, const float *gx, const floa
     auto aligned16 = [](const void *q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const bool x6 = D % 16 == 0 && aligned16(zx) && aligned16(zy) && aligned16(gx) && aligned16(gy) && !scores_force_f32();
     const dim3 grid((M + 127) / 128, (N + 127) / 128, (unsigned)nz);
-    if (x6)
+    // 256 x 256 tiles (8 waves, half the cuts and LDS traffic per MFMA) when they do not waste more than a quarter more
+    // of the matrix pipe on rows and columns outside the matrices than the 128 x 128 tiles do, and when there are at
+    // least two of them per CU (one workgroup per CU: a batch of few large tiles leaves CUs idle -- 3 x 1000 x 701:
+    // 129 us against 85 us with the small tiles)
+    const long long t128 = (long long)grid.x * grid.y, t256 = (long long)((M + 255) / 256) * ((N + 255) / 256) * 4;
+    const bool wide = x6 && !scores_force_narrow() && 4 * t256 <= 5 * t128 && (t256 / 4) * nz >= 2LL * num_cus(device);
+    if (wide)
+        hipLaunchKernelGGL(sdp_scores_x6w_kernel, dim3((M + 255) / 256, (N + 255) / 256, (unsigned)nz), dim3(512), sdp::SCORES_X6W_LDS_BYTES,
+                           (hipStream_t)stream, zx, zy, gx, gy, theta, A, B, N, M, D);
+    else if (x6)
         hipLaunchKernelGGL(sdp_scores_x6_kernel, grid, dim3(256), sdp::SCORES_X6_LDS_BYTES, (hipStream_t)stream, zx, zy, gx, gy, theta, A, B, N, M, D);
     else
         hipLaunchKernelGGL(sdp_scores_kernel, grid, dim3(256), sdp::SCORES_LDS_BYTES, (hipStream_t)stream, zx, zy, gx, gy, theta, A, B, N, M, D);

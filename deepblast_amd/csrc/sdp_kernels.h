@@ -125,6 +125,7 @@ __host__ __device__ inline int state_tpad(int M) { return (M + 63 + 63) / 64 * 6
 #endif
 constexpr int SCORES_LDS_BYTES = 2 * 2 * 128 * (SDP_SC_BK + 4) * 4;  // sdp_scores_kernel: [buffer][operand][128 rows][BK + 4 floats]
 constexpr int SCORES_X6_LDS_BYTES = 2 * 2 * 3 * 128 * 32;            // sdp_scores_x6_kernel: [buffer][operand][piece][128 rows][32 bytes]
+constexpr int SCORES_X6W_LDS_BYTES = 2 * 2 * 3 * 256 * 32;           // sdp_scores_x6w_kernel: the same with 256 rows per operand
 
 }  // namespace sdp
 
@@ -154,6 +155,8 @@ __global__ void sdp_scores_kernel(const float *zx, const float *zy, const float 
                                   int M, int D);
 __global__ void sdp_scores_x6_kernel(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
                                      int M, int D);
+__global__ void sdp_scores_x6w_kernel(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
+                                      int M, int D);
 __global__ void sdp_order_kernel(const int *lens, int *order, int B, int N, int M);
 __global__ void sdp_traceback_kernel(const float *grad, int *states, int *counts, const int *lens, int B, int N, int M, int cap);
 __global__ void sdp_traceback_cuda_kernel(const float *grad, int *states, int *counts, const int *lens, int B, int N, int M, int cap);

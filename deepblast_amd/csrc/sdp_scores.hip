@@ -27,10 +27,20 @@
 
 #include "sdp_kernels.h"
 
+// switches of sdp_scores_x6w_kernel (the 256 x 256 three-piece kernel at the end of this file)
+#ifndef SDP_XW_EPI_LDS
+#define SDP_XW_EPI_LDS 1   // epilogue through LDS with dwordx4 stores (0: one dword store per accumulator element)
+#endif
+#ifndef SDP_XW_ABL
+#define SDP_XW_ABL 0   // timing experiments (wrong results): 1 no MFMAs, 2 no cuts, 4 no epilogue, 16 no global loads, 32 no LDS reads, 64 no LDS writes
+#endif
+
 namespace sdp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int SC_TILE = 128;   // rows and columns of C per workgroup
 
@@ -80,7 +90,8 @@ __device__ __forceinline__ float logsigmoid_f(float x)
 // C/D layout of the 32x32 MFMA forms (the same for every input type on gfx950): col = lane & 31,
 // row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5).  For a fixed v the 32 lanes of a half-wave write 32 consecutive
 // columns (128 bytes) of one row.  The activation is applied here, so each output tensor is written exactly once.
-__device__ __forceinline__ void scores_epilogue(const f32x16 (&acc)[2][2], float *C, int N, int M, int i0, int j0, int wr, int wc,
+template <int NA, int NC>
+__device__ __forceinline__ void scores_epilogue(const f32x16 (&acc)[NA][NC], float *C, int N, int M, int i0, int j0, int wr, int wc,
                                                 int lane, int kind)
 {
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(C, 0, N * M * 4, 0x00020000);
@@ -89,9 +100,9 @@ __device__ __forceinline__ void scores_epilogue(const f32x16 (&acc)[2][2], float
     const float sg = kind ? -1.0f : 1.0f;
     const int row0 = i0 + wr + 4 * (lane >> 5);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int col = j0 + wc + 32 * c + (lane & 31);
             // byte offset of (row0, col); a column outside the matrix: out of range whatever is added (N * M * 4 <= 2^30)
             const unsigned base = col < M ? (unsigned)(row0 * M + col) * 4u : 0x80000000u;
@@ -104,6 +115,53 @@ __device__ __forceinline__ void scores_epilogue(const f32x16 (&acc)[2][2], float
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rc, off, 0, 0);
             }
         }
+}
+
+// The same through LDS, for full-width stores (round 3).  In the accumulator layout a lane holds ONE column of 16 rows, so
+// the direct epilogue above issues one dword store per element -- 128 instructions per lane for a 128 x 64 wave tile,
+// each moving two 128-byte row segments -- and with one workgroup per CU nothing hides them: the epilogue of the
+// 256 x 256 kernel took 315 of its 767 us.  Here a wave writes a 32 x 64 block of activated values to its own slice of
+// LDS (the staging buffers are free after the main loop) and reads it back row-wise, four consecutive columns per lane:
+// one dwordx4 store instruction then moves four 256-byte row segments, 8 instead of 32 instructions per block.
+// `slice`: this wave's private LDS area, >= 32 * EPI_PITCH floats.
+constexpr int EPI_PITCH = 68;   // floats per staged row: 64 + 4 (16-byte aligned rows; the two half-waves' writes land on disjoint banks)
+template <int NA>
+__device__ __forceinline__ void scores_epilogue_lds(const f32x16 (&acc)[NA][2], float *slice, float *C, int N, int M, int i0, int j0, int wr,
+                                                    int wc, int lane, int kind)
+{
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(C, 0, N * M * 4, 0x00020000);
+    const float sg = kind ? -1.0f : 1.0f;
+    const int wrow = 4 * (lane >> 5), wcol = lane & 31;      // where this lane's accumulator elements go (+ (v & 3) + 8 (v >> 2) rows, + 32 c columns)
+    const int rrow = lane >> 4, rcol = (lane & 15) * 4;      // what it reads back: rows rrow + 4 i, columns rcol .. rcol + 3
+    const int col = j0 + wc + rcol;
+    const bool vec = (M & 3) == 0;                           // rows 16-byte aligned: a float4 never straddles the end of a row
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const float x = acc[a][c][v];
+                slice[(wrow + (v & 3) + 8 * (v >> 2)) * EPI_PITCH + 32 * c + wcol] = sg * (__builtin_fmaxf(sg * x, 0.0f) + log1p_exp_neg_abs(x));
+            }
+        const int row0 = i0 + wr + 32 * a + rrow;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 y = *reinterpret_cast<const f32x4 *>(slice + (rrow + 4 * i) * EPI_PITCH + rcol);
+            const int row = row0 + 4 * i;
+            if (vec) {
+                const unsigned off = (row < N && col < M) ? (unsigned)(row * M + col) * 4u : 0x80000000u;
+                u32x4 w = {__float_as_uint(y[0]), __float_as_uint(y[1]), __float_as_uint(y[2]), __float_as_uint(y[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(w, rc, off, 0, 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned off = (row < N && col + e < M) ? (unsigned)(row * M + col + e) * 4u : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[e]), rc, off, 0, 0);
+                }
+            }
+        }
+    }
 }
 
 }  // namespace sdp
@@ -245,8 +303,6 @@ sdp_scores_kernel(const float *zx, const float *zy, const float *gx, const float
 #endif
 namespace sdp {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int X6_BK = 16;
 #ifndef SDP_X6_AHEAD
 #define SDP_X6_AHEAD 4
@@ -420,5 +476,194 @@ sdp_scores_x6_kernel(const float *zx, const float *zy, const float *gx, const fl
         if (acc[0][0][0] == 12345.f) C[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];
     } else {
         scores_epilogue(acc, C, N, M, i0, j0, wr, wc, lane, kind);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// The same three-piece product on 256 x 256 tiles (round 3).  In the 128 x 128 kernel above a wave issues ~200
+// instructions per 24-MFMA slab -- 88 of them the cuts -- and the issue port, not the matrix pipe, sets the pace
+// (0.38 of the bf16 peak).  The cuts and the LDS traffic grow with the tile's EDGE, the MFMAs with its AREA: one
+// workgroup of 8 waves (2 x 4, a wave owns 128 x 64 = 4 x 2 blocks, 128 accumulator registers) per 256 x 256 tile does
+// 48 MFMAs per wave and slab for the same 4 cuts per thread, 18 instead of 12 fragment reads, and one barrier.  The
+// fragments of the A side are read in two halves so that the kernel fits the 256 registers a wave has with two
+// waves per SIMD (241, no scratch); the global loads run two slabs ahead.  LDS: 2 buffers x 6 planes x 256 rows x 32 B =
+// 96 KiB, one workgroup per CU.  The epilogue goes through LDS for dwordx4 stores (scores_epilogue_lds).  Used when the
+// batch has enough 256 x 256 tiles to fill the chip (sdp_api.hip); same arithmetic as the 128 x 128 kernel:
+// bit-identical results.
+// Measured, B=256 N=M=D=512: 683-730 us against 850-900 us for the 128 x 128 kernel and 1.68 ms for the
+// reference's two einsums + activations in PyTorch on the same box.  What bounds it, from cycle stamps inside the kernel
+// (s_memtime ticks are shader cycles): the 48 MFMAs of a slab issue in ~1800 cycles (37 per MFMA, floor 32), a slab
+// period is ~3900 cycles, and a workgroup spends 5.4k / 134k / 13k cycles in prologue / main loop / epilogue -- at a
+// shader clock of ~1.6 GHz: on random operands this kernel runs into the chip's power limit, and the clock, not the
+// schedule, sets the time.  Variants that re-arranged the same work did not move it (rotated A/B, same run): two groups
+// of four waves half a period out of phase with three LDS buffers ("ping-pong": 688-728 us), global loads three slabs
+// ahead (688), s_setprio around the MFMAs (714), sched_group_barrier interleaving of cuts and MFMAs (744 vs 703).
+// ----------------------------------------------------------------------------------------------------------------
+namespace sdp {
+constexpr int XW_TILE = 256;
+constexpr int XW_PLANE = XW_TILE * X6_PITCH;
+constexpr int XW_BUF = 2 * 3 * XW_PLANE;
+static_assert(2 * XW_BUF == SCORES_X6W_LDS_BYTES, "sdp_kernels.h: SCORES_X6W_LDS_BYTES");
+#ifndef SDP_XW_AHEAD
+#define SDP_XW_AHEAD 2
+#endif
+}  // namespace sdp
+
+extern "C" __global__ void __launch_bounds__(512)
+sdp_scores_x6w_kernel(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
+                      int M, int D)
+{
+    using namespace sdp;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_xw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const TileId tile = xcd_tile();
+    const int kind = tile.z >= B;
+    const int b = kind ? tile.z - B : tile.z;
+    const float *X = (kind ? gx : zx) + ((SDP_XW_ABL & 128) ? 0 : (size_t)b * N * D);   // (ablation 128: every tile reads pair 0, tile 0: cache-served loads)
+    const float *Y = (kind ? gy : zy) + ((SDP_XW_ABL & 128) ? 0 : (size_t)b * M * D);
+    float *C = (kind ? A : theta) + (size_t)b * N * M;
+    const int i0 = tile.y * XW_TILE, j0 = tile.x * XW_TILE;
+    const int li0 = (SDP_XW_ABL & 128) ? 0 : i0, lj0 = (SDP_XW_ABL & 128) ? 0 : j0;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, N * D * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Y), 0, M * D * 4, 0x00020000);
+
+    // staging: a slab is 256 rows x 16 k per operand = 1024 float4; thread t moves rows t / 4 and t / 4 + 128, k = 4 (t % 4)
+    const int ld_row = tid >> 2, ld_k = (tid & 3) * 4;
+    const int st_col = (((ld_k >> 3) ^ ((ld_row >> 3) & 1)) << 4) + ((ld_k & 4) << 1);   // (rows + 128 keep the same swizzle bit)
+    unsigned row_off[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int op = 0; op < 2; ++op) {
+            const int row = (op ? lj0 : li0) + ld_row + 128 * q;
+            row_off[op][q] = row < (op ? M : N) ? (unsigned)((size_t)row * D + ld_k) * 4u : 0x80000000u;   // outside: zeros
+        }
+    constexpr int AHEAD = SDP_XW_AHEAD;
+    static_assert(AHEAD % 2 == 0, "the loop unrolls by AHEAD and a slab's LDS buffer is its parity");
+    f32x4 stage[AHEAD][2][2];
+    auto load_slab = [&](int k0, f32x4 (&st)[2][2]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int op = 0; op < 2; ++op) {
+                f32x4 v;
+                if constexpr (SDP_XW_ABL & 16) {
+                    v[0] = v[1] = v[2] = v[3] = (float)(k0 + q + op);
+                } else {
+                    const auto w = __builtin_amdgcn_raw_buffer_load_b128(op ? ry : rx, k0 < D ? row_off[op][q] : 0x80000000u, (SDP_XW_ABL & 256) ? 0 : k0 * 4, 0);   // (ablation 256: every slab re-reads slab 0: L1-served)
+                    v[0] = __uint_as_float(w[0]), v[1] = __uint_as_float(w[1]), v[2] = __uint_as_float(w[2]), v[3] = __uint_as_float(w[3]);
+                }
+                st[op][q] = v;
+            }
+    };
+    // rows ld_row + 128 q of both operands: cut into pieces, three 8-byte LDS writes each
+    auto store_half = [&](int buf, const f32x4 (&st)[2][2], int q) {
+#pragma unroll
+        for (int op = 0; op < 2; ++op) {
+            u32x2 piece[3];
+            if constexpr (SDP_XW_ABL & 2) {
+                piece[0][0] = __float_as_uint(st[op][q][0]), piece[0][1] = __float_as_uint(st[op][q][1]);
+                piece[1][0] = __float_as_uint(st[op][q][2]), piece[1][1] = __float_as_uint(st[op][q][3]);
+                piece[2] = piece[0];
+            } else {
+                cut3(st[op][q], piece);
+            }
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                if constexpr (SDP_XW_ABL & 64) {
+                    if (piece[pc][0] == 0x12345u) lds_xw[pc] = 1;
+                } else {
+                    *reinterpret_cast<u32x2 *>(lds_xw + buf * XW_BUF + (op * 3 + pc) * XW_PLANE + (ld_row + 128 * q) * X6_PITCH + st_col) = piece[pc];
+                }
+            }
+        }
+    };
+
+    const int wr = (wave >> 2) * 128, wc = (wave & 3) * 64;
+    const int fr = lane & 31, fkb = ((lane >> 5) ^ ((lane >> 3) & 1)) * 16;   // row within a 32-row block, byte offset of this lane's 8 k (swizzled)
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[a][c][v] = 0.f;
+
+    // One barrier per slab: [issue the loads of slab s + AHEAD] [fragments of slab s: B side and the first half of the A side]
+    // [24 MFMAs | the second half's A fragments arrive under them] [24 MFMAs] [cut slab s + 1 into the other buffer] [barrier].
+    // Within a half the four accumulators take turns (the same one every fourth MFMA): an MFMA that needs the result of the
+    // one or two before it waits for the pipe to drain (measured: 56 instead of 32 cycles per MFMA with two alternating).
+    // No branch inside the loop body: with one, the compiler's wait-count bookkeeping gives up at the loop header and drains
+    // every outstanding load there; the slab count is rounded up to a multiple of AHEAD instead -- the extra slab reads out
+    // of range, i.e. zeros, and the cut behind the last slab goes into a buffer nobody reads.
+    const int nslab = D / X6_BK;
+#pragma unroll
+    for (int u = 0; u < AHEAD; ++u) load_slab(u * X6_BK, stage[u]);
+    store_half(0, stage[0], 0);
+    store_half(0, stage[0], 1);
+    __syncthreads();
+    for (int s0 = 0; s0 < nslab; s0 += AHEAD) {
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) {
+            const int s = s0 + u;
+            const int buf = u & 1;   // = s & 1 (AHEAD is even)
+            load_slab((s + AHEAD) * X6_BK, stage[u]);   // slab s went to LDS in the previous iteration
+            const unsigned char *base = lds_xw + buf * XW_BUF;
+            bf16x8 fb[2][3], fa[2][2][3];
+            auto read_fa = [&](int h, bf16x8 (&f)[2][3]) {   // rows 64 h .. 64 h + 63 of this wave's 128: two 32-row blocks
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+                    for (int a2_ = 0; a2_ < 2; ++a2_) {
+                        if constexpr (SDP_XW_ABL & 32) { const u32x4 cst = {(unsigned)(s + h + a2_), (unsigned)pc, (unsigned)lane, 7u}; f[a2_][pc] = __builtin_bit_cast(bf16x8, cst); }
+                        else f[a2_][pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(base + pc * XW_PLANE + (wr + 64 * h + 32 * a2_ + fr) * X6_PITCH + fkb));
+                    }
+            };
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if constexpr (SDP_XW_ABL & 32) { const u32x4 cst = {(unsigned)(s + c), (unsigned)pc, (unsigned)lane, 9u}; fb[c][pc] = __builtin_bit_cast(bf16x8, cst); }
+                    else fb[c][pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(base + (3 + pc) * XW_PLANE + (wc + 32 * c + fr) * X6_PITCH + fkb));
+                }
+            read_fa(0, fa[0]);
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // the six piece pairs, smallest first
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h == 0) read_fa(1, fa[1]);
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int a2_ = 0; a2_ < 2; ++a2_)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            if constexpr (SDP_XW_ABL & 1) {
+                                const u32x4 ua = __builtin_bit_cast(u32x4, fa[h][a2_][PA[t]]), ub = __builtin_bit_cast(u32x4, fb[c][PB[t]]);
+                                acc[2 * h + a2_][c][t] += __uint_as_float(ua[0] ^ ub[1]);
+                            } else {
+                                acc[2 * h + a2_][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][a2_][PA[t]], fb[c][PB[t]], acc[2 * h + a2_][c], 0, 0, 0);
+                            }
+                        }
+            }
+            store_half(buf ^ 1, stage[(u + 1) % AHEAD], 0);   // slab s + 1
+            store_half(buf ^ 1, stage[(u + 1) % AHEAD], 1);
+            __syncthreads();
+        }
+    }
+    if constexpr (SDP_XW_ABL & 4) {
+        float sum = 0.f;   // every accumulator must stay live, or the compiler deletes its MFMAs
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) sum += acc[a][c][(3 * a + c) & 15];
+        if (sum == 12345.f) C[0] = sum;
+    } else {
+#if SDP_XW_EPI_LDS
+        // every wave is past its last fragment read (the phase barriers above): the staging buffers are free
+        static_assert(8 * 32 * EPI_PITCH * 4 <= SCORES_X6W_LDS_BYTES, "one 32-row slice per wave");
+        scores_epilogue_lds(acc, reinterpret_cast<float *>(lds_xw) + wave * 32 * EPI_PITCH, C, N, M, i0, j0, wr, wc, lane, kind);
+#else
+        scores_epilogue(acc, C, N, M, i0, j0, wr, wc, lane, kind);
+#endif
     }
 }

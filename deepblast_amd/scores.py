@@ -37,7 +37,10 @@ class _Scores(torch.autograd.Function):
         # the library's own choice (sdp_api.hip): whole 16-deep slabs of 16-byte aligned rows take the three-piece bf16
         # product, anything else the f32-input MFMA kernel; the name only labels the launch for bench.py's timer
         x6 = D % 16 == 0 and all((t.data_ptr() & 15) == 0 for t in (zx_, zy_, gx_, gy_))
-        with torch.cuda.device(dev), eng._bracket("sdp_scores_x6_kernel" if x6 else "sdp_scores_kernel"):
+        t256 = -(-N // 256) * -(-M // 256)
+        wide = (x6 and 16 * t256 <= 5 * (-(-N // 128) * -(-M // 128))
+                and t256 * 2 * B >= 2 * torch.cuda.get_device_properties(dev).multi_processor_count)   # 256 x 256 tiles (sdp_api.hip)
+        with torch.cuda.device(dev), eng._bracket(("sdp_scores_x6w_kernel" if wide else "sdp_scores_x6_kernel") if x6 else "sdp_scores_kernel"):
             rc = eng.lib.sdp_scores_f32(_ptr(zx_), _ptr(zy_), _ptr(gx_), _ptr(gy_), _ptr(theta), _ptr(A), B, N, M, D, dev,
                                         eng._stream(dev))
         _lib.check(rc, "sdp_scores_f32")

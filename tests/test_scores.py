@@ -66,6 +66,37 @@ def test_kernel_matches_oracle(shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(160, 500, 760, 48), (150, 510, 514, 32), (256, 512, 512, 512)], ids=lambda s: "x".join(map(str, s)))
+def test_wide_and_narrow_tiles_agree_bit_for_bit(shape):
+    """Full batches take the 256 x 256-tile kernel (sdp_scores_x6w_kernel: 8 waves, epilogue through LDS), small ones the
+    128 x 128 tiles; same arithmetic in the same order, so the results must be identical -- ragged edges in N and M, an M
+    that is not a multiple of 4 (the epilogue's dword path) included.  The experiments build can force the small tiles."""
+    import ctypes
+    import os
+    import torch
+    from deepblast_amd import _lib, build
+    B, N, M, D = shape
+    t256 = -(-N // 256) * -(-M // 256)
+    assert 16 * t256 <= 5 * (-(-N // 128) * -(-M // 128)) and t256 * 2 * B >= 512   # this shape does take the wide kernel on 256 CUs
+    exp = _lib.load_path(build.EXP_OUT)
+    t = [torch.from_numpy((datagen.normal(800 + i, (B, n, D)) * 2.0 / np.sqrt(D)).astype(np.float32)).cuda() for i, n in enumerate((N, M, N, M))]
+    outs = []
+    for mask in (0, 32):
+        exp.sdp_set_debug(mask)
+        theta = torch.full((B, N, M), 7.0, device="cuda")
+        A = torch.full((B, N, M), 7.0, device="cuda")
+        rc = exp.sdp_scores_f32(*(x.data_ptr() for x in t), theta.data_ptr(), A.data_ptr(), B, N, M, D, 0, torch.cuda.current_stream().cuda_stream)
+        exp.sdp_set_debug(0)
+        assert rc == 0
+        outs.append((theta, A))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    sel = [0, B // 2, B - 1]
+    rt, ra = scores_oracle.scores(*[x[sel].cpu().numpy() for x in t])
+    assert parity.rel_err(outs[0][0][sel].cpu().numpy(), rt) <= parity.TOL and parity.rel_err(outs[0][1][sel].cpu().numpy(), ra) <= parity.TOL
+
+
+@pytest.mark.gpu
 def test_bf16_piece_kernel_has_fp32_accuracy_and_unaligned_rows_fall_back():
     """The default kernel for D % 16 == 0 multiplies exact three-piece bf16 operands (six products per k): its error
     against a float64 einsum must be that of an fp32 product (a two-piece split would show 2^-16 per product: 3e-4 here),
