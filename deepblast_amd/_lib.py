@@ -57,6 +57,7 @@ SIGNATURES = {
 # only in -DSDP_EXPERIMENTS builds (deepblast_amd/libsdp_hip_exp.so; never the shipped library)
 EXPERIMENT_SIGNATURES = {
     "sdp_set_debug": (ctypes.c_int, [ctypes.c_int]),
+    "sdp_set_trace": (ctypes.c_int, [ctypes.c_void_p]),
 }
 
 

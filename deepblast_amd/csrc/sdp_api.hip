@@ -17,6 +17,7 @@ namespace {
 thread_local char g_err[256] = "";
 #ifdef SDP_EXPERIMENTS
 std::atomic<int> g_dbg{0};
+std::atomic<unsigned long long *> g_trace{nullptr};
 #endif
 
 // ---- per-device status words (host-pinned, device-visible) ----
@@ -293,6 +294,7 @@ int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state 
     p.status = status_words(device);
 #ifdef SDP_EXPERIMENTS
     p.dbg = g_dbg.load();
+    p.trace = g_trace.load();
 #else
     p.dbg = 0;
 #endif
@@ -381,6 +383,13 @@ int sdp_device_status(int device, int32_t info[4])
 int sdp_set_debug(int mask)
 {
     return g_dbg.exchange(mask);
+}
+// device buffer (>= 4 pairs x 4 waves x 2 strips x 40 blocks x 8 stamps x 8 B = 80 KiB) that the forward sweep of pairs
+// 0, 64, 128, 192 fills with shader-cycle stamps per 16-step block; null = off
+int sdp_set_trace(void *buf)
+{
+    g_trace.store(static_cast<unsigned long long *>(buf));
+    return 0;
 }
 #endif
 

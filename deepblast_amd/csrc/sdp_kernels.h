@@ -94,6 +94,7 @@ struct Params {
                          // pair 0; bit3: strips never publish their progress (exercises the hand-off time-out)
     const int *order;    // launch order (pair per workgroup) or null = identity; lives in the tail of the Q state buffer
     int *status;         // host-visible status words of the device: [0] hand-off time-outs, [1..3] first (pair, strip, chunk | pass << 24)
+    unsigned long long *trace;   // experiments build only (sdp_set_trace): cycle stamps of the forward sweep's blocks, or null
 };
 
 // per-wave LDS staging (floats): input planes are rings [64][2K], the output ring is [64][2K+1]

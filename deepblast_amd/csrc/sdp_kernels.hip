@@ -842,59 +842,97 @@ __device__ __forceinline__ void sweep(const Params &p)
         // Both forms produce identical bits (same 2^theta, exact power-of-two rescaling), so results do not depend on
         // which form a block ran in, on K, or on the batch.
         constexpr bool FWD_SUB = PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_WF && SDP_FWD_SUB;
+        auto read_inputs = [&](int tb, float *d0, float *d1) {
+            const int pr = (tb & (RING - 1)) + 4 * ring_pi(lane & 7);
+#pragma unroll
+            for (int g = 0; g < WB / 4; ++g) {
+                const int idx = lane * PITCH + ((pr + 4 * g) & (RING - 1));
+                const float4 v0 = *reinterpret_cast<const float4 *>(lds_in + idx);
+                const float4 v1 = *reinterpret_cast<const float4 *>(lds_in + PLANE + idx);
+                d0[4 * g] = v0.x, d0[4 * g + 1] = v0.y, d0[4 * g + 2] = v0.z, d0[4 * g + 3] = v0.w;
+                d1[4 * g] = v1.x, d1[4 * g + 1] = v1.y, d1[4 * g + 2] = v1.z, d1[4 * g + 3] = v1.w;
+            }
+        };
+        // Boundary row of the block-wise forward sweep: the 8 bytes per column are kept as two PLANES -- mcap values (float)
+        // followed by mcap exponents (int) -- instead of (value, exponent) pairs.  A block published in one frame (the
+        // normal case) writes and reads its 16 values only: four 16-byte LDS accesses instead of sixteen 8-byte ones on
+        // either side (a wave issues one LDS instruction per ~20 cycles, and the 64 of them per chunk that the boundary
+        // cost were a tenth of the sweep's time); the exponents of such a block ARE its frame word.  Values that could not
+        // be put into one frame carry their exponents in the second plane.
+        const float *bv_in = reinterpret_cast<const float *>(bnd_in);
+        const int *be_in = reinterpret_cast<const int *>(bnd_in) + p.mcap;
+        float *bv_out = reinterpret_cast<float *>(bnd_out);
+        int *be_out = reinterpret_cast<int *>(bnd_out) + p.mcap;
+        auto read_boundary = [&](int tb, float *bcf, int &fa, int &fb) {   // lane 0 at step tb+j needs column tb+j
+            if (has_pred && tb < m) {
+                if (tb + WB <= m) {
+#pragma unroll
+                    for (int g = 0; g < WB / 4; ++g) {   // (tb is a multiple of 16 and the rows are 16-byte aligned: ds_read_b128)
+                        const float4 v = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(bv_in + tb + 4 * g, 16));
+                        bcf[4 * g] = v.x, bcf[4 * g + 1] = v.y, bcf[4 * g + 2] = v.z, bcf[4 * g + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < WB; ++j) bcf[j] = (tb + j < m) ? bv_in[tb + j] : EXP_ONE_A;
+                }
+                fa = frm_in[(tb + 63) / WB];                    // block that produced column tb
+                fb = tb + 1 < m ? frm_in[(tb + 64) / WB] : fa;  // ... columns tb+1 .. tb+WB-1
+            } else {
+#pragma unroll
+                for (int j = 0; j < WB; ++j) bcf[j] = EXP_ONE_A;
+            }
+        };
+        // (value, exponent) pairs for the per-step form: the exponent of a column is its block's frame word, or -- for a
+        // block that was not published in one frame -- what the exponent plane holds
+        auto boundary_pairs = [&](int tb, const float *bcf, int fa, int fb, u64 *bcv) {
+            if (has_pred && tb < m) {
+#pragma unroll
+                for (int j = 0; j < WB; ++j) {
+                    const int f = j == 0 ? fa : fb;
+                    int e = f;
+                    if (f == FRAME_NONE) e = (tb + j < m) ? be_in[tb + j] : EXP_ONE_E;
+                    bcv[j] = (tb + j < m) ? pack2(__float_as_uint(bcf[j]), (unsigned)e) : edge_zero<KIND>();
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < WB; ++j) bcv[j] = edge_zero<KIND>();
+            }
+        };
         auto fwd_blocks = [&](int c, int t0) {
             if constexpr (FWD_SUB) {
                 int thr = lane + (sw ? 1 : 0);  // EDGE: the lane's cell is live at step t iff t >= thr
                 if (sw && i0 + lane == 0) thr = 0x7fffffff;  // padded row 1 of Smith-Waterman never is
-                for (int sb = 0; sb < K / WB; ++sb) {
+                auto one_block = [&](auto sb_tag) {
+                    constexpr int sb = decltype(sb_tag)::value;
                     const int tb = t0 + sb * WB;
                     const bool blk_interior = plain_strip && tb >= 63 && tb + WB < m;
-                    // ---- boundary values of this block: lane 0 at step tb+j needs column tb+j ----
-                    // (read by each form on its own: the windowed form turns the registers into its `up` values in
-                    // place, and the rare fallback simply reads the row again -- the strip above cannot overwrite these
-                    // columns before this strip has produced its own)
-                    const bool use_pred = has_pred && tb < m;
-                    auto read_bcv = [&](u64 *bcv) {
-                        if (use_pred) {
-                            if (tb + WB <= m) {
-#pragma unroll
-                                for (int j = 0; j < WB; ++j) bcv[j] = bnd_in[tb + j];
-                            } else {
-#pragma unroll
-                                for (int j = 0; j < WB; ++j) bcv[j] = (tb + j < m) ? bnd_in[tb + j] : edge_zero<KIND>();
-                            }
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < WB; ++j) bcv[j] = edge_zero<KIND>();
+                    // experiments build, sdp_set_trace: shader-cycle stamps of this block -- [pair / 64][wave][strip round][block][4]
+                    auto stamp = [&](int k) {
+                        if constexpr (SDP_EXP_BUILD != 0) {
+                            if (p.trace && (b & 63) == 0 && b < 256 && lane == 0 && sidx / W < 2 && tb / WB < 40)
+                                p.trace[((((b >> 6) * 4 + wave) * 2 + sidx / W) * 40 + tb / WB) * 8 + k] = __builtin_readcyclecounter();   // (k < 4 used)
                         }
                     };
+                    stamp(0);
+                    // ---- boundary values of this block: lane 0 at step tb+j needs column tb+j ----
+                    // (the windowed form turns the registers into its `up` values in place, and the rare fallback simply
+                    // reads the row again -- the strip above cannot overwrite these columns before this strip has
+                    // produced its own)
+                    const bool use_pred = has_pred && tb < m;
                     // One LDS round trip per block instead of four: the progress word of the strip above is read FIRST,
-                    // the boundary values, their frame words and (below) this block's inputs are read right behind it, and
-                    // there is a single wait.  LDS executes a wave's reads in order, so if the progress word already covers
-                    // the block, the values read behind it are the published ones; otherwise (only while the pipeline
-                    // fills) the wave spins as before and reads them again.
-                    u64 bcv0[WB];
+                    // the boundary values, their frame words and this block's inputs are read right behind it, and there
+                    // is a single wait.  LDS executes a wave's reads in order, so if the progress word already covers the
+                    // block, the values read behind it are the published ones; otherwise (only while the pipeline fills)
+                    // the wave spins as before and reads them again.
+                    float bcf0[WB];
+                    float in0[WB], in1[WB];
                     int fa0 = 0, fb0 = 0, prog_seen = 0;
                     const int need = tb + WB < m ? tb + WB : m;
                     if (use_pred) {
                         if constexpr (!ABL_NOSYNC) prog_seen = lds_issue_i32(prog + 4 * pword);
-                        read_bcv(bcv0);
-                        fa0 = frm_in[(tb + 63) / WB];                    // block that produced column tb
-                        fb0 = tb + 1 < m ? frm_in[(tb + 64) / WB] : fa0;  // ... columns tb+1 .. tb+WB-1
                     }
-                    // ---- staged inputs of this block ----
-                    float in0[WB], in1[WB];
-                    {
-                        const int pr = (tb & (RING - 1)) + 4 * ring_pi(lane & 7);
-#pragma unroll
-                        for (int g = 0; g < WB / 4; ++g) {
-                            const int idx = lane * PITCH + ((pr + 4 * g) & (RING - 1));
-                            const float4 v0 = *reinterpret_cast<const float4 *>(lds_in + idx);
-                            const float4 v1 = *reinterpret_cast<const float4 *>(lds_in + PLANE + idx);
-                            in0[4 * g] = v0.x, in0[4 * g + 1] = v0.y, in0[4 * g + 2] = v0.z, in0[4 * g + 3] = v0.w;
-                            in1[4 * g] = v1.x, in1[4 * g + 1] = v1.y, in1[4 * g + 2] = v1.z, in1[4 * g + 3] = v1.w;
-                        }
-                    }
+                    read_boundary(tb, bcf0, fa0, fb0);
+                    read_inputs(tb, in0, in1);
                     if (use_pred) {
                         bool ready = ABL_NOSYNC;
                         if constexpr (!ABL_NOSYNC) {
@@ -918,13 +956,55 @@ __device__ __forceinline__ void sweep(const Params &p)
                                     p.status[1] = b, p.status[2] = s, p.status[3] = c | (PASS << 24);
                                 }
                             }
-                            read_bcv(bcv0);
-                            fa0 = frm_in[(tb + 63) / WB];
-                            fb0 = tb + 1 < m ? frm_in[(tb + 64) / WB] : fa0;
+                            read_boundary(tb, bcf0, fa0, fb0);
                         }
                     }
                     u64 hist[WB];
                     int frame_pub = FRAME_NONE;
+                    stamp(1);
+
+                    // ---- publish the block: 16 boundary values, their frame word, then the progress word.  Called at the end of
+                    // whichever form computed the block -- NOT once behind both: with the 16 values (32 registers) flowing
+                    // from two code paths into one publishing site the compiler shuffled them into common registers
+                    // with 45-70 moves per block (a seventh of the block's instructions) ----
+                    auto publish = [&]() {
+                        stamp(2);
+                    // ---- publish the block: 16 boundary values, their frame word, then the progress word ----
+                        if (has_succ) {
+                            const int c_lo = tb - 63;  // lane 63 produced column tb+j-63 at step j
+                            if (lane == PUB_LANE) {
+                                // values always; exponents only where the block is not in one frame (c_lo = tb - 63 is 1 mod 4:
+                                // the 16-byte stores are not aligned, which LDS accepts -- one lane, off the critical path)
+                                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                                // (written as asm: for a 4-byte aligned vector store the compiler emits dword stores)
+                                auto st128 = [&](const void *dst, u32x4 v) {
+                                    asm volatile("ds_write_b128 %0, %1" : : "v"((unsigned)(uintptr_t)dst), "v"(v) : "memory");
+                                };
+                                if (c_lo >= 0 && c_lo + WB <= m) {
+#pragma unroll
+                                    for (int g = 0; g < WB / 4; ++g)
+                                        st128(bv_out + c_lo + 4 * g, (u32x4){lo32(hist[4 * g]), lo32(hist[4 * g + 1]), lo32(hist[4 * g + 2]), lo32(hist[4 * g + 3])});
+                                    if (frame_pub == FRAME_NONE) {
+#pragma unroll
+                                        for (int g = 0; g < WB / 4; ++g)
+                                            st128(be_out + c_lo + 4 * g, (u32x4){hi32(hist[4 * g]), hi32(hist[4 * g + 1]), hi32(hist[4 * g + 2]), hi32(hist[4 * g + 3])});
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int j = 0; j < WB; ++j) {
+                                        const int col = c_lo + j;
+                                        if (col >= 0 && col < m) bv_out[col] = __uint_as_float(lo32(hist[j])), be_out[col] = (int)hi32(hist[j]);
+                                    }
+                                }
+                                frm_out[tb / WB] = frame_pub;
+                            }
+                            const int hi = tb + WB - 63;
+                            const int pub_done = hi < 0 ? 0 : (hi > m ? m : hi);
+                            // LDS executes a wave's DS instructions in order, so the data written above is visible to any
+                            // wave that observes this word (the asm statements also stop compiler reordering)
+                            if (lane == PUB_LANE && !(SDP_EXP_BUILD && (p.dbg & 8))) lds_store_i32(prog + 4 * oword, obase + pub_done);
+                        }
+                    };
 
                     // ---- windowed form; returns 1 = done, 0 = not applicable here, -1 = out of range ----
                     auto wf_block = [&](auto edge_tag, auto pred_tag) -> int {
@@ -954,9 +1034,9 @@ __device__ __forceinline__ void sweep(const Params &p)
                         if (!EDGE || tb > thr) mn = __float_as_uint(x);  // a value that is not live yet may be arbitrarily small
                         float bf[WB];  // lane 0's `up` values in its frame
                         if (use_pred) {
-                            bf[0] = __builtin_amdgcn_ldexpf(__uint_as_float(lo32(bcv0[0])), fa - R);
+                            bf[0] = __builtin_amdgcn_ldexpf(bcf0[0], fa - R);
 #pragma unroll
-                            for (int j = 1; j < WB; ++j) bf[j] = __uint_as_float(lo32(bcv0[j]));
+                            for (int j = 1; j < WB; ++j) bf[j] = bcf0[j];
                         } else {
 #pragma unroll
                             for (int j = 0; j < WB; ++j) bf[j] = xz;
@@ -1035,6 +1115,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                             }
                         }
                         frame_pub = R;
+                        publish();
                         return 1;
                     };
 
@@ -1042,7 +1123,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                     auto norm_block = [&](auto edge_tag) {
                         constexpr bool EDGE = decltype(edge_tag)::value;
                         u64 bcv[WB];
-                        read_bcv(bcv);
+                        boundary_pairs(tb, bcf0, fa0, fb0, bcv);
 #pragma unroll
                         for (int j = 0; j < WB; ++j) {
                             const int t = tb + j;
@@ -1135,6 +1216,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                                 frame_pub = R;
                             }
                         }
+                        publish();
                     };
 
                     bool done = false;
@@ -1151,29 +1233,11 @@ __device__ __forceinline__ void sweep(const Params &p)
                         else norm_block(std::true_type{});
                     }
 
-                    // ---- publish the block: 16 boundary values, their frame word, then the progress word ----
-                    if (has_succ) {
-                        const int c_lo = tb - 63;  // lane 63 produced column tb+j-63 at step j
-                        if (lane == PUB_LANE) {
-                            if (c_lo >= 0 && c_lo + WB <= m) {
-#pragma unroll
-                                for (int j = 0; j < WB; ++j) bnd_out[c_lo + j] = hist[j];
-                            } else {
-#pragma unroll
-                                for (int j = 0; j < WB; ++j) {
-                                    const int col = c_lo + j;
-                                    if (col >= 0 && col < m) bnd_out[col] = hist[j];
-                                }
-                            }
-                            frm_out[tb / WB] = frame_pub;
-                        }
-                        const int hi = tb + WB - 63;
-                        const int pub_done = hi < 0 ? 0 : (hi > m ? m : hi);
-                        // LDS executes a wave's DS instructions in order, so the data written above is visible to any
-                        // wave that observes this word (the asm statements also stop compiler reordering)
-                        if (lane == PUB_LANE && !(SDP_EXP_BUILD && (p.dbg & 8))) lds_store_i32(prog + 4 * oword, obase + pub_done);
-                    }
-                }
+                    stamp(3);
+                };
+                one_block(std::integral_constant<int, 0>{});
+                if constexpr (K / WB > 1) one_block(std::integral_constant<int, 1>{});
+                static_assert(K / WB <= 2, "blocks per chunk");
             }
         };
 

@@ -216,6 +216,8 @@ int sdp_plan(int pass, int B, int N, int M, int has_lens, int exact_state, int c
  * results.  bit0/1/2: inputs / outputs / state of every pair alias pair 0 (all traffic cache-served); bit3: strips
  * never publish their progress, so every hand-off times out (tests the SDP_E_HANDOFF path).  Returns the old mask. */
 int sdp_set_debug(int mask);
+/* Cycle stamps of the forward sweep (tools/fwd_trace.py): a device buffer of >= 40 KiB, or NULL to switch it off. */
+int sdp_set_trace(void *buf);
 #endif
 
 #ifdef __cplusplus
