@@ -23,6 +23,7 @@ SIGNATURES = {
     "sdp_state_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "sdp_state_d_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "sdp_plan": (ctypes.c_int, [ctypes.c_int] * 7 + [ctypes.POINTER(ctypes.c_int)] * 3 + [ctypes.POINTER(ctypes.c_size_t)]),
+    "sdp_plan_parts": (ctypes.c_int, [ctypes.c_int] * 7),
     "sdp_forward_f32": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_int, _c_i32p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "sdp_backward_f32": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -132,6 +132,7 @@ struct Plan {
     Variant v;
     int W;
     size_t lds, stage_off;
+    int parts;   // strips per workgroup when the pairs are spread over several workgroups (0: one workgroup per pair)
 };
 
 // kernel id -> its general-pitch instantiation (or itself if it has none: builds whose staged blocks keep the
@@ -150,8 +151,13 @@ int general_id(int id)
     }
 }
 
+// Strips per part when a pair is spread over several workgroups (sdp_kernels.hip, "PARTS"): one strip per wave of the
+// 4-wave throughput builds.
+constexpr int PART_STRIPS = 4;
+inline int parts_per_pair(int N) { return (sdp::state_nstrips(N) + PART_STRIPS - 1) / PART_STRIPS; }
+
 Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cus, int forced_waves, bool fused_seed = false,
-          bool general_pitch = false)
+          bool general_pitch = false, int allow_parts = 1 /* 0 never, 1 where it pays, 2 wherever it is possible */)
 {
     const int nstrips = sdp::state_nstrips(N);
     const int mcap = (M + 63) / 64 * 64;
@@ -182,6 +188,29 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
     const int nin = (pass == sdp::PASS_AFWD && fused_seed) ? 3 : 0;   // three staged planes (ref, pred, G)
     if (nin) v = variant(10);
     if (general_pitch) v = variant(general_id(v.id));
+    // A pair over several workgroups (sdp_kernels.hip, "PARTS"): parts of four strips, each on a CU of its own, one strip
+    // per wave of the 4-wave throughput builds, instead of one CU taking all the pair's strips in rounds.  It pays only
+    // where CUs would otherwise idle AND the pair is long enough for the extra lag per bridge (measured, round 3, us
+    // forward / backward, one workgroup per pair -> parts):
+    //   per-pair lengths, 256 pairs: n, m <= 1022 x 1020 (BASELINE configs[2]) 648 / 622 -> 592 / 538; <= 832^2 455 / 381 ->
+    //   422 / 363; <= 640^2 295 / 243 -> 274 / 218; <= 512^2 (two parts) 201 / 154 -> 204 / 180 (worse); 64 pairs <= 1022 x 1020
+    //   532 / 385 -> 462 / 309; 700 pairs (more than CUs) 1017 / 1187 -> 1266 / 1209 (worse);
+    //   equal pairs: 16 x 1024^2 445 / 330 -> 451 / 291; 64 x 640 x 500 240 / 163 -> 260 / 183 (worse); 16 x 512^2 worse.
+    // So: three parts or more; with per-pair lengths whenever the batch does not outnumber the CUs; equal pairs only the
+    // backward sweep of pairs of four parts.  The adjoint pair (float64 carries) keeps one workgroup per pair.
+    int parts = 0;
+    const bool parts_fit = sweep12 && forced_waves <= 0 && nstrips > PART_STRIPS;
+    const bool parts_pay = nstrips > 2 * PART_STRIPS && B <= cus &&
+                           (has_lens || (pass == sdp::PASS_BWD && nstrips > 3 * PART_STRIPS && (long long)B * parts_per_pair(N) <= cus));
+    if (parts_fit && (allow_parts == 2 || (allow_parts == 1 && parts_pay))) {
+        Variant tv = variant(pass == sdp::PASS_FWD ? (exact_state ? 9 : 0) : (exact_state ? 7 : 1));
+        if (general_pitch) tv = variant(general_id(tv.id));
+        if (lds_bytes(pass, tv.K, PART_STRIPS, mcap, nullptr) <= 160 * 1024) {
+            v = tv;
+            W = PART_STRIPS;
+            parts = PART_STRIPS;
+        }
+    }
     if (W > v.maxw) W = v.maxw;
     if (W > nstrips) W = nstrips;
     size_t off = 0, lds = 0;
@@ -189,7 +218,7 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
         lds = lds_bytes(pass, v.K, W, mcap, &off, nin);
         if (lds <= 160 * 1024 || W == 1) break;
     }
-    return {v, W, lds, off};
+    return {v, W, lds, off, parts};
 }
 
 // Where the 32-step units of the skewed state live (sdp_kernels.hip, "Skewed state addressing").  Default: every
@@ -239,12 +268,34 @@ size_t packed_body_bytes(int B, int N, int M)
 {
     return (size_t)B * sdp::state_nstrips(N) * sdp::state_tpad(M) * 64 * 6;
 }
-bool wants_order(int B, const int32_t *lens, int device) { return lens != nullptr && B > num_cus(device); }
+bool wants_order(int B, int N, const int32_t *lens, int device)
+{
+    (void)N;
+    return lens != nullptr && B > num_cus(device);
+}
 const int *order_in_state(const void *state, int B, int N, int M, bool exact)
 {
     const size_t body = exact ? (size_t)B * sdp::state_rows2(N, M) * 64 * sizeof(float2)
                               : packed_body_bytes(B, N, M);
     return reinterpret_cast<const int *>(static_cast<const char *>(state) + body);
+}
+// ... and behind the order: the bridge rows between the parts of a pair (8-byte granules; reset before every launch
+// that uses them, so the forward and the backward sweep share the room)
+size_t bridge_bytes(int B, int N, int M)
+{
+    const int np = parts_per_pair(N);
+    return np > 1 ? (size_t)B * (np - 1) * sdp::xb_row_granules(M) * 8 : 0;
+}
+// ... and behind those the dispatch order of the parts of a batch with per-pair lengths (one int per workgroup)
+size_t parts_map_bytes(int B, int N)
+{
+    const int np = parts_per_pair(N);
+    return np > 1 ? ((size_t)B * np * 4 + 255) / 256 * 256 : 0;
+}
+unsigned long long *bridge_in_state(const void *state, int B, int N, int M, bool exact)
+{
+    return reinterpret_cast<unsigned long long *>(const_cast<char *>(reinterpret_cast<const char *>(order_in_state(state, B, N, M, exact))) +
+                                                  sdp::state_order_bytes(B));
 }
 
 // flags or-ed into `variant` (include/sdp.h): SDP_EXACT_STATE, SDP_WAVES(w)
@@ -282,7 +333,8 @@ int raise_lds_limit(const Variant &v, int device)
     return 0;
 }
 
-int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state = false, int forced_waves = 0, bool fused_seed = false)
+int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state = false, int forced_waves = 0, bool fused_seed = false,
+           const void *state = nullptr)
 {
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
@@ -303,14 +355,41 @@ int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state 
     // caller may pass a view)
     auto misaligned = [](const void *ptr) { return ptr != nullptr && ((uintptr_t)ptr & 127u) != 0; };
     const bool general_pitch = (p.M & 31) != 0 || misaligned(p.sin0) || misaligned(p.sin1) || misaligned(p.sin2) || misaligned(p.sout);
-    const Plan pl = plan(pass, p.B, p.N, p.M, p.lens != nullptr, exact_state, num_cus(device), forced_waves, fused_seed, general_pitch);
+    int allow_parts = state != nullptr ? 1 : 0;
+#ifdef SDP_EXPERIMENTS
+    if (allow_parts && (g_dbg.load() & 512)) allow_parts = 2;   // sdp_set_debug(512): parts wherever they are possible (bit-identity test)
+    if (g_dbg.load() & 64) allow_parts = 0;   // sdp_set_debug(64): one workgroup per pair whatever the shape (A/B timing, bit-identity test)
+    if ((g_dbg.load() & 128) && pass == sdp::PASS_BWD) allow_parts = 0;   // (128: ... in the backward sweep only)
+    if ((g_dbg.load() & 256) && pass == sdp::PASS_FWD) allow_parts = 0;   // (256: ... in the forward sweep only)
+#endif
+    const Plan pl = plan(pass, p.B, p.N, p.M, p.lens != nullptr, exact_state, num_cus(device), forced_waves, fused_seed, general_pitch, allow_parts);
     const Variant v = pl.v;
     const int W = pl.W;
     const size_t lds = pl.lds, off = pl.stage_off;
     p.stage_off = (int)off;
     if (int rc = raise_lds_limit(v, device)) return rc;
+    unsigned grid = (unsigned)p.B;
+    if (pl.parts) {
+        p.parts = pl.parts;
+        p.nparts_max = parts_per_pair(p.N);
+        p.xb = bridge_in_state(state, p.B, p.N, p.M, exact_state);
+        p.xb_row = sdp::xb_row_granules(p.M);
+        // every granule "not written yet" (tag 0x7f7f7f7f): enqueued on the caller's stream like the launch itself
+        e = hipMemsetAsync(p.xb, 0x7f, bridge_bytes(p.B, p.N, p.M), (hipStream_t)stream);
+        if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(bridge rows)");
+        grid = (unsigned)p.B * (unsigned)p.nparts_max;
+        p.order = nullptr;
+        if (p.lens != nullptr) {
+            int *map = reinterpret_cast<int *>(reinterpret_cast<char *>(p.xb) + bridge_bytes(p.B, p.N, p.M));
+            hipLaunchKernelGGL(sdp_parts_map_kernel, dim3((grid + 3) / 4), dim3(256), 0, (hipStream_t)stream, p.lens, map, p.B, p.N, p.M,
+                               p.nparts_max, pl.parts);
+            e = hipGetLastError();
+            if (e != hipSuccess) return fail_hip(e, "sdp_parts_map_kernel");
+            p.wg_map = map;
+        }
+    }
     void *args[] = {&p};
-    e = hipLaunchKernel(v.kernel, dim3(p.B), dim3(64 * W), args, lds, (hipStream_t)stream);
+    e = hipLaunchKernel(v.kernel, dim3(grid), dim3(64 * W), args, lds, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hipLaunchKernel");
     return 0;
 }
@@ -331,13 +410,13 @@ size_t sdp_state_bytes(int B, int N, int M)
     // 2 x 23 bits per cell, 3 dwords per 2 cells (a 768-byte record row per pair of steps); + the launch order of a
     // variable-length batch.  Problems longer than PACKED_MAX_PATH keep the exact state (see exact_for).
     if (exact_for(false, N, M)) return sdp_state_d_bytes(B, N, M);
-    return packed_body_bytes(B, N, M) + sdp::state_order_bytes(B);
+    return packed_body_bytes(B, N, M) + sdp::state_order_bytes(B) + bridge_bytes(B, N, M) + parts_map_bytes(B, N);
 }
 
 size_t sdp_state_d_bytes(int B, int N, int M)
 {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
-    return (size_t)B * sdp::state_rows2(N, M) * 64 * sizeof(float2) + sdp::state_order_bytes(B);
+    return (size_t)B * sdp::state_rows2(N, M) * 64 * sizeof(float2) + sdp::state_order_bytes(B) + bridge_bytes(B, N, M) + parts_map_bytes(B, N);
 }
 
 int sdp_plan(int pass, int B, int N, int M, int has_lens, int exact_state, int cus, int *kernel_id, int *chunk,
@@ -353,6 +432,13 @@ int sdp_plan(int pass, int B, int N, int M, int has_lens, int exact_state, int c
     if (waves) *waves = pl.W;
     if (lds) *lds = pl.lds;
     return 0;
+}
+
+int sdp_plan_parts(int pass, int B, int N, int M, int has_lens, int exact_state, int cus)
+{
+    if (pass < 0 || pass > 3 || check_shape(B, N, M, SDP_NW) || cus <= 0) return 0;
+    const bool exact = (pass == sdp::PASS_FWD || pass == sdp::PASS_BWD) ? exact_for(exact_state != 0, N, M) : exact_state != 0;
+    return plan(pass, B, N, M, has_lens != 0, exact, cus, 0).parts;
 }
 
 int sdp_init(int device)
@@ -384,7 +470,7 @@ int sdp_set_debug(int mask)
 {
     return g_dbg.exchange(mask);
 }
-// device buffer (>= 4 pairs x 4 waves x 2 strips x 40 blocks x 8 stamps x 8 B = 80 KiB) that the forward sweep of pairs
+// device buffer (>= 4 pairs x 4 waves x 4 strip rounds or parts x 40 blocks x 8 stamps x 8 B = 160 KiB) that the forward sweep of pairs
 // 0, 64, 128, 192 fills with shader-cycle stamps per 16-step block; null = off
 int sdp_set_trace(void *buf)
 {
@@ -408,16 +494,16 @@ int sdp_forward_f32(const float *theta, const float *A, float *state, float *Vt,
     p.vout = Vt;
     p.lens = lens;
     p.B = B, p.N = N, p.M = M, p.variant = variant;
-    if (wants_order(B, lens, device)) {
+    if (wants_order(B, N, lens, device)) {
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
         int *order = const_cast<int *>(order_in_state(state, B, N, M, exact));
         hipLaunchKernelGGL(sdp_order_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, lens, order, B, N, M);
         e = hipGetLastError();
         if (e != hipSuccess) return fail_hip(e, "sdp_order_kernel");
-        p.order = order;
+        if (B > num_cus(device)) p.order = order;   // (with parts the launch takes it from the state by itself)
     }
-    return launch(sdp::PASS_FWD, p, device, stream, exact, vb.waves);
+    return launch(sdp::PASS_FWD, p, device, stream, exact, vb.waves, false, state);
 }
 
 int sdp_backward_f32(const float *Et, const float *state, float *E, int B, int N, int M, const int32_t *lens,
@@ -434,8 +520,8 @@ int sdp_backward_f32(const float *Et, const float *state, float *E, int B, int N
     p.sout = E;
     p.lens = lens;
     p.B = B, p.N = N, p.M = M, p.variant = variant;
-    if (wants_order(B, lens, device)) p.order = order_in_state(state, B, N, M, exact);
-    return launch(sdp::PASS_BWD, p, device, stream, exact, vb.waves);
+    if (lens != nullptr && B > num_cus(device)) p.order = order_in_state(state, B, N, M, exact);
+    return launch(sdp::PASS_BWD, p, device, stream, exact, vb.waves, false, state);
 }
 
 int sdp_adjoint_forward_f32(const float *state, const float *Ztheta, const float *ZA, float *Vtd, float *state_d,
@@ -453,7 +539,7 @@ int sdp_adjoint_forward_f32(const float *state, const float *Ztheta, const float
     p.vout = Vtd;
     p.lens = lens;
     p.B = B, p.N = N, p.M = M, p.variant = variant;
-    if (wants_order(B, lens, device)) p.order = order_in_state(state, B, N, M, true);
+    if (lens != nullptr && B > num_cus(device)) p.order = order_in_state(state, B, N, M, true);
     return launch(sdp::PASS_AFWD, p, device, stream, false, vb.waves);
 }
 
@@ -478,7 +564,7 @@ int sdp_adjoint_forward_loss_f32(const float *state, const float *ref, const flo
     p.vout = Vtd;
     p.lens = lens;
     p.B = B, p.N = N, p.M = M, p.variant = variant;
-    if (wants_order(B, lens, device)) p.order = order_in_state(state, B, N, M, true);
+    if (lens != nullptr && B > num_cus(device)) p.order = order_in_state(state, B, N, M, true);
     return launch(sdp::PASS_AFWD, p, device, stream, false, vb.waves, true);
 }
 
@@ -496,7 +582,7 @@ int sdp_adjoint_backward_f32(const float *E, const float *state, const float *st
     p.sout = Ed;
     p.lens = lens;
     p.B = B, p.N = N, p.M = M, p.variant = variant;
-    if (wants_order(B, lens, device)) p.order = order_in_state(state, B, N, M, true);
+    if (lens != nullptr && B > num_cus(device)) p.order = order_in_state(state, B, N, M, true);
     return launch(sdp::PASS_ABWD, p, device, stream, false, vb.waves);
 }
 

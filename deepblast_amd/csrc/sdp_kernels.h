@@ -95,7 +95,18 @@ struct Params {
     const int *order;    // launch order (pair per workgroup) or null = identity; lives in the tail of the Q state buffer
     int *status;         // host-visible status words of the device: [0] hand-off time-outs, [1..3] first (pair, strip, chunk | pass << 24)
     unsigned long long *trace;   // experiments build only (sdp_set_trace): cycle stamps of the forward sweep's blocks, or null
+    int parts;           // strips per workgroup when a pair is spread over several (0 = one workgroup per pair)
+    int nparts_max;      // workgroups per pair launched: ceil(ceil(N / 64) / parts)
+    unsigned long long *xb;   // bridge between parts: per (pair, boundary between two parts) xb_row granules of 8 bytes
+    int xb_row;          // granules per bridged boundary row
+    const int *wg_map;   // parts with per-pair lengths: workgroup -> pair * nparts_max + part (sdp_parts_map_kernel), or null
 };
+
+// granules per bridged boundary row: one per column, shifted by 63 in the forward sweep (a block of 16 published values
+// starts at column 16 j - 63), rounded up to whole 128-byte lines, plus one chunk of slack
+__host__ __device__ inline int xb_frame_base(int M) { return (M + 63 + 63) / 64 * 64 + 64; }                 // column granules (+ slack for whole units)
+__host__ __device__ inline int xb_row_granules(int M) { return xb_frame_base(M) + (M + 63 + 63) / 64 * 4 + 4; }   // + one frame granule per 16-step block
+constexpr unsigned XB_INVALID = 0x7f7f7f7fu;   // tag (high word) of a granule that has not been written: the memset pattern
 
 // per-wave LDS staging (floats): input planes are rings [64][2K], the output ring is [64][2K+1]
 __host__ __device__ constexpr int stage_out_pitch(int K) { return 2 * K + 1; }
@@ -159,6 +170,7 @@ __global__ void sdp_scores_x6_kernel(const float *zx, const float *zy, const flo
 __global__ void sdp_scores_x6w_kernel(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
                                       int M, int D);
 __global__ void sdp_order_kernel(const int *lens, int *order, int B, int N, int M);
+__global__ void sdp_parts_map_kernel(const int *lens, int *map, int B, int N, int M, int nparts_max, int strips);
 __global__ void sdp_traceback_kernel(const float *grad, int *states, int *counts, const int *lens, int B, int N, int M, int cap);
 __global__ void sdp_traceback_cuda_kernel(const float *grad, int *states, int *counts, const int *lens, int B, int N, int M, int cap);
 }

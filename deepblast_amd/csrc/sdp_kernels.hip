@@ -420,7 +420,23 @@ __device__ __forceinline__ void sweep(const Params &p)
     // batches with per-pair lengths and more pairs than CUs are launched longest-first (p.order: pair handled by
     // each workgroup, written by sdp_order_kernel): the hardware hands workgroups to CUs in index order as they
     // free up, which then is the longest-processing-time-first rule
-    const int b = p.order ? p.order[blockIdx.x] : (int)blockIdx.x;
+    //
+    // PARTS (p.parts > 0; forward and fp32 backward sweeps): a pair's strips are cut into parts of p.parts strips and every
+    // part is a workgroup of its own -- on its own CU -- so that a long pair is swept by several CUs at once, each with
+    // one strip per wave, instead of one CU taking the strips in rounds.  The boundary between the last strip of a part
+    // and the first strip of the next crosses CUs through global memory (see "bridge" below).  Which (pair, part) a
+    // workgroup takes follows from a priority order in which a consumer always has a higher index than its producer:
+    // workgroups are dispatched in index order, so a waiting part never keeps its producer off the chip.
+    int wg_pair = (int)blockIdx.x, wg_part = 0;
+    if (p.parts) {
+        if (p.wg_map) {   // per-pair lengths: sdp_parts_map_kernel ranked the parts by the critical path that hangs on them
+            const int e = p.wg_map[blockIdx.x];
+            wg_pair = e / p.nparts_max, wg_part = e % p.nparts_max;
+        } else {          // equal pairs: every pair's part 0, then every pair's part 1, ...
+            wg_pair = (int)blockIdx.x % p.B, wg_part = (int)blockIdx.x / p.B;
+        }
+    }
+    const int b = (p.order && !p.parts) ? p.order[wg_pair] : wg_pair;
 
     int n = p.N, m = p.M;
     if (p.lens) {
@@ -434,6 +450,15 @@ __device__ __forceinline__ void sweep(const Params &p)
     const int nstrips = (n + 63) >> 6;
     const int nchunks = (m + 63 + K - 1) / K;  // steps t in [0, m+63)
     const bool sw = p.variant == SDP_SW;
+    // strips of this workgroup: [s_lo, s_hi).  Reverse sweeps count their parts from the END of the pair (part 0 = the last
+    // strips, swept first), so that also there a producer has the lower workgroup index.
+    const int nparts = p.parts ? (nstrips + p.parts - 1) / p.parts : 1;
+    const int part = wg_part;
+    if (part >= nparts) return;   // this pair has fewer parts than the longest pair of the batch
+    const int part_pos = (REV && p.parts) ? nparts - 1 - part : part;   // position of the part in strip order
+    const int s_lo = p.parts ? part_pos * p.parts : 0;
+    const int s_hi = p.parts ? (s_lo + p.parts < nstrips ? s_lo + p.parts : nstrips) : nstrips;
+    const int nstrips_wg = s_hi - s_lo;
 
     // ---- LDS carve: boundary rows (8-byte slots), progress words, per-wave staging ----
     // Two boundary rows suffice for any number of waves: strip s+2 can only overwrite column c of the row it
@@ -449,7 +474,7 @@ __device__ __forceinline__ void sweep(const Params &p)
     float *lds_in = stage;
     float *lds_out = stage + T::SIN * PLANE;
 
-    if (threadIdx.x < (unsigned)W) lds_store_i32(prog + 4 * threadIdx.x, 0);
+    if (threadIdx.x <= (unsigned)W) lds_store_i32(prog + 4 * threadIdx.x, 0);   // (word W: imported boundaries)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the store above is inline asm: the compiler's own counter tracking does not see it
     __syncthreads();
 
@@ -463,9 +488,9 @@ __device__ __forceinline__ void sweep(const Params &p)
     // long before the batch's longest pair), otherwise by every wave after its last strip.
     auto zero_fill = [&]() {
         if constexpr (T::SOUT > 0) {
-            if (p.lens == nullptr || (n == p.N && m == p.M)) return;
-            const int idle = W > nstrips ? W - nstrips : 0;
-            const int parts = idle > 0 ? idle : W, part = idle > 0 ? wave - nstrips : wave;
+            if (p.lens == nullptr || (n == p.N && m == p.M) || part != 0) return;   // (with parts: the first workgroup of the pair)
+            const int idle = W > nstrips_wg ? W - nstrips_wg : 0;
+            const int parts = idle > 0 ? idle : W, part = idle > 0 ? wave - nstrips_wg : wave;
             if (part < 0) return;
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 z4 = {0u, 0u, 0u, 0u};
@@ -490,7 +515,7 @@ __device__ __forceinline__ void sweep(const Params &p)
             }
         }
     };
-    if (wave >= nstrips) {
+    if (wave >= nstrips_wg) {
         zero_fill();
         return;
     }
@@ -516,15 +541,21 @@ __device__ __forceinline__ void sweep(const Params &p)
     const float et = (PASS == PASS_BWD) ? p.vin[b] : 0.f;
     const float seed_scale = (PASS == PASS_AFWD && QX) ? p.vin[b] : 0.f;   // fused loss seed: per-pair factor of dLoss/dE
 
-    for (int sidx = wave; sidx < nstrips; sidx += W) {
-        const int s = REV ? nstrips - 1 - sidx : sidx;  // strip handled now
+    for (int sidx = wave; sidx < nstrips_wg; sidx += W) {
+        const int s = REV ? s_hi - 1 - sidx : s_lo + sidx;  // strip handled now
         const int i0 = s << 6;
         const int rows = (n - i0) < 64 ? (n - i0) : 64;
         const bool has_pred = REV ? (s + 1 < nstrips) : (s > 0);   // strip whose boundary we consume
         const bool has_succ = REV ? (s > 0) : (s + 1 < nstrips);   // strip that consumes ours
         const int pidx = sidx - 1;                                  // producer's position in processing order
-        const int pslot = has_pred ? pidx % nslot : 0, oslot = sidx % nslot;                 // boundary rows
-        const int pword = has_pred ? pidx % W : 0, pbase = has_pred ? (pidx / W) * PROG_STRIDE : 0;  // progress words
+        // bridged: the strip whose boundary we consume / that consumes ours belongs to another workgroup (parts)
+        const bool imported = has_pred && sidx == 0 && p.parts != 0;
+        const bool exported = has_succ && sidx == nstrips_wg - 1 && p.parts != 0;
+        // the boundary row an imported boundary is replayed into is the one strip sidx + 1 publishes to: that strip
+        // trails this one by a whole lag and never reaches a column this strip still has to read; its progress word
+        // is word W (no wave's own)
+        const int pslot = has_pred ? (imported ? 1 : pidx % nslot) : 0, oslot = sidx % nslot;                 // boundary rows
+        const int pword = has_pred ? (imported ? W : pidx % W) : 0, pbase = (has_pred && !imported) ? (pidx / W) * PROG_STRIDE : 0;  // progress words
         const int oword = sidx % W, obase = (sidx / W) * PROG_STRIDE;
         const u64 *bnd_in = bnd + (size_t)pslot * p.mcap;
         u64 *bnd_out = bnd + (size_t)oslot * p.mcap;
@@ -863,6 +894,80 @@ __device__ __forceinline__ void sweep(const Params &p)
         const int *be_in = reinterpret_cast<const int *>(bnd_in) + p.mcap;
         float *bv_out = reinterpret_cast<float *>(bnd_out);
         int *be_out = reinterpret_cast<int *>(bnd_out) + p.mcap;
+        // ---- bridge between parts (p.parts): a boundary that crosses workgroups travels through global memory as 8-byte
+        // GRANULES {value, tag}: one naturally aligned 8-byte store per column (write-through, sc0 sc1), so a granule is
+        // either wholly the memset pattern or wholly written, and neither side needs a flag or a fence (the tag -- the
+        // exponent in the forward sweep, 0 in the fp32 backward sweep -- can never equal the pattern).  The PRODUCER
+        // publishes into its LDS row as always and then copies what it published to the bridge row, one granule per lane,
+        // one store instruction per block / chunk.  The CONSUMER replays the producer's publishing into its own LDS row
+        // before it looks at the row -- values, frame word, progress word, exactly what a strip of its own workgroup would
+        // have written -- so everything behind the LDS protocol is unchanged.  Granules are loaded one block / chunk ahead.
+        const int xb_in_k = REV ? part_pos : part_pos - 1, xb_out_k = REV ? part_pos - 1 : part_pos;   // boundary k lies between part positions k, k + 1
+        __amdgpu_buffer_rsrc_t rs_xi = make_rsrc(imported ? (const void *)(p.xb + ((size_t)b * (p.nparts_max - 1) + xb_in_k) * p.xb_row) : (const void *)p.vout,
+                                                 imported ? (unsigned)p.xb_row * 8u : 0u);
+        __amdgpu_buffer_rsrc_t rs_xo = make_rsrc(exported ? (const void *)(p.xb + ((size_t)b * (p.nparts_max - 1) + xb_out_k) * p.xb_row) : (const void *)p.vout,
+                                                 exported ? (unsigned)p.xb_row * 8u : 0u);
+        constexpr int XB_AUX = 17;   // sc0 sc1: stores write through to memory, loads are served from memory (no XCD's L2 in between)
+        constexpr int XN = (PASS == PASS_FWD) ? WB : K;   // column granules per unit: a 16-step block (forward) / a chunk (reverse)
+        // the forward sweep's blocks also have a FRAME word (the exponent all the block's columns were published in, or
+        // FRAME_NONE), and which form the consumer's block takes -- its rounding -- depends on it: it travels as one more
+        // granule {frame, 0} per block, behind the columns of the row, written and read by lane XN in the same instructions
+        constexpr int XV = (PASS == PASS_FWD) ? XN + 1 : XN;   // lanes that hold a granule
+        const int xb_frm0 = xb_frame_base(p.M);
+        auto xb_off = [&](int unit) -> unsigned {
+            if (lane < XN) return (unsigned)((unit * XN + lane) * 8);
+            return (PASS == PASS_FWD && lane == XN) ? (unsigned)((xb_frm0 + unit) * 8) : OOB;
+        };
+        // granules are loaded TWO units ahead of their use, into two register sets that take turns (set = unit & 1): a
+        // load that bypasses the L2s takes 1-2 us, a block of the forward sweep ~1.5 us
+        unsigned xg_lo[2] = {0u, 0u}, xg_hi[2] = {XB_INVALID, XB_INVALID};   // lanes < XN hold one granule each
+        int xg_unit[2] = {-(1 << 30), -(1 << 30)};                             // which unit a set holds
+        int ximp = (PASS == PASS_FWD) ? 0 : (m - 1) / K;   // next unit to import: producer block (ascending) / producer chunk (descending)
+        constexpr int XDIR = (PASS == PASS_FWD) ? 1 : -1;
+        auto xb_issue_set = [&](auto set_tag, int unit) {
+            constexpr int st = decltype(set_tag)::value;
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_xi, unit >= 0 ? xb_off(unit) : OOB, 0, XB_AUX);
+            const unsigned v0 = v[0], v1 = v[1];
+            xg_lo[st] = v0, xg_hi[st] = v1, xg_unit[st] = unit;
+        };
+        auto xb_issue = [&](int unit) {
+            if (unit & 1) xb_issue_set(std::integral_constant<int, 1>{}, unit);
+            else xb_issue_set(std::integral_constant<int, 0>{}, unit);
+        };
+        // -> the unit's granules (value, tag) once every one of them is there (bounded spin, reported like a missed LDS
+        // hand-off).  A consumer that has caught up with its producer finds its early loads still unwritten and has to ask
+        // again -- a round trip to memory for EVERY unit from then on, since it keeps running right behind the producer.
+        // So a consumer that had to wait lets the producer get XB_LAG units ahead before it carries on (once; if it
+        // catches up again, again): after that the early loads hit.
+        constexpr int XB_LAG = 4;
+        const int x_last = (PASS == PASS_FWD) ? nchunks * (K / WB) - 1 : 0;   // the last unit the producer writes
+        auto xb_wait = [&](int unit, int c, unsigned &glo, unsigned &ghi) {
+            const int st = unit & 1;
+            if ((st ? xg_unit[1] : xg_unit[0]) != unit) xb_issue(unit);
+            glo = st ? xg_lo[1] : xg_lo[0], ghi = st ? xg_hi[1] : xg_hi[0];
+            bool ok = __builtin_amdgcn_ballot_w64(lane < XV && ghi == XB_INVALID) == 0;
+            if (!ok) {
+                const int spin_cap = (SDP_EXP_BUILD && (p.dbg & 8)) ? (1 << 8) : (1 << 19);
+                const int ahead = (PASS == PASS_FWD) ? (unit + XB_LAG < x_last ? unit + XB_LAG : x_last) : (unit - XB_LAG > 0 ? unit - XB_LAG : 0);
+                for (int spin = 0; spin < spin_cap && !ok; ++spin) {   // the unit ahead is written after the unit itself
+                    __builtin_amdgcn_s_sleep(4);
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_xi, xb_off(ahead), 0, XB_AUX);
+                    const unsigned v1 = v[1];
+                    ok = __builtin_amdgcn_ballot_w64(lane < XV && v1 == XB_INVALID) == 0;
+                }
+                xb_issue(unit);
+                glo = st ? xg_lo[1] : xg_lo[0], ghi = st ? xg_hi[1] : xg_hi[0];
+                ok = ok && __builtin_amdgcn_ballot_w64(lane < XV && ghi == XB_INVALID) == 0;
+                if (!ok && p.status && lane == 0) {
+                    if (__hip_atomic_fetch_add(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+                        p.status[1] = b, p.status[2] = s, p.status[3] = c | (PASS << 24);
+                    }
+                }
+                xb_issue(unit + XDIR);   // (its early load predates the wait)
+            }
+            xb_issue(unit + 2 * XDIR);   // two units ahead, into the set this unit leaves
+            return ok;
+        };
         auto read_boundary = [&](int tb, float *bcf, int &fa, int &fb) {   // lane 0 at step tb+j needs column tb+j
             if (has_pred && tb < m) {
                 if (tb + WB <= m) {
@@ -909,8 +1014,8 @@ __device__ __forceinline__ void sweep(const Params &p)
                     // experiments build, sdp_set_trace: shader-cycle stamps of this block -- [pair / 64][wave][strip round][block][4]
                     auto stamp = [&](int k) {
                         if constexpr (SDP_EXP_BUILD != 0) {
-                            if (p.trace && (b & 63) == 0 && b < 256 && lane == 0 && sidx / W < 2 && tb / WB < 40)
-                                p.trace[((((b >> 6) * 4 + wave) * 2 + sidx / W) * 40 + tb / WB) * 8 + k] = __builtin_readcyclecounter();   // (k < 4 used)
+                            if (p.trace && (b & 63) == 0 && b < 256 && lane == 0 && (p.parts ? part < 4 : sidx / W < 2) && tb / WB < 40)
+                                p.trace[((((b >> 6) * 4 + wave) * 4 + (p.parts ? part : sidx / W)) * 40 + tb / WB) * 8 + k] = __builtin_readcyclecounter();   // (k < 4 used)
                         }
                     };
                     stamp(0);
@@ -928,6 +1033,28 @@ __device__ __forceinline__ void sweep(const Params &p)
                     float in0[WB], in1[WB];
                     int fa0 = 0, fb0 = 0, prog_seen = 0;
                     const int need = tb + WB < m ? tb + WB : m;
+                    if (use_pred && imported) {
+                        // replay the producer blocks this block depends on: block j published columns 16 j - 63 .. 16 j - 48 and
+                        // left the progress word at 16 j - 47 (clipped to [0, m])
+                        const int jneed = (need + 47 + 15) / 16;
+                        float *bv_w = reinterpret_cast<float *>(bnd + (size_t)pslot * p.mcap);
+                        int *be_w = reinterpret_cast<int *>(bv_w) + p.mcap;
+                        int *frm_w = frm + pslot * FRAME_CAP;
+                        while (ximp <= jneed) {
+                            unsigned xg_lo = 0, xg_hi = 0;
+                            xb_wait(ximp, c, xg_lo, xg_hi);
+                            const int col = 16 * ximp - 63 + lane;
+                            const bool colok = lane < WB && col >= 0 && col < m;
+                            if (colok) bv_w[col] = __uint_as_float(xg_lo), be_w[col] = (int)xg_hi;
+                            const int frame = __builtin_amdgcn_readlane((int)xg_lo, XN);   // the block's frame word, as the producer wrote it
+                            const int hi_ = 16 * ximp - 47, done_ = hi_ < 0 ? 0 : (hi_ > m ? m : hi_);
+                            if (lane == 0) {
+                                frm_w[ximp] = frame;
+                                lds_store_i32(prog + 4 * pword, done_);   // behind the values: LDS executes a wave's instructions in order
+                            }
+                            ++ximp;
+                        }
+                    }
                     if (use_pred) {
                         if constexpr (!ABL_NOSYNC) prog_seen = lds_issue_i32(prog + 4 * pword);
                     }
@@ -1003,6 +1130,22 @@ __device__ __forceinline__ void sweep(const Params &p)
                             // LDS executes a wave's DS instructions in order, so the data written above is visible to any
                             // wave that observes this word (the asm statements also stop compiler reordering)
                             if (lane == PUB_LANE && !(SDP_EXP_BUILD && (p.dbg & 8))) lds_store_i32(prog + 4 * oword, obase + pub_done);
+                            if (exported) {
+                                // the same 16 columns to the bridge row, one granule per lane (columns outside the matrix: a
+                                // valid dummy -- the consumer waits for whole blocks)
+                                const int col = c_lo + lane;
+                                const bool colok = lane < WB && col >= 0 && col < m;
+                                unsigned gv = __float_as_uint(EXP_ONE_A), ge = (unsigned)EXP_ONE_E;
+                                const int fpub = __builtin_amdgcn_readlane(frame_pub, PUB_LANE);   // (every lane has a frame of its own: the publishing lane's)
+                                if (colok) {
+                                    gv = __float_as_uint(bv_out[col]);
+                                    ge = fpub != FRAME_NONE ? (unsigned)fpub : (unsigned)be_out[col];
+                                }
+                                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                                if (!(SDP_EXP_BUILD && (p.dbg & 8)))
+                                    __builtin_amdgcn_raw_buffer_store_b64(lane == WB ? (u32x2){(unsigned)fpub, 0u} : (u32x2){gv, ge}, rs_xo,
+                                                                          lane < WB ? (unsigned)((tb + lane) * 8) : (lane == WB ? (unsigned)((xb_frm0 + tb / WB) * 8) : OOB), 0, XB_AUX);
+                            }
                         }
                     };
 
@@ -1322,6 +1465,22 @@ __device__ __forceinline__ void sweep(const Params &p)
                     } else {
                         const int hi = c_lo + K < m ? c_lo + K : m;
                         need = (c_lo < m) ? hi : 0;
+                    }
+                }
+                if constexpr (REV && KIND == CK_F32) {
+                    if (need > 0 && imported) {
+                        // replay the producer's chunks (it works through the columns from the right, K at a time, and leaves the
+                        // progress word at m - first column) down to the one that holds the lowest column needed here
+                        const int lo = c_lo < 0 ? 0 : c_lo;
+                        u64 *bnd_w = bnd + (size_t)pslot * p.mcap;
+                        while (ximp >= lo / K) {
+                            unsigned xg_lo = 0, xg_hi = 0;
+                            xb_wait(ximp, c, xg_lo, xg_hi);
+                            const int col = ximp * K + lane;
+                            if (lane < K && col < m) bnd_w[col] = pack2(xg_lo, 0u);
+                            if (lane == 0) lds_store_i32(prog + 4 * pword, m - ximp * K);
+                            --ximp;
+                        }
                     }
                 }
                 if (need > 0) {
@@ -1822,6 +1981,16 @@ __device__ __forceinline__ void sweep(const Params &p)
                     }
                 }
                 if (lane == PUB_LANE && !(SDP_EXP_BUILD && (p.dbg & 8))) lds_store_i32(prog + 4 * oword, obase + done);
+                if constexpr (REV && KIND == CK_F32) {
+                    if (exported && t0 < m) {
+                        // the chunk's columns to the bridge row, one granule per lane (tag 0; columns past the matrix: dummies)
+                        const int col = t0 + lane;
+                        const unsigned gv = (lane < K && col < m) ? lo32(bnd_out[col]) : 0u;
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        if (!(SDP_EXP_BUILD && (p.dbg & 8)))
+                            __builtin_amdgcn_raw_buffer_store_b64((u32x2){gv, 0u}, rs_xo, lane < K ? (unsigned)(col * 8) : OOB, 0, XB_AUX);
+                    }
+                }
             }
 
             // ---- flush: one memory-aligned K-element block per row (see fo_* above) ----
@@ -1896,6 +2065,41 @@ extern "C" __global__ void __launch_bounds__(256) sdp_order_kernel(const int *le
         rank += (w > mine || (w == mine && i < b)) ? 1 : 0;
     }
     order[rank] = b;
+}
+
+// ----------------------------------------------------------------------------------
+// dispatch order when pairs are spread over several workgroups ("parts") and have their own lengths: map[h] = pair *
+// nparts_max + part for workgroup h.  Priority = the length of the critical path that still hangs on a part, in steps: a
+// part is ready one four-strip lag after the part before it, and a pair is done one part's run after its last part
+// started -- so part k of a pair with P parts and m columns has (P - 1 - k) * 4 * 79 + 3 * 79 + m + 63 steps ahead of
+// it.  Sorting by that, largest first, starts every pair's parts in order (a producer always precedes its consumer),
+// puts the long pairs' first parts ahead of everything and the parts that could only wait behind work that can run.
+// Parts a pair does not have sort last (their workgroups exit at once).  Rank by counting, as above.
+// ----------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(256) sdp_parts_map_kernel(const int *lens, int *map, int B, int N, int M, int nparts_max, int strips)
+{
+    // one wavefront per workgroup-to-be: its 64 lanes share the scan over the list (ranking 1024 parts with one thread
+    // each took ~50 us -- a tenth of the sweep it was meant to speed up)
+    const int h = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int total = B * nparts_max;
+    if (h >= total) return;
+    auto key = [&](int e) {
+        const int pr = e / nparts_max, k = e % nparts_max;
+        int n = lens[2 * pr], m = lens[2 * pr + 1];
+        n = n < 1 ? 1 : (n > N ? N : n);
+        m = m < 1 ? 1 : (m > M ? M : m);
+        const int np = ((n + 63) / 64 + strips - 1) / strips;
+        return k < np ? (np - 1 - k) * strips * 79 + (strips - 1) * 79 + m + 63 : -1;
+    };
+    const int mine = key(h);
+    int cnt = 0;
+    for (int e = lane; e < total; e += 64) {
+        const int w = key(e);
+        cnt += (w > mine || (w == mine && e < h)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) map[cnt] = h;
 }
 
 // ----------------------------------------------------------------------------------

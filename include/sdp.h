@@ -211,10 +211,18 @@ int sdp_device_status(int device, int32_t info[4]);
 int sdp_plan(int pass, int B, int N, int M, int has_lens, int exact_state, int cus, int *kernel_id, int *chunk,
              int *waves, size_t *lds);
 
+/* ... and whether that launch would spread every pair over several workgroups (CUs): the number of 64-row strips per
+ * workgroup, or 0 for one workgroup per pair.  Forward and backward sweeps do it where it was measured to pay: padded
+ * batches with per-pair lengths and pairs of more than eight strips (the batch takes as long as its longest pair), and the
+ * backward sweep of a few equal pairs of more than twelve strips; the boundary between two parts of a pair then crosses
+ * CUs through 8-byte granules in the tail of the state buffer.  Results do not depend on it (bit-identical). */
+int sdp_plan_parts(int pass, int B, int N, int M, int has_lens, int exact_state, int cus);
+
 #ifdef SDP_EXPERIMENTS
 /* Only in libraries built with -DSDP_EXPERIMENTS (never the shipped one): timing experiments that produce WRONG
  * results.  bit0/1/2: inputs / outputs / state of every pair alias pair 0 (all traffic cache-served); bit3: strips
- * never publish their progress, so every hand-off times out (tests the SDP_E_HANDOFF path).  Returns the old mask. */
+ * never publish their progress, so every hand-off times out (tests the SDP_E_HANDOFF path); 16 / 32: scores kernel choice;
+ * 64: never spread a pair over several workgroups (128 / 256: not in the backward / forward sweep); 512: wherever possible.  Returns the old mask. */
 int sdp_set_debug(int mask);
 /* Cycle stamps of the forward sweep (tools/fwd_trace.py): a device buffer of >= 40 KiB, or NULL to switch it off. */
 int sdp_set_trace(void *buf);

@@ -50,10 +50,14 @@ def test_state_bytes(lib):
     # Q: 6 B (two 23-bit weights) per cell of the skewed layout; Qd: float2 per cell
     # Q: 6 B (two 23-bit weights) per cell of the skewed, padded layout (+ a tail for the launch order of
     # variable-length batches: B ints, 256-byte granules)
-    assert lib.sdp_state_bytes(256, 512, 512) == 256 * 8 * 576 * 64 * 6 + 1024
+    # ... and, for pairs of more than four strips, the bridge rows between the parts a pair may be cut into: per pair
+    # (ceil(strips / 4) - 1) rows of roundup(M + 63, 64) + 64 granules of 8 bytes
+    bridge = 256 * 1 * (576 + 64 + 40) * 8 + 256 * 2 * 4   # (+ the dispatch order of the parts: one int per workgroup)
+    assert lib.sdp_state_bytes(256, 512, 512) == 256 * 8 * 576 * 64 * 6 + 1024 + bridge
     assert lib.sdp_state_bytes(1, 1, 1) == 1 * 1 * 64 * 64 * 6 + 256
     assert lib.sdp_state_bytes(3, 65, 2) == 3 * 2 * 128 * 64 * 6 + 256
-    assert lib.sdp_state_d_bytes(256, 512, 512) == 256 * 8 * 576 * 64 * 8 + 1024
+    assert lib.sdp_state_bytes(2, 1024, 100) == 2 * 16 * 192 * 64 * 6 + 256 + 2 * 3 * (192 + 64 + 16) * 8 + 256
+    assert lib.sdp_state_d_bytes(256, 512, 512) == 256 * 8 * 576 * 64 * 8 + 1024 + bridge
     assert lib.sdp_state_d_bytes(0, 5, 5) == 0
     assert lib.sdp_state_bytes(0, 5, 5) == 0
 
@@ -92,10 +96,20 @@ def test_launch_plan_policy(lib):
     # small batch -> latency builds, 8 waves, short chunks
     assert _plan(lib, 0, 16, 512, 512)[:3] == (6, 16, 8)
     assert _plan(lib, 1, 16, 512, 512)[:3] == (4, 16, 8)
+    # a pair spread over several CUs, four strips (one per wave of the throughput builds) per workgroup: where it was
+    # measured to pay -- per-pair lengths and more than eight strips, batch within the CU count; equal pairs: the backward
+    # sweep of a few pairs of more than twelve strips; never the adjoint pair
+    pp = lambda pass_, B, N, M, lens, exact=0: lib.sdp_plan_parts(pass_, B, N, M, lens, exact, 256)
+    assert pp(0, 256, 1022, 1020, 1) == 4 and pp(1, 256, 1022, 1020, 1) == 4 and pp(0, 256, 640, 640, 1) == 4
+    assert pp(0, 256, 512, 512, 1) == 0 and pp(0, 700, 1022, 1020, 1) == 0
+    assert pp(0, 16, 1024, 1024, 0) == 0 and pp(1, 16, 1024, 1024, 0) == 4 and pp(1, 64, 640, 500, 0) == 0 and pp(1, 128, 1024, 512, 0) == 0
+    assert pp(2, 16, 1024, 1024, 1, 1) == 0 and pp(3, 16, 1024, 1024, 1, 1) == 0
+    assert _plan(lib, 1, 16, 1024, 1024)[:3] == (1, 32, 4)
     # more pairs than CUs: two waves when that needs fewer rounds
     assert _plan(lib, 0, 512, 512, 512)[2] == 2 and _plan(lib, 0, 768, 512, 512)[2] == 4
-    # per-pair lengths on a batch that does not queue up: treated like a small batch
-    assert _plan(lib, 0, 256, 1024, 1024, lens=1)[:3] == (6, 16, 8)
+    # per-pair lengths on a batch that does not queue up: long pairs in parts (above), otherwise treated like a small batch
+    assert _plan(lib, 0, 256, 1024, 1024, lens=1)[:3] == (0, 32, 4)
+    assert _plan(lib, 0, 256, 512, 1024, lens=1)[:3] == (6, 16, 8)
     # exact state for the adjoint sweeps: its own build
     assert _plan(lib, 0, 256, 512, 512, exact=1)[0] == 9 and _plan(lib, 0, 16, 512, 512, exact=1)[0] == 5
     assert _plan(lib, 1, 256, 512, 512, exact=1)[:3] == (7, 32, 4) and _plan(lib, 1, 16, 512, 512, exact=1)[:3] == (8, 16, 8)

@@ -612,3 +612,69 @@ def test_fuzz2_hundred_seeded_cases(part):
             r64 = parity.oracle_all(f8(c["theta"]), f8(c["A"]), f8(c["Et"]), f8(c["Z"]), c["variant"], ZA=f8(c["ZA"]))
             e64, noise = parity.compare(got, r64), parity.compare(ref, r64)
             assert max(e64["Ed"], e64["Vtd"]) <= 0.2 * parity.TOL and max(noise["Ed"], noise["Vtd"]) >= 0.9 * second, (it, c["tag"], e, e64, noise)
+
+
+@pytest.mark.parametrize("case", [(5, 1024, 1024, 0, False), (3, 1000, 700, 1, False), (2, 1990, 1200, 0, False), (40, 700, 333, 1, True),
+                                  (256, 640, 200, 0, True), (7, 321, 1500, 0, False), (300, 900, 130, 0, True)],
+                         ids=lambda c: "x".join(str(int(v)) for v in c))
+def test_pairs_spread_over_several_workgroups(case):
+    """Long pairs cut into parts of four strips, each part a workgroup on its own CU, the boundary between two parts
+    crossing CUs through 8-byte granules in global memory (sdp_kernels.hip: PARTS, bridge).  The library does that where
+    it pays (sdp_api.hip::plan); here the experiments build forces it in both sweeps for every case, and the results must
+    be bit-identical to the one-workgroup-per-pair schedule -- forward and backward, packed and exact state, per-pair
+    lengths with the dispatch map -- and in parity with the oracle through the shipped library."""
+    import ctypes
+    import torch
+    from deepblast_amd import _lib, build
+    from deepblast_amd._engine import get_engine
+    B, N, M, variant, use_lens = case
+    eng = get_engine()
+    theta, A = datagen.theta_A(91000 + N, B, N, M)
+    theta = (theta * (3.0 if B < 10 else 1.0)).astype(np.float32)
+    lens = None
+    if use_lens:
+        lens = datagen.lengths(91001, B, 1, N)
+        lens[:, 1] = np.minimum(lens[:, 1] * M // N + 1, M)
+        lens[0] = (N, M)
+        lens[1] = (N, 1)
+        lens[2] = (257, M)
+    ref = parity.oracle_lens(theta, A, None, None, variant, lens, threads=16) if use_lens else parity.oracle_all(theta, A, None, None, variant, omp=True)
+    t, a = torch.from_numpy(theta).cuda(), torch.from_numpy(A).cuda()
+    et = torch.from_numpy((0.5 + datagen.uniform(91002, (B,))).astype(np.float32)).cuda()
+    ln = None if lens is None else torch.from_numpy(lens).cuda()
+    ones = torch.ones(B, device="cuda")
+    out = {}
+    for exact in (False, True):
+        Vt, Q = eng.forward(t, a, variant, ln, exact_state=exact)
+        E = eng.backward(ones, Q, (B, N, M), variant, ln, exact_state=exact)
+        E2 = eng.backward(et, Q, (B, N, M), variant, ln, exact_state=exact)
+        torch.cuda.synchronize()
+        assert eng.check_device()[0] == 0
+        errs = parity.compare({"Vt": Vt.cpu().numpy(), "E": E.cpu().numpy()}, ref)
+        _assert(errs, f"parts {case} exact={exact}")
+        out[exact] = (Vt, E, E2)
+    # the experiments build: parts forced on against parts switched off, both with the 4-wave throughput kernels (what the
+    # parts run on; the 8-wave latency builds a small batch would otherwise take cut the columns into shorter chunks and
+    # may round a block differently): same bits
+    exp = _lib.load_path(build.EXP_OUT)
+    stream = torch.cuda.current_stream().cuda_stream
+    for exact in (False, True):
+        flag = 0x100 if exact else 0
+        nbytes = (exp.sdp_state_d_bytes if exact else exp.sdp_state_bytes)(B, N, M)
+        res = []
+        for mask, waves in ((64, 4), (512, 0)):
+            exp.sdp_set_debug(mask)
+            st = torch.empty(nbytes // 4, device="cuda")
+            vt = torch.empty(B, device="cuda")
+            E = torch.empty(B, N, M, device="cuda")
+            lp = None if ln is None else ln.data_ptr()
+            assert exp.sdp_forward_f32(t.data_ptr(), a.data_ptr(), st.data_ptr(), vt.data_ptr(), B, N, M, lp, variant | flag | (waves << 12), 0, stream) == 0
+            assert exp.sdp_backward_f32(et.data_ptr(), st.data_ptr(), E.data_ptr(), B, N, M, lp, variant | flag | (waves << 12), 0, stream) == 0
+            exp.sdp_set_debug(0)
+            torch.cuda.synchronize()
+            info = (ctypes.c_int32 * 4)()
+            assert exp.sdp_device_status(torch.cuda.current_device(), info) == 0 and info[0] == 0, (case, exact, mask, list(info))
+            res.append((vt, E))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), (case, exact)
+        if all(eng.lib.sdp_plan_parts(p_, B, N, M, int(use_lens), int(exact), 256) == 4 for p_ in (0, 1)):   # what the library does by itself
+            assert torch.equal(res[1][0], out[exact][0]) and torch.equal(res[1][1], out[exact][2]), (case, exact)

@@ -10,27 +10,31 @@ lib = gpu_tune.load(os.path.join(ROOT, "deepblast_amd", "libsdp_hip_exp.so"))
 lib.sdp_set_trace.restype, lib.sdp_set_trace.argtypes = ctypes.c_int, [ctypes.c_void_p]
 B, N, M = 256, 512, 512
 alias = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-trace = torch.zeros(4 * 4 * 2 * 40 * 8, dtype=torch.int64, device="cuda")
+if len(sys.argv) > 4:
+    B, N, M = (int(v) for v in sys.argv[2:5])
+trace = torch.zeros(4 * 4 * 4 * 40 * 8, dtype=torch.int64, device="cuda")
 gpu_tune.set_debug(lib, alias)
 r0 = gpu_tune.run(lib, B, N, M, (0, 0, 0, 0), "fb")
 lib.sdp_set_trace(trace.data_ptr())
 r = gpu_tune.run(lib, B, N, M, (0, 0, 0, 0), "fb")
 lib.sdp_set_trace(None); gpu_tune.set_debug(lib, 0)
 print(f"alias={alias}: fwd {r0['fwd']:.1f} us untraced, {r['fwd']:.1f} us traced")
-t = trace.cpu().numpy().reshape(4, 4, 2, 40, 8)
-for pair in (0, 2):
+t = trace.cpu().numpy().reshape(4, 4, 4, 40, 8)
+for pair in ((0,) if B < 129 else (0, 2)):
     t0 = t[pair][t[pair] > 0].min()
     print(f"pair {64 * pair}: per wave and strip round: first block start, last block end (cycles since the pair's first stamp); mean cycles per block: wait | compute | publish | gap to next block")
     for w in range(4):
-        for rd in range(2):
+        for rd in range(4):
             x = t[pair, w, rd]
             nb = int((x[:, 0] > 0).sum())
+            if nb < 10:
+                continue
             x = x[:nb]
             wait, comp, pub = x[:, 1] - x[:, 0], x[:, 2] - x[:, 1], x[:, 3] - x[:, 2]
             gap = x[1:, 0] - x[:-1, 3]
             mid = slice(6, nb - 2)   # interior blocks
             odd = x[7:nb - 2:2]
-            if (odd[:, 4] > 0).all():
+            if False:
                 print(f"     odd blocks: start->check {(odd[:, 4] - odd[:, 0]).mean():.0f}  write_block {(odd[:, 5] - odd[:, 4]).mean():.0f}  load_block {(odd[:, 6] - odd[:, 5]).mean():.0f}  prefetch issue {(odd[:, 7] - odd[:, 6]).mean():.0f}  ->compute {(odd[:, 1] - odd[:, 7]).mean():.0f};  even blocks wait {(x[6:nb - 2:2, 1] - x[6:nb - 2:2, 0]).mean():.0f}")
-            print(f"  wave {w} strip {w + 4 * rd}: {x[0, 0] - t0:8d} .. {x[-1, 3] - t0:8d}  blocks {nb}  "
+            print(f"  wave {w} round/part {rd}: {x[0, 0] - t0:8d} .. {x[-1, 3] - t0:8d}  blocks {nb}  "
                   f"wait {wait[mid].mean():6.0f} compute {comp[mid].mean():6.0f} publish {pub[mid].mean():5.0f} gap(even->odd block, odd->next chunk) {gap[6:-2:2].mean():6.0f} {gap[7:-2:2].mean():6.0f}")

@@ -1,4 +1,3 @@
 #!/bin/bash
-OUT=gpurun_out/r03a; mkdir -p $OUT; export TMPDIR=/tmp
-timeout 600 python tools/ab.py 256x512x512 2>&1 | grep -v amdgpu
-timeout 600 python tools/ab.py 256x512x512 2>&1 | grep -v amdgpu
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests/test_parity_gpu.py tests/test_robustness_gpu.py -m gpu -x -q 2>&1 | tail -6
