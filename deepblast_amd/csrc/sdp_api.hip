@@ -94,6 +94,15 @@ Variant variant(int id)
     case 18: return {(const void *)sdp_bwd_x_g_kernel, SDP_K_BWD, SDP_MAXW_BWD, 18};
     case 19: return {(const void *)sdp_bwd_x_lat_g_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 19};
     case 20: return {(const void *)sdp_fwd_x_tp_g_kernel, SDP_K_FWD, SDP_MAXW_FWD, 20};
+    // PARTS instantiations of the throughput builds (a pair over several workgroups): 21 + (fwd, fwd exact, bwd, bwd exact), + 4 general pitch
+    case 21: return {(const void *)sdp_fwd_p_kernel, SDP_K_FWD, SDP_MAXW_FWD, 21};
+    case 22: return {(const void *)sdp_fwd_x_tp_p_kernel, SDP_K_FWD, SDP_MAXW_FWD, 22};
+    case 23: return {(const void *)sdp_bwd_p_kernel, SDP_K_BWD, SDP_MAXW_BWD, 23};
+    case 24: return {(const void *)sdp_bwd_x_p_kernel, SDP_K_BWD, SDP_MAXW_BWD, 24};
+    case 25: return {(const void *)sdp_fwd_pg_kernel, SDP_K_FWD, SDP_MAXW_FWD, 25};
+    case 26: return {(const void *)sdp_fwd_x_tp_pg_kernel, SDP_K_FWD, SDP_MAXW_FWD, 26};
+    case 27: return {(const void *)sdp_bwd_pg_kernel, SDP_K_BWD, SDP_MAXW_BWD, 27};
+    case 28: return {(const void *)sdp_bwd_x_pg_kernel, SDP_K_BWD, SDP_MAXW_BWD, 28};
     default: return {(const void *)sdp_bwd_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 4};
     }
 }
@@ -192,19 +201,20 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
     // per wave of the 4-wave throughput builds, instead of one CU taking all the pair's strips in rounds.  It pays only
     // where CUs would otherwise idle AND the pair is long enough for the extra lag per bridge (measured, round 3, us
     // forward / backward, one workgroup per pair -> parts):
-    //   per-pair lengths, 256 pairs: n, m <= 1022 x 1020 (BASELINE configs[2]) 648 / 622 -> 592 / 538; <= 832^2 455 / 381 ->
-    //   422 / 363; <= 640^2 295 / 243 -> 274 / 218; <= 512^2 (two parts) 201 / 154 -> 204 / 180 (worse); 64 pairs <= 1022 x 1020
-    //   532 / 385 -> 462 / 309; 700 pairs (more than CUs) 1017 / 1187 -> 1266 / 1209 (worse);
+    //   per-pair lengths, 256 pairs: n, m <= 1022 x 1020 (BASELINE configs[2]) 640 / 610 -> 515 / 465; <= 640^2 301 / 245 ->
+    //   287 / 240; <= 512^2 (two parts) 199 / 169 -> 210 / 148; 128 pairs <= 512^2 170 / 157 -> 194 / 146; 64 pairs <= 1022 x 1020
+    //   532 / 385 -> 462 / 309; more pairs than CUs, <= 1022 x 1020: 384 pairs 752 / 761 -> 778 / 743, 512 pairs 832 / 1023 ->
+    //   1000 / 950, 700 pairs 998 / 1188 -> 1250 / 1300;
     //   equal pairs: 16 x 1024^2 445 / 330 -> 451 / 291; 64 x 640 x 500 240 / 163 -> 260 / 183 (worse); 16 x 512^2 worse.
-    // So: three parts or more; with per-pair lengths whenever the batch does not outnumber the CUs; equal pairs only the
-    // backward sweep of pairs of four parts.  The adjoint pair (float64 carries) keeps one workgroup per pair.
+    // So: with per-pair lengths whenever the batch does not outnumber the CUs -- the forward sweep from three parts on, the
+    // backward sweep from two; equal pairs only the backward sweep of pairs of four parts.  The adjoint pair (float64
+    // carries) keeps one workgroup per pair.
     int parts = 0;
     const bool parts_fit = sweep12 && forced_waves <= 0 && nstrips > PART_STRIPS;
-    const bool parts_pay = nstrips > 2 * PART_STRIPS && B <= cus &&
-                           (has_lens || (pass == sdp::PASS_BWD && nstrips > 3 * PART_STRIPS && (long long)B * parts_per_pair(N) <= cus));
+    const bool parts_pay = B <= cus && (has_lens ? (pass == sdp::PASS_BWD || nstrips > 2 * PART_STRIPS)
+                                                 : (pass == sdp::PASS_BWD && nstrips > 3 * PART_STRIPS && (long long)B * parts_per_pair(N) <= cus));
     if (parts_fit && (allow_parts == 2 || (allow_parts == 1 && parts_pay))) {
-        Variant tv = variant(pass == sdp::PASS_FWD ? (exact_state ? 9 : 0) : (exact_state ? 7 : 1));
-        if (general_pitch) tv = variant(general_id(tv.id));
+        const Variant tv = variant(21 + (pass == sdp::PASS_FWD ? 0 : 2) + (exact_state ? 1 : 0) + (general_pitch ? 4 : 0));
         if (lds_bytes(pass, tv.K, PART_STRIPS, mcap, nullptr) <= 160 * 1024) {
             v = tv;
             W = PART_STRIPS;
@@ -324,7 +334,7 @@ VariantBits split_variant(int variant)
 // 160 KiB the hardware has, so concurrent callers cannot disagree
 int raise_lds_limit(const Variant &v, int device)
 {
-    static thread_local unsigned long long lds_raised[21] = {0};  // per kernel id: bit d = done on device d
+    static thread_local unsigned long long lds_raised[29] = {0};  // per kernel id: bit d = done on device d
     if (device >= 64 || !(lds_raised[v.id] >> device & 1ull)) {
         hipError_t e = hipFuncSetAttribute(v.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");

@@ -155,6 +155,14 @@ __global__ void sdp_adj_fwd_loss_kernel(const sdp::Params p);
 __global__ void sdp_adj_bwd_kernel(const sdp::Params p);
 __global__ void sdp_fwd_g_kernel(const sdp::Params p);
 __global__ void sdp_fwd_x_tp_g_kernel(const sdp::Params p);
+__global__ void sdp_fwd_p_kernel(const sdp::Params p);
+__global__ void sdp_fwd_x_tp_p_kernel(const sdp::Params p);
+__global__ void sdp_bwd_p_kernel(const sdp::Params p);
+__global__ void sdp_bwd_x_p_kernel(const sdp::Params p);
+__global__ void sdp_fwd_pg_kernel(const sdp::Params p);
+__global__ void sdp_fwd_x_tp_pg_kernel(const sdp::Params p);
+__global__ void sdp_bwd_pg_kernel(const sdp::Params p);
+__global__ void sdp_bwd_x_pg_kernel(const sdp::Params p);
 __global__ void sdp_bwd_g_kernel(const sdp::Params p);
 __global__ void sdp_bwd_lat_g_kernel(const sdp::Params p);
 __global__ void sdp_bwd_x_g_kernel(const sdp::Params p);

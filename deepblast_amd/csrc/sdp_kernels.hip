@@ -99,6 +99,9 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #else
 #define SDP_EXP_BUILD 0  // default library: Params::dbg is ignored, no wrong-results switch is reachable
 #endif
+#ifndef SDP_ZF_AUX
+#define SDP_ZF_AUX 0   // cache policy of the zero-fill stores
+#endif
 #ifndef SDP_TB_WINDOW
 #define SDP_TB_WINDOW 32  // traceback: edge of the LDS window of E (32 or 64 cells)
 #endif
@@ -391,7 +394,7 @@ __device__ __forceinline__ float loss_dterm(float r, float y, float sc, int kind
 // start on K-float boundaries (M a multiple of 32, 128-byte aligned tensors): the same formulas with the offsets
 // folded to constants -- the host picks per launch (sdp_api.hip), and the headline shape pays nothing for generality
 // (with one instantiation for both, the forward kernel measured +5 % and the backward +3 % at M = 512).
-template <int PASS, int K, bool QX = false, bool LINES = false, bool GEN = false>
+template <int PASS, int K, bool QX = false, bool LINES = false, bool GEN = false, bool PARTS = false>
 __device__ __forceinline__ void sweep(const Params &p)
 {
     using T = Traits<PASS, QX>;
@@ -417,26 +420,32 @@ __device__ __forceinline__ void sweep(const Params &p)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = blockDim.x >> 6;
+    const int parts = PARTS ? p.parts : 0;   // (only the PARTS instantiations carry the bridge code: in the others it costs the forward sweep a fifth of its speed)
     // batches with per-pair lengths and more pairs than CUs are launched longest-first (p.order: pair handled by
     // each workgroup, written by sdp_order_kernel): the hardware hands workgroups to CUs in index order as they
     // free up, which then is the longest-processing-time-first rule
     //
-    // PARTS (p.parts > 0; forward and fp32 backward sweeps): a pair's strips are cut into parts of p.parts strips and every
+    // PARTS (parts > 0; forward and fp32 backward sweeps): a pair's strips are cut into parts of parts strips and every
     // part is a workgroup of its own -- on its own CU -- so that a long pair is swept by several CUs at once, each with
     // one strip per wave, instead of one CU taking the strips in rounds.  The boundary between the last strip of a part
     // and the first strip of the next crosses CUs through global memory (see "bridge" below).  Which (pair, part) a
     // workgroup takes follows from a priority order in which a consumer always has a higher index than its producer:
     // workgroups are dispatched in index order, so a waiting part never keeps its producer off the chip.
     int wg_pair = (int)blockIdx.x, wg_part = 0;
-    if (p.parts) {
-        if (p.wg_map) {   // per-pair lengths: sdp_parts_map_kernel ranked the parts by the critical path that hangs on them
+    if (parts) {
+        if (p.wg_map) {   // per-pair lengths: the order sdp_parts_map_kernel worked out
             const int e = p.wg_map[blockIdx.x];
             wg_pair = e / p.nparts_max, wg_part = e % p.nparts_max;
         } else {          // equal pairs: every pair's part 0, then every pair's part 1, ...
             wg_pair = (int)blockIdx.x % p.B, wg_part = (int)blockIdx.x / p.B;
         }
     }
-    const int b = (p.order && !p.parts) ? p.order[wg_pair] : wg_pair;
+    // (b and the part are the same for the whole workgroup, but come out of memory: say so -- without it the forward
+    //  parts kernels of the shipped build took every buffer descriptor derived from them for divergent, wrapped 150-260
+    //  loads and stores in readfirstlane loops and waited for each bridge load on the spot: 672 instead of 585 us at
+    //  BASELINE configs[2])
+    wg_pair = __builtin_amdgcn_readfirstlane(wg_pair), wg_part = __builtin_amdgcn_readfirstlane(wg_part);
+    const int b = __builtin_amdgcn_readfirstlane((p.order && !parts) ? p.order[wg_pair] : wg_pair);
 
     int n = p.N, m = p.M;
     if (p.lens) {
@@ -452,12 +461,12 @@ __device__ __forceinline__ void sweep(const Params &p)
     const bool sw = p.variant == SDP_SW;
     // strips of this workgroup: [s_lo, s_hi).  Reverse sweeps count their parts from the END of the pair (part 0 = the last
     // strips, swept first), so that also there a producer has the lower workgroup index.
-    const int nparts = p.parts ? (nstrips + p.parts - 1) / p.parts : 1;
+    const int nparts = parts ? (nstrips + parts - 1) / parts : 1;
     const int part = wg_part;
-    if (part >= nparts) return;   // this pair has fewer parts than the longest pair of the batch
-    const int part_pos = (REV && p.parts) ? nparts - 1 - part : part;   // position of the part in strip order
-    const int s_lo = p.parts ? part_pos * p.parts : 0;
-    const int s_hi = p.parts ? (s_lo + p.parts < nstrips ? s_lo + p.parts : nstrips) : nstrips;
+    const bool absent = part >= nparts;   // this pair has fewer parts than the longest pair of the batch: see zero_fill
+    const int part_pos = (REV && parts) ? nparts - 1 - part : part;   // position of the part in strip order
+    const int s_lo = parts ? part_pos * parts : 0;
+    const int s_hi = parts ? (s_lo + parts < nstrips ? s_lo + parts : nstrips) : nstrips;
     const int nstrips_wg = s_hi - s_lo;
 
     // ---- LDS carve: boundary rows (8-byte slots), progress words, per-wave staging ----
@@ -486,36 +495,48 @@ __device__ __forceinline__ void sweep(const Params &p)
     // sweep only writes the block; the rest is zero-filled here by the pair's own workgroup (no separate memset
     // pass over the whole tensor): by the waves that have no strip (short pairs -- they start at once and finish
     // long before the batch's longest pair), otherwise by every wave after its last strip.
+    // With PARTS a pair has as many workgroup slots as the longest pair of the batch has parts; the slots past its own
+    // parts ("absent" parts: the shorter the pair, the more of them and the more there is to fill) share the fill, all
+    // their waves, and the parts that sweep do none.  Those slots sort last in the dispatch order: the fill runs on the
+    // CUs the short pairs have left, under the chains of the long ones (configs[2], backward sweep: 506 -> 3xx us; with
+    // the fill done by each pair's first part after its sweep the CUs it kept busy were missing for the queued parts).
     auto zero_fill = [&]() {
         if constexpr (T::SOUT > 0) {
-            if (p.lens == nullptr || (n == p.N && m == p.M) || part != 0) return;   // (with parts: the first workgroup of the pair)
+            if (p.lens == nullptr || (n == p.N && m == p.M)) return;
+#ifdef SDP_NO_ZERO_FILL
+            return;   // timing experiment only: E keeps whatever was in the buffer outside the pair's block
+#endif
+            const int nabsent = parts ? p.nparts_max - nparts : 0;
+            if (nabsent > 0 ? !absent : part != 0) return;
             const int idle = W > nstrips_wg ? W - nstrips_wg : 0;
-            const int parts = idle > 0 ? idle : W, part = idle > 0 ? wave - nstrips_wg : wave;
+            const int parts = absent ? nabsent * W : (idle > 0 ? idle : W);                                 // waves that share the fill,
+            const int part = absent ? (wg_part - nparts) * W + wave : (idle > 0 ? wave - nstrips_wg : wave);   // this one's index among them
             if (part < 0) return;
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            constexpr int ZF_AUX = SDP_ZF_AUX;
             const u32x4 z4 = {0u, 0u, 0u, 0u};
             __amdgpu_buffer_rsrc_t rz = make_rsrc(p.sout + ((SDP_EXP_BUILD && (p.dbg & 2)) ? 0 : (size_t)b) * plane_elems, plane_bytes);
             // rows [n, N): one contiguous run; stores past the end of the plane are dropped dword by dword
             const unsigned tail1 = (unsigned)(p.N * p.M);
             for (unsigned e = (unsigned)(n * p.M) + (unsigned)(part * 64 + lane) * 4u; e < tail1; e += (unsigned)parts * 256u)
-                __builtin_amdgcn_raw_buffer_store_b128(z4, rz, e * 4u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(z4, rz, e * 4u, 0, ZF_AUX);
             // rows [0, n): columns [m, M)
             if (m < p.M) {
                 for (int r = part; r < n; r += parts) {
                     const unsigned row = (unsigned)(r * p.M);
                     for (int c = m + 4 * lane; c < p.M; c += 256) {
                         if (c + 4 <= p.M) {
-                            __builtin_amdgcn_raw_buffer_store_b128(z4, rz, (row + c) * 4u, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(z4, rz, (row + c) * 4u, 0, ZF_AUX);
                         } else {
                             for (int q = 0; q < 4; ++q)
-                                if (c + q < p.M) __builtin_amdgcn_raw_buffer_store_b32(0u, rz, (row + c + q) * 4u, 0, 0);
+                                if (c + q < p.M) __builtin_amdgcn_raw_buffer_store_b32(0u, rz, (row + c + q) * 4u, 0, ZF_AUX);
                         }
                     }
                 }
             }
         }
     };
-    if (wave >= nstrips_wg) {
+    if (absent || wave >= nstrips_wg) {
         zero_fill();
         return;
     }
@@ -549,8 +570,8 @@ __device__ __forceinline__ void sweep(const Params &p)
         const bool has_succ = REV ? (s > 0) : (s + 1 < nstrips);   // strip that consumes ours
         const int pidx = sidx - 1;                                  // producer's position in processing order
         // bridged: the strip whose boundary we consume / that consumes ours belongs to another workgroup (parts)
-        const bool imported = has_pred && sidx == 0 && p.parts != 0;
-        const bool exported = has_succ && sidx == nstrips_wg - 1 && p.parts != 0;
+        const bool imported = has_pred && sidx == 0 && parts != 0;
+        const bool exported = has_succ && sidx == nstrips_wg - 1 && parts != 0;
         // the boundary row an imported boundary is replayed into is the one strip sidx + 1 publishes to: that strip
         // trails this one by a whole lag and never reaches a column this strip still has to read; its progress word
         // is word W (no wave's own)
@@ -894,7 +915,7 @@ __device__ __forceinline__ void sweep(const Params &p)
         const int *be_in = reinterpret_cast<const int *>(bnd_in) + p.mcap;
         float *bv_out = reinterpret_cast<float *>(bnd_out);
         int *be_out = reinterpret_cast<int *>(bnd_out) + p.mcap;
-        // ---- bridge between parts (p.parts): a boundary that crosses workgroups travels through global memory as 8-byte
+        // ---- bridge between parts (parts): a boundary that crosses workgroups travels through global memory as 8-byte
         // GRANULES {value, tag}: one naturally aligned 8-byte store per column (write-through, sc0 sc1), so a granule is
         // either wholly the memset pattern or wholly written, and neither side needs a flag or a fence (the tag -- the
         // exponent in the forward sweep, 0 in the fp32 backward sweep -- can never equal the pattern).  The PRODUCER
@@ -1014,8 +1035,8 @@ __device__ __forceinline__ void sweep(const Params &p)
                     // experiments build, sdp_set_trace: shader-cycle stamps of this block -- [pair / 64][wave][strip round][block][4]
                     auto stamp = [&](int k) {
                         if constexpr (SDP_EXP_BUILD != 0) {
-                            if (p.trace && (b & 63) == 0 && b < 256 && lane == 0 && (p.parts ? part < 4 : sidx / W < 2) && tb / WB < 40)
-                                p.trace[((((b >> 6) * 4 + wave) * 4 + (p.parts ? part : sidx / W)) * 40 + tb / WB) * 8 + k] = __builtin_readcyclecounter();   // (k < 4 used)
+                            if (p.trace && (b & 63) == 0 && b < 256 && lane == 0 && (parts ? part < 4 : sidx / W < 2) && tb / WB < 40)
+                                p.trace[((((b >> 6) * 4 + wave) * 4 + (parts ? part : sidx / W)) * 40 + tb / WB) * 8 + k] = __builtin_readcyclecounter();   // (k < 4 used)
                         }
                     };
                     stamp(0);
@@ -2035,6 +2056,15 @@ SDP_KERNEL(sdp_bwd_x_lat_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT,
 SDP_KERNEL(sdp_adj_fwd_kernel, sdp::PASS_AFWD, SDP_K_AFWD, SDP_MAXW_AFWD)
 SDP_KERNEL(sdp_adj_fwd_loss_kernel, sdp::PASS_AFWD, SDP_K_AFWD, 4, true)
 SDP_KERNEL(sdp_adj_bwd_kernel, sdp::PASS_ABWD, SDP_K_ABWD, SDP_MAXW_ABWD)
+// PARTS instantiations: the throughput builds with the bridge between workgroups (a pair spread over several CUs)
+SDP_KERNEL(sdp_fwd_p_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LINES != 0, false, true)
+SDP_KERNEL(sdp_fwd_x_tp_p_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, SDP_LINES != 0, false, true)
+SDP_KERNEL(sdp_bwd_p_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, false, false, false, true)
+SDP_KERNEL(sdp_bwd_x_p_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, true, false, false, true)
+SDP_KERNEL(sdp_fwd_pg_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LINES != 0, true, true)
+SDP_KERNEL(sdp_fwd_x_tp_pg_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, SDP_LINES != 0, true, true)
+SDP_KERNEL(sdp_bwd_pg_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, false, false, true, true)
+SDP_KERNEL(sdp_bwd_x_pg_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, true, false, true, true)
 // general-pitch instantiations (GEN = true) of the kernels that stage outputs, and of the line-aligned forward builds
 SDP_KERNEL(sdp_fwd_g_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LINES != 0, true)
 SDP_KERNEL(sdp_fwd_x_tp_g_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, SDP_LINES != 0, true)
@@ -2069,12 +2099,16 @@ extern "C" __global__ void __launch_bounds__(256) sdp_order_kernel(const int *le
 
 // ----------------------------------------------------------------------------------
 // dispatch order when pairs are spread over several workgroups ("parts") and have their own lengths: map[h] = pair *
-// nparts_max + part for workgroup h.  Priority = the length of the critical path that still hangs on a part, in steps: a
-// part is ready one four-strip lag after the part before it, and a pair is done one part's run after its last part
-// started -- so part k of a pair with P parts and m columns has (P - 1 - k) * 4 * 79 + 3 * 79 + m + 63 steps ahead of
-// it.  Sorting by that, largest first, starts every pair's parts in order (a producer always precedes its consumer),
-// puts the long pairs' first parts ahead of everything and the parts that could only wait behind work that can run.
-// Parts a pair does not have sort last (their workgroups exit at once).  Rank by counting, as above.
+// nparts_max + part for workgroup h.  Workgroups are handed to CUs in index order as CUs free up, and a part that is on
+// a CU before its producer has reached it only waits there.  So: every pair's part 0 first, then the parts 1, ... -- part
+// k has nothing to do for the first k * 4 * 79 steps (~60 us each) of its pair, about the time the shortest pairs of the
+// batch take to leave their CUs -- and within one k by the critical path that still hangs on the part, longest first
+// ((P - 1 - k) * 4 * 79 + 3 * 79 + m + 63 steps for a pair of P parts and m columns).  A producer always precedes its
+// consumer, so a waiting part never keeps its producer off the chip.  (Ranking by the critical path alone put all parts
+// of the long pairs on CUs at once, most of them waiting: forward sweep of BASELINE configs[2] 600 us instead of 511.)
+// Slots k of pairs with k parts or fewer come at the end of the parts k: in the forward sweep they exit at once, in the
+// backward sweep they zero-fill E outside the pair's block (sorted behind everything else the fill ran at the very end,
+// on the few CUs that were free: 483 instead of 3xx us).  Rank by counting, as above.
 // ----------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(256) sdp_parts_map_kernel(const int *lens, int *map, int B, int N, int M, int nparts_max, int strips)
 {
@@ -2089,7 +2123,7 @@ extern "C" __global__ void __launch_bounds__(256) sdp_parts_map_kernel(const int
         n = n < 1 ? 1 : (n > N ? N : n);
         m = m < 1 ? 1 : (m > M ? M : m);
         const int np = ((n + 63) / 64 + strips - 1) / strips;
-        return k < np ? (np - 1 - k) * strips * 79 + (strips - 1) * 79 + m + 63 : -1;
+        return (nparts_max - k) * 65536 + (k < np ? (np - 1 - k) * strips * 79 + (strips - 1) * 79 + m + 63 : 0);
     };
     const int mine = key(h);
     int cnt = 0;

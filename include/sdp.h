@@ -207,14 +207,16 @@ int sdp_device_status(int device, int32_t info[4]);
  * state (latency), 6 fwd latency, 7 / 8 bwd reading the exact state (throughput / latency), 9 fwd exact state
  * (throughput)), chunk length, waves per pair,
  * dynamic LDS bytes.  Pure function, needs no device.  (Reported for tensors whose rows and planes start on 128-byte
- * lines -- M a multiple of 32; other launches use the "general pitch" instantiations of the same builds, ids 11-20.) */
+ * lines -- M a multiple of 32; other launches use the "general pitch" instantiations of the same builds, ids 11-20.
+ * Ids 21-28: the throughput builds with the bridge between workgroups, see sdp_plan_parts.) */
 int sdp_plan(int pass, int B, int N, int M, int has_lens, int exact_state, int cus, int *kernel_id, int *chunk,
              int *waves, size_t *lds);
 
 /* ... and whether that launch would spread every pair over several workgroups (CUs): the number of 64-row strips per
  * workgroup, or 0 for one workgroup per pair.  Forward and backward sweeps do it where it was measured to pay: padded
- * batches with per-pair lengths and pairs of more than eight strips (the batch takes as long as its longest pair), and the
- * backward sweep of a few equal pairs of more than twelve strips; the boundary between two parts of a pair then crosses
+ * batches with per-pair lengths that do not outnumber the CUs (the batch takes as long as its longest pair; forward sweep:
+ * pairs of more than eight strips, backward sweep: more than four), and the backward sweep of a few equal pairs of more
+ * than twelve strips; the boundary between two parts of a pair then crosses
  * CUs through 8-byte granules in the tail of the state buffer.  Results do not depend on it (bit-identical). */
 int sdp_plan_parts(int pass, int B, int N, int M, int has_lens, int exact_state, int cus);
 

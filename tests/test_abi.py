@@ -97,18 +97,19 @@ def test_launch_plan_policy(lib):
     assert _plan(lib, 0, 16, 512, 512)[:3] == (6, 16, 8)
     assert _plan(lib, 1, 16, 512, 512)[:3] == (4, 16, 8)
     # a pair spread over several CUs, four strips (one per wave of the throughput builds) per workgroup: where it was
-    # measured to pay -- per-pair lengths and more than eight strips, batch within the CU count; equal pairs: the backward
-    # sweep of a few pairs of more than twelve strips; never the adjoint pair
+    # measured to pay -- per-pair lengths and a batch within the CU count: forward sweep from three parts on, backward sweep
+    # from two; equal pairs: the backward sweep of a few pairs of more than twelve strips; never the adjoint pair
     pp = lambda pass_, B, N, M, lens, exact=0: lib.sdp_plan_parts(pass_, B, N, M, lens, exact, 256)
     assert pp(0, 256, 1022, 1020, 1) == 4 and pp(1, 256, 1022, 1020, 1) == 4 and pp(0, 256, 640, 640, 1) == 4
-    assert pp(0, 256, 512, 512, 1) == 0 and pp(0, 700, 1022, 1020, 1) == 0
+    assert pp(0, 256, 512, 512, 1) == 0 and pp(1, 256, 512, 512, 1) == 4 and pp(1, 256, 256, 512, 1) == 0
+    assert pp(0, 700, 1022, 1020, 1) == 0 and pp(1, 700, 1022, 1020, 1) == 0
     assert pp(0, 16, 1024, 1024, 0) == 0 and pp(1, 16, 1024, 1024, 0) == 4 and pp(1, 64, 640, 500, 0) == 0 and pp(1, 128, 1024, 512, 0) == 0
     assert pp(2, 16, 1024, 1024, 1, 1) == 0 and pp(3, 16, 1024, 1024, 1, 1) == 0
-    assert _plan(lib, 1, 16, 1024, 1024)[:3] == (1, 32, 4)
+    assert _plan(lib, 1, 16, 1024, 1024)[:3] == (23, 32, 4)   # (the parts instantiation of the throughput build)
     # more pairs than CUs: two waves when that needs fewer rounds
     assert _plan(lib, 0, 512, 512, 512)[2] == 2 and _plan(lib, 0, 768, 512, 512)[2] == 4
     # per-pair lengths on a batch that does not queue up: long pairs in parts (above), otherwise treated like a small batch
-    assert _plan(lib, 0, 256, 1024, 1024, lens=1)[:3] == (0, 32, 4)
+    assert _plan(lib, 0, 256, 1024, 1024, lens=1)[:3] == (21, 32, 4)
     assert _plan(lib, 0, 256, 512, 1024, lens=1)[:3] == (6, 16, 8)
     # exact state for the adjoint sweeps: its own build
     assert _plan(lib, 0, 256, 512, 512, exact=1)[0] == 9 and _plan(lib, 0, 16, 512, 512, exact=1)[0] == 5

@@ -7,16 +7,22 @@ import datagen, gpu_tune
 B, N, M = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (5, 1024, 1024)))
 use_lens = "lens" in sys.argv
 exp = gpu_tune.load(os.path.join(ROOT, "deepblast_amd", "libsdp_hip_exp.so"))
-theta, A = datagen.theta_A(91000 + N, B, N, M)
+cfg3 = "cfg3" in sys.argv   # BASELINE configs[2] exactly as tools/gpu_configs.py builds it
+if cfg3:
+    ln3 = datagen.lengths(2, B, 64, 1024)
+    N, M = int(ln3[:, 0].max()), int(ln3[:, 1].max())
+theta, A = datagen.theta_A(2 if cfg3 else 91000 + N, B, N, M)
 t, a = torch.from_numpy(theta).cuda(), torch.from_numpy(A).cuda()
 et = torch.ones(B, device="cuda")
 lens = None
 if use_lens:
     ln = datagen.lengths(2, B, 64, N); ln[:, 1] = np.minimum(ln[:, 1], M)
+    if cfg3:
+        ln = ln3
     lens = torch.from_numpy(ln).cuda()
 stream = torch.cuda.current_stream().cuda_stream
 res = {}
-for mask in (64, 128, 256, 0):
+for mask in (64, 512 | 128, 512 | 256, 512):
     gpu_tune.set_debug(exp, mask)
     st = torch.empty(exp.sdp_state_bytes(B, N, M) // 4, device="cuda")
     vt = torch.empty(B, device="cuda"); E = torch.empty(B, N, M, device="cuda")
@@ -27,9 +33,9 @@ for mask in (64, 128, 256, 0):
     torch.cuda.synchronize()
     tf, tb = gpu_tune.timeit(f), gpu_tune.timeit(g)
     res[mask] = (vt.clone(), E.clone(), st.clone())
-    print(f"parts {({64: 'off', 128: 'fwd only', 256: 'bwd only', 0: 'on'})[mask]}: fwd {tf:.1f} us  bwd {tb:.1f} us")
+    print(f"parts {({64: 'off', 512 | 128: 'fwd only', 512 | 256: 'bwd only', 512: 'on'})[mask]}: fwd {tf:.1f} us  bwd {tb:.1f} us")
 gpu_tune.set_debug(exp, 0)
-for mask in (128, 256, 0):
+for mask in (512 | 128, 512 | 256, 512):
     dv = (res[mask][0] - res[64][0]).abs()
     dE = (res[mask][1] - res[64][1]).abs()
     rows = dE.amax(dim=2)[0].cpu().numpy()
@@ -40,7 +46,7 @@ for mask in (128, 256, 0):
 
 # packed state: per (pair, strip) tpad * 384 bytes; compare parts-forward (mask 128) with no parts (64), pair 0
 nstrips, tpad = (N + 63) // 64, (M + 63 + 63) // 64 * 64
-sa = res[128][2].view(torch.uint8)[: nstrips * tpad * 384].view(nstrips, tpad // 2, 768).cpu().numpy()
+sa = res[512 | 128][2].view(torch.uint8)[: nstrips * tpad * 384].view(nstrips, tpad // 2, 768).cpu().numpy()
 sb = res[64][2].view(torch.uint8)[: nstrips * tpad * 384].view(nstrips, tpad // 2, 768).cpu().numpy()
 for s_ in range(nstrips):
     d = (sa[s_] != sb[s_]).any(axis=1)
