@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import source_stamp  # noqa: E402
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", f"round_{tag}")
 dst = os.path.join(ROOT, "profiles")
 stamp = json.load(open(os.path.join(src, "stamp.json")))
@@ -39,6 +39,11 @@ for name, pattern in (("kernel_stats.csv", "prof/**/*kernel_stats.csv"), ("train
                       ("pmc_train_fetch_size.csv", "pmc_train_FETCH_SIZE/**/*counter_collection.csv"),
                       ("pmc_train_write_size.csv", "pmc_train_WRITE_SIZE/**/*counter_collection.csv"),
                       ("bench.json", "bench.json"), ("bench_train.json", "bench_train.json"),
+                      ("scores_kernel_stats.csv", "prof_scores/**/*kernel_stats.csv"), ("configs_kernel_stats.csv", "prof_cfg/**/*kernel_stats.csv"),
+                      ("bench_scores.json", "bench_scores.json"), ("bench_traceback.json", "bench_traceback.json"),
+                      ("configs.txt", "configs.txt"), ("parts_configs2.txt", "parts_configs2.txt"),
+                      ("ubench_mix.txt", "ubench_mix.txt"), ("ubench_mix2.txt", "ubench_mix2.txt"),
+                      ("pytest_multigpu.txt", "pytest_multigpu.txt"), ("multigpu_skipped.txt", "multigpu_skipped.txt"),
                       ("pytest_gpu.txt", "pytest_gpu.txt"), ("smoke.txt", "smoke.txt"), ("fuzz2.txt", "fuzz2.txt")):
     f = first(pattern)
     if f:

@@ -5,7 +5,7 @@
 # modes, FETCH_SIZE and WRITE_SIZE counter passes (separate runs, kernel-trace only -- gpurun refuses pmc + other
 # traces), and the source hash the numbers belong to.  Afterwards, in the build container:
 #   python tools/collect_profiles.py <tag>    -> profiles/<tag>_*.csv|json + profiles/traffic.json (stamped)
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/round_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -29,6 +29,8 @@ else
 fi
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o fwdbwd -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/rocprof.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o train -- python bench.py --steps 10 --warmup 2 --mode train --no-cpu-baseline > $OUT/bench_prof_train.json 2>> $OUT/rocprof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_scores -o scores -- python bench.py --steps 10 --warmup 2 --mode scores+dp --no-cpu-baseline > $OUT/bench_prof_scores.json 2>> $OUT/rocprof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_cfg -o cfg -- python tools/gpu_configs.py > $OUT/configs_prof.txt 2>> $OUT/rocprof.err
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o fwdbwd -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$C.err
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_train_$C -o train -- python bench.py --steps 3 --warmup 1 --mode train --no-cpu-baseline > /dev/null 2>> $OUT/pmc_$C.err
@@ -38,6 +40,14 @@ done
 python tools/collect_profiles.py $TAG > $OUT/collect.txt 2>&1
 timeout 600 python bench.py --steps 20 --warmup 3 2> $OUT/bench.err | tee $OUT/bench.json
 timeout 600 python bench.py --steps 20 --warmup 3 --mode train --no-cpu-baseline 2>> $OUT/bench.err | tee $OUT/bench_train.json
+timeout 600 python bench.py --steps 20 --warmup 3 --mode scores+dp --no-cpu-baseline 2>> $OUT/bench.err | tee $OUT/bench_scores.json
+timeout 600 python bench.py --steps 20 --warmup 3 --mode align+traceback --no-cpu-baseline 2>> $OUT/bench.err | tee $OUT/bench_traceback.json
+# BASELINE configs[1..3] through the public API (configs[2]: reference semantics and lengths-aware), and the per-pair-lengths
+# batch through the library with and without the pairs spread over several workgroups
+timeout 300 python tools/gpu_configs.py 2> /dev/null | tee $OUT/configs.txt
+timeout 300 python tools/parts_probe.py 256 1022 1020 lens cfg3 2> /dev/null | grep "^parts" | tee $OUT/parts_configs2.txt
+# bare read / write / mixed streams of the forward sweep's size: what this box's memory system gives
+for u in mix mix2; do hipcc --offload-arch=gfx950 -O3 -o /tmp/$u tools/ubench/$u.hip 2> /dev/null && timeout 120 /tmp/$u 2>&1 | tee $OUT/ubench_$u.txt; done
 # keep what is merged back small: the per-dispatch traces are large, the stats and counter CSVs are not
 find $OUT -name "*kernel_trace.csv" -size +4M -delete
-for f in $(find $OUT/prof $OUT/prof_train -name "*kernel_stats.csv"); do echo "== $f"; head -8 $f; done
+for f in $(find $OUT/prof $OUT/prof_train $OUT/prof_scores $OUT/prof_cfg -name "*kernel_stats.csv"); do echo "== $f"; head -8 $f; done
