@@ -399,6 +399,37 @@ int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state 
         }
     }
     void *args[] = {&p};
+    if (pl.parts) {
+        // Two parts launches must not share the chip.  Within ONE launch a consumer can never keep its producer off a CU
+        // (index order, see sdp_parts_map_kernel); with two launches on two streams the waiting parts of one could hold
+        // the CUs the other's producers are queued for, and vice versa -- a deadlock that the bounded spins would turn
+        // into SDP_E_HANDOFF and wrong results.  So every parts launch waits for the previous one on this device,
+        // whatever stream that was on (an event per device; the lock keeps wait + launch + record of two host threads
+        // apart).  Not during stream capture, where an event of uncaptured work may not be waited on: launches inside one
+        // graph are ordered by the graph, and concurrent graphs that both hold parts launches are the caller's to order.
+        static std::mutex mtx;
+        static hipEvent_t last[64];
+        static bool have[64] = {false};
+        std::lock_guard<std::mutex> lock(mtx);
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        const bool track = device < 64 && hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
+        if (track && have[device]) {
+            e = hipStreamWaitEvent((hipStream_t)stream, last[device], 0);
+            if (e != hipSuccess) return fail_hip(e, "hipStreamWaitEvent(previous parts launch)");
+        }
+        e = hipLaunchKernel(v.kernel, dim3(grid), dim3(64 * W), args, lds, (hipStream_t)stream);
+        if (e != hipSuccess) return fail_hip(e, "hipLaunchKernel");
+        if (track) {
+            if (!have[device]) {
+                e = hipEventCreateWithFlags(&last[device], hipEventDisableTiming);
+                if (e != hipSuccess) return fail_hip(e, "hipEventCreateWithFlags");
+                have[device] = true;
+            }
+            e = hipEventRecord(last[device], (hipStream_t)stream);
+            if (e != hipSuccess) return fail_hip(e, "hipEventRecord(parts launch)");
+        }
+        return 0;
+    }
     e = hipLaunchKernel(v.kernel, dim3(grid), dim3(64 * W), args, lds, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "hipLaunchKernel");
     return 0;

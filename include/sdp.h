@@ -217,7 +217,9 @@ int sdp_plan(int pass, int B, int N, int M, int has_lens, int exact_state, int c
  * batches with per-pair lengths that do not outnumber the CUs (the batch takes as long as its longest pair; forward sweep:
  * pairs of more than eight strips, backward sweep: more than four), and the backward sweep of a few equal pairs of more
  * than twelve strips; the boundary between two parts of a pair then crosses
- * CUs through 8-byte granules in the tail of the state buffer.  Results do not depend on it (bit-identical). */
+ * CUs through 8-byte granules in the tail of the state buffer.  Results do not depend on it (bit-identical).  Such
+ * launches wait for the previous one of their kind on the same device, whatever its stream (two of them sharing the chip
+ * could starve each other's producers); during stream capture that ordering is the graph's / the caller's. */
 int sdp_plan_parts(int pass, int B, int N, int M, int has_lens, int exact_state, int cus);
 
 #ifdef SDP_EXPERIMENTS

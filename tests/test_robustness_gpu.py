@@ -103,3 +103,63 @@ def test_two_threads_two_streams_overlap():
         for k, v in jobs[i][4].items():
             assert np.array_equal(results[i][k], v), (i, k)
     assert eng.check_device()[0] == 0
+
+
+def test_pairs_over_several_workgroups_repeat_and_overlap():
+    """Parts of a pair hand their boundary over through global memory with no fence and no flag (8-byte granules that
+    are either the memset pattern or written, sdp_kernels.hip "bridge"), in an order that must never leave a consumer on
+    a CU without its producer.  A protocol like that can be right by luck: run a batch with per-pair lengths that takes
+    it (the library's own policy) forty times, the second half of them while another stream streams through memory and a
+    second batch with its own state runs its sweeps on a third stream; every run must return the same bits, equal the
+    one-workgroup schedule, and no hand-off may have timed out."""
+    from deepblast_amd._engine import get_engine
+    eng = get_engine()
+    B, N, M = 200, 960, 640
+    assert eng.lib.sdp_plan_parts(0, B, N, M, 1, 0, 256) == 4 and eng.lib.sdp_plan_parts(1, B, N, M, 1, 0, 256) == 4
+    theta, A = datagen.theta_A(93001, B, N, M)
+    lens = datagen.lengths(93002, B, 1, N)
+    lens[:, 1] = np.minimum(lens[:, 1] * M // N + 1, M)
+    lens[0] = (N, M)
+    t, a = torch.from_numpy(theta).cuda(), torch.from_numpy(A).cuda()
+    ln = torch.from_numpy(lens).cuda()
+    et = torch.from_numpy((0.5 + datagen.uniform(93003, (B,))).astype(np.float32)).cuda()
+    # a second problem that takes parts too, for the third stream
+    t2, a2, ln2 = t[:64].contiguous() * 0.5, a[:64].contiguous(), ln[:64].contiguous()
+    s_noise, s_other = torch.cuda.Stream(), torch.cuda.Stream()
+    big = torch.empty(64 * 1024 * 1024, device="cuda")
+
+    def sweep(tt, aa, ll, ee):
+        Vt, Q = eng.forward(tt, aa, 0, ll)
+        return Vt, eng.backward(ee, Q, tuple(tt.shape), 0, ll)
+
+    first = other_first = None
+    for it in range(40):
+        if it >= 20:
+            s_noise.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s_noise):
+                big.add_(1.0)
+            s_other.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s_other):
+                o = sweep(t2, a2, ln2, et[:64])
+        Vt, E = sweep(t, a, ln, et)
+        torch.cuda.synchronize()
+        if first is None:
+            first = (Vt.clone(), E.clone())
+        assert torch.equal(Vt, first[0]) and torch.equal(E, first[1]), it
+        if it >= 20:
+            if other_first is None:
+                other_first = (o[0].clone(), o[1].clone())
+            assert torch.equal(o[0], other_first[0]) and torch.equal(o[1], other_first[1]), it
+    assert eng.check_device()[0] == 0
+    # the same batch through the experiments build with one workgroup per pair (throughput kernels, like the parts)
+    exp = _exp_lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    exp.sdp_set_debug(64)
+    st = torch.empty(exp.sdp_state_bytes(B, N, M) // 4, device="cuda")
+    vt = torch.empty(B, device="cuda")
+    E1 = torch.empty(B, N, M, device="cuda")
+    assert exp.sdp_forward_f32(t.data_ptr(), a.data_ptr(), st.data_ptr(), vt.data_ptr(), B, N, M, ln.data_ptr(), 4 << 12, 0, stream) == 0
+    assert exp.sdp_backward_f32(et.data_ptr(), st.data_ptr(), E1.data_ptr(), B, N, M, ln.data_ptr(), 4 << 12, 0, stream) == 0
+    exp.sdp_set_debug(0)
+    torch.cuda.synchronize()
+    assert torch.equal(vt, first[0]) and torch.equal(E1, first[1])
