@@ -663,6 +663,8 @@ int sdp_scores_f32(const float *zx, const float *zy, const float *gx, const floa
         if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(sdp_scores_kernel)");
         e = hipFuncSetAttribute((const void *)sdp_scores_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sdp::SCORES_X6_LDS_BYTES);
         if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(sdp_scores_x6_kernel)");
+        e = hipFuncSetAttribute((const void *)sdp_scores_x6s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sdp::SCORES_X6_LDS_BYTES);
+        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(sdp_scores_x6s_kernel)");
         e = hipFuncSetAttribute((const void *)sdp_scores_x6w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sdp::SCORES_X6W_LDS_BYTES);
         if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(sdp_scores_x6w_kernel)");
         if (device < 64) raised |= 1ull << device;
@@ -681,6 +683,8 @@ int sdp_scores_f32(const float *zx, const float *zy, const float *gx, const floa
     if (wide)
         hipLaunchKernelGGL(sdp_scores_x6w_kernel, dim3((M + 255) / 256, (N + 255) / 256, (unsigned)nz), dim3(512), sdp::SCORES_X6W_LDS_BYTES,
                            (hipStream_t)stream, zx, zy, gx, gy, theta, A, B, N, M, D);
+    else if (x6 && t128 * nz <= 2LL * num_cus(device))   // (no CU ever holds a third tile: the build with two workgroups' worth of registers, no scratch)
+        hipLaunchKernelGGL(sdp_scores_x6s_kernel, grid, dim3(256), sdp::SCORES_X6_LDS_BYTES, (hipStream_t)stream, zx, zy, gx, gy, theta, A, B, N, M, D);
     else if (x6)
         hipLaunchKernelGGL(sdp_scores_x6_kernel, grid, dim3(256), sdp::SCORES_X6_LDS_BYTES, (hipStream_t)stream, zx, zy, gx, gy, theta, A, B, N, M, D);
     else

@@ -175,6 +175,8 @@ __global__ void sdp_scores_kernel(const float *zx, const float *zy, const float 
                                   int M, int D);
 __global__ void sdp_scores_x6_kernel(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
                                      int M, int D);
+__global__ void sdp_scores_x6s_kernel(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
+                                     int M, int D);
 __global__ void sdp_scores_x6w_kernel(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
                                       int M, int D);
 __global__ void sdp_order_kernel(const int *lens, int *order, int B, int N, int M);

@@ -332,11 +332,10 @@ __device__ __forceinline__ void cut3(const f32x4 v, u32x2 (&piece)[3])
 }
 }  // namespace sdp
 
-extern "C" __global__ void __launch_bounds__(256, 3)
-sdp_scores_x6_kernel(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
-                     int M, int D)
+namespace sdp {
+__device__ __forceinline__ void scores_x6_body(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B,
+                                               int N, int M, int D)
 {
-    using namespace sdp;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_x6[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const TileId tile = xcd_tile();
@@ -477,6 +476,22 @@ sdp_scores_x6_kernel(const float *zx, const float *zy, const float *gx, const fl
     } else {
         scores_epilogue(acc, C, N, M, i0, j0, wr, wc, lane, kind);
     }
+}
+}  // namespace sdp
+
+// Two register budgets for the same code (identical results).  Three workgroups per CU (168 VGPRs; 8 of them spill to
+// scratch outside the slab loop) when there are enough tiles to have three on a CU; two workgroups per CU (no spills) for
+// the small batches, where a CU never sees a third tile anyway: 2-7 % faster there (16 x 512^2 x 512: 60.1 -> 58.7 us,
+// 4 x 1000 x 700 x 1024: 94.7 -> 88.2), 5 % slower with many tiles (100 x 300 x 200 x 512: 119 -> 125).
+extern "C" __global__ void __launch_bounds__(256, 3)
+sdp_scores_x6_kernel(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N, int M, int D)
+{
+    sdp::scores_x6_body(zx, zy, gx, gy, theta, A, B, N, M, D);
+}
+extern "C" __global__ void __launch_bounds__(256, 2)
+sdp_scores_x6s_kernel(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N, int M, int D)
+{
+    sdp::scores_x6_body(zx, zy, gx, gy, theta, A, B, N, M, D);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
