@@ -67,6 +67,19 @@ constexpr int max_waves(int pass)
 }
 
 constexpr int MAX_COLS = 2048;     // boundary rows live in LDS (4 x MAX_COLS x 8 B = 64 KiB)
+// how a pass represents the values that flow from cell to cell (sdp_kernels.hip, "Carry kinds")
+enum { CK_F64 = 0, CK_F32 = 1, CK_EXP = 2 };
+#ifndef SDP_FWD_KIND
+#define SDP_FWD_KIND 2
+#endif
+#ifndef SDP_BWD_KIND
+#define SDP_BWD_KIND 1
+#endif
+#ifndef SDP_ABWD_KIND
+#define SDP_ABWD_KIND 0
+#endif
+// bytes of one slot of a boundary row in LDS: 4 where the values are single floats (the fp32 backward sweep), else 8
+__host__ __device__ constexpr int boundary_slot_bytes(int pass) { return (pass == PASS_BWD && SDP_BWD_KIND == CK_F32) ? 4 : 8; }
 constexpr int FRAME_CAP = 136;     // frame words per boundary row: >= 16-step blocks of a strip at MAX_COLS (+ a chunk)
 constexpr int PROG_STRIDE = 4096;  // > MAX_COLS: progress words are (use index)*PROG_STRIDE + columns
 

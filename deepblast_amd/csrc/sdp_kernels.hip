@@ -291,17 +291,7 @@ __device__ __forceinline__ void q_sharpen(float &wx, float &wy, float wm)
 //            power of two (added to the exponent) and a factor in [1,2), and the three operands are
 //            aligned to their largest exponent, so no finite input can overflow or cancel; every
 //            rescale is an exact power of two, so the only rounding is the fp32 fma chain itself.
-enum { CK_F64 = 0, CK_F32 = 1, CK_EXP = 2 };
-
-#ifndef SDP_FWD_KIND
-#define SDP_FWD_KIND 2
-#endif
-#ifndef SDP_BWD_KIND
-#define SDP_BWD_KIND 1
-#endif
-#ifndef SDP_ABWD_KIND
-#define SDP_ABWD_KIND 0
-#endif
+// (the enum, the SDP_*_KIND macros and boundary_slot_bytes live in sdp_kernels.h: the host sizes the LDS rows by them)
 
 template <int PASS>
 struct Kind {
@@ -474,7 +464,10 @@ __device__ __forceinline__ void sweep(const Params &p)
     // shares with strip s after strip s+1 -- the reader of that row -- has produced its own column c.  The
     // progress words are per wave (strips that share a word are processed one after the other by that wave).
     constexpr int nslot = 2;
-    u64 *bnd = reinterpret_cast<u64 *>(smem);
+    // (a slot holds what one column hands down: 8 bytes -- a float64, or the forward sweep's value / exponent pair -- and
+    //  4 in the fp32 backward sweep, whose LDS need at M <= 1024 thereby stays under half a CU's: two workgroups per CU)
+    using slot_t = std::conditional_t<boundary_slot_bytes(PASS) == 4, unsigned, u64>;
+    slot_t *bnd = reinterpret_cast<slot_t *>(smem);
     const unsigned prog = (unsigned)(uintptr_t)(bnd + (size_t)nslot * p.mcap);  // LDS byte address of word 0
     // frame words (forward sweep): one per boundary row and producer chunk, FRAME_NONE or the common exponent of
     // the K values that chunk published
@@ -495,11 +488,12 @@ __device__ __forceinline__ void sweep(const Params &p)
     // sweep only writes the block; the rest is zero-filled here by the pair's own workgroup (no separate memset
     // pass over the whole tensor): by the waves that have no strip (short pairs -- they start at once and finish
     // long before the batch's longest pair), otherwise by every wave after its last strip.
-    // With PARTS a pair has as many workgroup slots as the longest pair of the batch has parts; the slots past its own
-    // parts ("absent" parts: the shorter the pair, the more of them and the more there is to fill) share the fill, all
-    // their waves, and the parts that sweep do none.  Those slots sort last in the dispatch order: the fill runs on the
-    // CUs the short pairs have left, under the chains of the long ones (configs[2], backward sweep: 506 -> 3xx us; with
-    // the fill done by each pair's first part after its sweep the CUs it kept busy were missing for the queued parts).
+    // With PARTS a pair has as many workgroup slots as the longest pair of the batch has parts; the first slot past its
+    // own parts (an "absent" part: the shorter the pair, the more there is to fill) does the fill, all four waves, and
+    // the parts that sweep do none.  Measured on BASELINE configs[2] (backward sweep, 784 MB of zeros next to 724 MB of
+    // sweep traffic; 350 us with the fill switched off): fill by each pair's first part after its sweep 506 us; shared by
+    // all absent slots 475-510; by the first absent slot 445-490 (adopted); absent slots first in the dispatch order 533;
+    // throttled with s_sleep 500-870; nt / sc0 sc1 stores no change.  The fill costs about what it would cost alone.
     auto zero_fill = [&]() {
         if constexpr (T::SOUT > 0) {
             if (p.lens == nullptr || (n == p.N && m == p.M)) return;
@@ -508,9 +502,10 @@ __device__ __forceinline__ void sweep(const Params &p)
 #endif
             const int nabsent = parts ? p.nparts_max - nparts : 0;
             if (nabsent > 0 ? !absent : part != 0) return;
+            if (absent && wg_part != nparts) return;   // (the first of them does it all: the later ones come last in the dispatch order)
             const int idle = W > nstrips_wg ? W - nstrips_wg : 0;
-            const int parts = absent ? nabsent * W : (idle > 0 ? idle : W);                                 // waves that share the fill,
-            const int part = absent ? (wg_part - nparts) * W + wave : (idle > 0 ? wave - nstrips_wg : wave);   // this one's index among them
+            const int parts = absent ? W : (idle > 0 ? idle : W);                            // waves that share the fill,
+            const int part = absent ? wave : (idle > 0 ? wave - nstrips_wg : wave);          // this one's index among them
             if (part < 0) return;
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             constexpr int ZF_AUX = SDP_ZF_AUX;
@@ -578,8 +573,8 @@ __device__ __forceinline__ void sweep(const Params &p)
         const int pslot = has_pred ? (imported ? 1 : pidx % nslot) : 0, oslot = sidx % nslot;                 // boundary rows
         const int pword = has_pred ? (imported ? W : pidx % W) : 0, pbase = (has_pred && !imported) ? (pidx / W) * PROG_STRIDE : 0;  // progress words
         const int oword = sidx % W, obase = (sidx / W) * PROG_STRIDE;
-        const u64 *bnd_in = bnd + (size_t)pslot * p.mcap;
-        u64 *bnd_out = bnd + (size_t)oslot * p.mcap;
+        const slot_t *bnd_in = bnd + (size_t)pslot * p.mcap;
+        slot_t *bnd_out = bnd + (size_t)oslot * p.mcap;
         const int *frm_in = frm + pslot * FRAME_CAP;
         int *frm_out = frm + oslot * FRAME_CAP;
         int wf_skip = 0;  // blocks to leave to the normalised form after a failed windowed attempt
@@ -1493,12 +1488,12 @@ __device__ __forceinline__ void sweep(const Params &p)
                         // replay the producer's chunks (it works through the columns from the right, K at a time, and leaves the
                         // progress word at m - first column) down to the one that holds the lowest column needed here
                         const int lo = c_lo < 0 ? 0 : c_lo;
-                        u64 *bnd_w = bnd + (size_t)pslot * p.mcap;
+                        slot_t *bnd_w = bnd + (size_t)pslot * p.mcap;
                         while (ximp >= lo / K) {
                             unsigned xg_lo = 0, xg_hi = 0;
                             xb_wait(ximp, c, xg_lo, xg_hi);
                             const int col = ximp * K + lane;
-                            if (lane < K && col < m) bnd_w[col] = pack2(xg_lo, 0u);
+                            if (lane < K && col < m) bnd_w[col] = (slot_t)xg_lo;   // (value in the low word, 0 above it)
                             if (lane == 0) lds_store_i32(prog + 4 * pword, m - ximp * K);
                             --ximp;
                         }
@@ -1977,12 +1972,12 @@ __device__ __forceinline__ void sweep(const Params &p)
                 if (lane == PUB_LANE) {
                     if (c_lo >= 0 && c_lo + K <= m) {
 #pragma unroll
-                        for (int k = 0; k < K; ++k) bnd_out[c_lo + k] = hist[k];
+                        for (int k = 0; k < K; ++k) bnd_out[c_lo + k] = (slot_t)hist[k];
                     } else {
 #pragma unroll
                         for (int k = 0; k < K; ++k) {
                             const int col = c_lo + k;
-                            if (col >= 0 && col < m) bnd_out[col] = hist[k];
+                            if (col >= 0 && col < m) bnd_out[col] = (slot_t)hist[k];
                         }
                     }
                 }
@@ -2006,7 +2001,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                     if (exported && t0 < m) {
                         // the chunk's columns to the bridge row, one granule per lane (tag 0; columns past the matrix: dummies)
                         const int col = t0 + lane;
-                        const unsigned gv = (lane < K && col < m) ? lo32(bnd_out[col]) : 0u;
+                        const unsigned gv = (lane < K && col < m) ? (unsigned)bnd_out[col] : 0u;
                         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                         if (!(SDP_EXP_BUILD && (p.dbg & 8)))
                             __builtin_amdgcn_raw_buffer_store_b64((u32x2){gv, 0u}, rs_xo, lane < K ? (unsigned)(col * 8) : OOB, 0, XB_AUX);

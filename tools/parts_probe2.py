@@ -9,6 +9,8 @@ ln3 = datagen.lengths(2, B, 64, 1024)
 N, M = int(ln3[:, 0].max()), int(ln3[:, 1].max())
 if "aligned" in sys.argv:
     N = M = 1024   # rows of the padded batch on 128-byte lines: the kernels without per-row offsets
+if "round32" in sys.argv:   # column tails of E then start on 128-byte lines (with `aligned`)
+    ln3[:, 1] = np.minimum((ln3[:, 1] + 31) // 32 * 32, M)
 theta, A = datagen.theta_A(2, B, N, M)
 t, a = torch.from_numpy(theta).cuda(), torch.from_numpy(A).cuda()
 et = torch.ones(B, device="cuda")
