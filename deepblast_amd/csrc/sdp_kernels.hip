@@ -138,7 +138,10 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #define SDP_AUX_ST_LOAD ((SDP_NT & 2) ? 2 : 0)
 #endif
 constexpr int AUX_ST_STORE = SDP_AUX_ST_STORE, AUX_ST_LOAD = SDP_AUX_ST_LOAD;
-constexpr int AUX_IN_LOAD = (SDP_NT & 4) ? 2 : 0, AUX_OUT_STORE = (SDP_NT & 8) ? 2 : 0;
+#ifndef SDP_AUX_OUT_STORE   // explicit policy bits of the staged output stores (E, Ed)
+#define SDP_AUX_OUT_STORE ((SDP_NT & 8) ? 2 : 0)
+#endif
+constexpr int AUX_IN_LOAD = (SDP_NT & 4) ? 2 : 0, AUX_OUT_STORE = SDP_AUX_OUT_STORE;
 constexpr bool ABL_NOSTORE = (SDP_ABL & 1) != 0;
 constexpr bool ABL_NOLOAD = (SDP_ABL & 2) != 0;
 constexpr bool ABL_NOSYNC = (SDP_ABL & 4) != 0;
