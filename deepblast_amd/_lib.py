@@ -37,6 +37,8 @@ SIGNATURES = {
                                                 ctypes.c_int, ctypes.c_int, _c_i32p, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_void_p]),
     "sdp_scores_f32": (ctypes.c_int, [_c_f32p] * 6 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "sdp_scores_backward_ws_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "sdp_scores_backward_f32": (ctypes.c_int, [_c_f32p] * 13 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "sdp_traceback_capacity": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "sdp_traceback_i32": (ctypes.c_int, [_c_f32p, _c_i32p, _c_i32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i32p,
                                          ctypes.c_int, ctypes.c_void_p]),

@@ -694,6 +694,59 @@ int sdp_scores_f32(const float *zx, const float *zy, const float *gx, const floa
     return 0;
 }
 
+size_t sdp_scores_backward_ws_bytes(int B, int N, int M)
+{
+    if (B <= 0 || N <= 0 || M <= 0) return 0;
+    return (size_t)2 * B * N * M * sizeof(float);   // dS of theta, dS of A
+}
+
+int sdp_scores_backward_f32(const float *g_theta, const float *g_A, const float *theta, const float *A, const float *zx,
+                            const float *zy, const float *gx, const float *gy, float *ws, float *dzx, float *dzy, float *dgx,
+                            float *dgy, int B, int N, int M, int D, int device, void *stream)
+{
+    const bool has_t = g_theta != nullptr, has_a = g_A != nullptr;
+    if (!has_t && !has_a) return fail(SDP_E_NULLPTR, "sdp_scores_backward_f32: neither g_theta nor g_A");
+    if (!ws || (has_t && !(theta && zx && zy && dzx && dzy)) || (has_a && !(A && gx && gy && dgx && dgy)))
+        return fail(SDP_E_NULLPTR, "sdp_scores_backward_f32: null pointer");
+    if (B <= 0 || N <= 0 || M <= 0 || D <= 0) return fail(SDP_E_SHAPE, "B, N, M and D must be positive");
+    if ((size_t)N * M > ((size_t)1 << 28) || (size_t)N * D > ((size_t)1 << 28) || (size_t)M * D > ((size_t)1 << 28))
+        return fail(SDP_E_TOOBIG, "a matrix of one pair exceeds 2^28 elements");
+    auto aligned16 = [](const void *q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (M % 4 != 0 || D % 4 != 0 || !(aligned16(g_theta) && aligned16(g_A) && aligned16(theta) && aligned16(A) && aligned16(zx) && aligned16(zy) &&
+                                      aligned16(gx) && aligned16(gy) && aligned16(ws) && aligned16(dzx) && aligned16(dzy) && aligned16(dgx) && aligned16(dgy)))
+        return fail(SDP_E_SHAPE, "sdp_scores_backward_f32 needs M and D multiples of 4 and 16-byte aligned tensors");
+    const long long nz = (long long)(has_t && has_a ? 2 : 1) * B;
+    if (nz > 65535) return fail(SDP_E_TOOBIG, "too many pairs for one launch (grid.z)");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    static thread_local unsigned long long raised = 0;
+    if (device >= 64 || !(raised >> device & 1ull)) {
+        e = hipFuncSetAttribute((const void *)sdp_scores_bwd_x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sdp::SCORES_X6W_LDS_BYTES);
+        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(sdp_scores_bwd_x_kernel)");
+        e = hipFuncSetAttribute((const void *)sdp_scores_bwd_y_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sdp::SCORES_X6W_LDS_BYTES);
+        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(sdp_scores_bwd_y_kernel)");
+        if (device < 64) raised |= 1ull << device;
+    }
+    const size_t plane = (size_t)B * N * M;
+    float *ds_t = ws, *ds_a = ws + plane;
+    hipLaunchKernelGGL(sdp_scores_ds_kernel, dim3(num_cus(device) * 8), dim3(256), 0, (hipStream_t)stream, g_theta, g_A, theta, A, ds_t, ds_a, plane / 4);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "sdp_scores_ds_kernel");
+    // tensor 0 / 1 of a launch: theta's operands first when both are asked for
+    const float *d0 = has_t ? ds_t : ds_a, *d1 = ds_a;
+    const float *y0 = has_t ? zy : gy, *y1 = gy, *x0 = has_t ? zx : gx, *x1 = gx;
+    float *cx0 = has_t ? dzx : dgx, *cx1 = dgx, *cy0 = has_t ? dzy : dgy, *cy1 = dgy;
+    hipLaunchKernelGGL(sdp_scores_bwd_x_kernel, dim3((D + 255) / 256, (N + 255) / 256, (unsigned)nz), dim3(512), sdp::SCORES_X6W_LDS_BYTES,
+                       (hipStream_t)stream, d0, d1, y0, y1, cx0, cx1, B, N, M, D);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "sdp_scores_bwd_x_kernel");
+    hipLaunchKernelGGL(sdp_scores_bwd_y_kernel, dim3((D + 255) / 256, (M + 255) / 256, (unsigned)nz), dim3(512), sdp::SCORES_X6W_LDS_BYTES,
+                       (hipStream_t)stream, d0, d1, x0, x1, cy0, cy1, B, N, M, D);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "sdp_scores_bwd_y_kernel");
+    return 0;
+}
+
 int sdp_traceback_capacity(int N, int M) { return (N > 0 && M > 0) ? N + M + 2 : 0; }
 
 int sdp_traceback_rule_i32(const float *grad, int32_t *states, int32_t *counts, int B, int N, int M, const int32_t *lens,

@@ -524,34 +524,83 @@ static_assert(2 * XW_BUF == SCORES_X6W_LDS_BYTES, "sdp_kernels.h: SCORES_X6W_LDS
 #endif
 }  // namespace sdp
 
-extern "C" __global__ void __launch_bounds__(512)
-sdp_scores_x6w_kernel(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
-                      int M, int D)
+namespace sdp {
+
+// an operand of the 256 x 256 product: `rows` output indices r, `kd` contraction indices k, element (r, k) at
+// p[r * ld + k] (ROW mode: k contiguous -- the embeddings in the forward product) or at p[k * ld + r] (COL mode: r
+// contiguous -- the operands of the backward products, which contract over the ROWS of the tensors as they lie in memory)
+struct XwOperand {
+    const float *p;
+    int rows, ld;
+};
+
+// unpermute an index within its block of 32: COL-mode operands sit in LDS with row 4 g + e of a block at position g + 8 e
+// (see store_half), so position x holds row 4 (x & 7) + (x >> 3)
+__device__ __forceinline__ int xw_unperm(int x) { return (x & ~31) + 4 * (x & 7) + ((x >> 3) & 3); }
+
+// epilogue of the general product through LDS: as scores_epilogue_lds, with the output's own extents and pitch, without
+// the activation, and with the rows / columns of COL-mode operands put back in order on the way into the slice
+template <int NA, bool APERM, bool BPERM>
+__device__ __forceinline__ void xw_epilogue_plain(const f32x16 (&acc)[NA][2], float *slice, float *C, int R, int Cn, int i0, int j0, int wr, int wc,
+                                                  int lane)
 {
-    using namespace sdp;
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(C, 0, R * Cn * 4, 0x00020000);
+    const int wrow = 4 * (lane >> 5), wcol = BPERM ? xw_unperm(lane & 31) : (lane & 31);
+    const int rrow = lane >> 4, rcol = (lane & 15) * 4;
+    const int col = j0 + wc + rcol;   // (Cn is a multiple of 4: a float4 never straddles the end of a row)
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int pr = wrow + (v & 3) + 8 * (v >> 2);
+                slice[(APERM ? xw_unperm(pr) : pr) * EPI_PITCH + 32 * c + wcol] = acc[a][c][v];
+            }
+        const int row0 = i0 + wr + 32 * a + rrow;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 y = *reinterpret_cast<const f32x4 *>(slice + (rrow + 4 * i) * EPI_PITCH + rcol);
+            const int row = row0 + 4 * i;
+            const unsigned off = (row < R && col < Cn) ? (unsigned)(row * Cn + col) * 4u : 0x80000000u;
+            u32x4 w = {__float_as_uint(y[0]), __float_as_uint(y[1]), __float_as_uint(y[2]), __float_as_uint(y[3])};
+            __builtin_amdgcn_raw_buffer_store_b128(w, rc, off, 0, 0);
+        }
+    }
+}
+
+// The 256 x 256 three-piece product  C[r, c] = sum_k X(r, k) Y(c, k)  of one tile (i0, j0).  FWD: both operands in ROW mode,
+// kd a multiple of 16, softplus / logsigmoid epilogue (the forward scores).  Otherwise: the operand modes given, any kd,
+// plain epilogue with output pitch Y.rows (the backward products).
+template <bool ACOL, bool BCOL, bool FWD>
+__device__ __forceinline__ void xw_gemm(const XwOperand X, const XwOperand Y, int kd, float *C, int i0, int j0, int kind)
+{
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_xw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const TileId tile = xcd_tile();
-    const int kind = tile.z >= B;
-    const int b = kind ? tile.z - B : tile.z;
-    const float *X = (kind ? gx : zx) + ((SDP_XW_ABL & 128) ? 0 : (size_t)b * N * D);   // (ablation 128: every tile reads pair 0, tile 0: cache-served loads)
-    const float *Y = (kind ? gy : zy) + ((SDP_XW_ABL & 128) ? 0 : (size_t)b * M * D);
-    float *C = (kind ? A : theta) + (size_t)b * N * M;
-    const int i0 = tile.y * XW_TILE, j0 = tile.x * XW_TILE;
     const int li0 = (SDP_XW_ABL & 128) ? 0 : i0, lj0 = (SDP_XW_ABL & 128) ? 0 : j0;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, N * D * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Y), 0, M * D * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X.p), 0, (ACOL ? kd : X.rows) * X.ld * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Y.p), 0, (BCOL ? kd : Y.rows) * Y.ld * 4, 0x00020000);
 
-    // staging: a slab is 256 rows x 16 k per operand = 1024 float4; thread t moves rows t / 4 and t / 4 + 128, k = 4 (t % 4)
+    // staging, ROW mode: a slab is 256 rows x 16 k per operand = 1024 float4; thread t moves rows t / 4 and t / 4 + 128, k = 4 (t % 4)
     const int ld_row = tid >> 2, ld_k = (tid & 3) * 4;
     const int st_col = (((ld_k >> 3) ^ ((ld_row >> 3) & 1)) << 4) + ((ld_k & 4) << 1);   // (rows + 128 keep the same swizzle bit)
+    // COL mode: the slab is 16 rows of memory (k) x 256 consecutive r; thread t moves r = 4 (t / 8) .. + 3 of the two rows
+    // k = 2 (t % 8), + 1 -- one float4 each -- and so holds, for each of its four r, the two k that share a dword of bf16 pairs
+    const int cg = tid >> 3, ckq = tid & 7;
     unsigned row_off[2][2];
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int op = 0; op < 2; ++op) {
-            const int row = (op ? lj0 : li0) + ld_row + 128 * q;
-            row_off[op][q] = row < (op ? M : N) ? (unsigned)((size_t)row * D + ld_k) * 4u : 0x80000000u;   // outside: zeros
+            const bool colmode = op ? BCOL : ACOL;
+            const XwOperand &P = op ? Y : X;
+            if (colmode) {
+                const int r = (op ? lj0 : li0) + 4 * cg;
+                row_off[op][q] = r < P.rows ? (unsigned)((size_t)(2 * ckq + q) * P.ld + r) * 4u : 0x80000000u;
+            } else {
+                const int row = (op ? lj0 : li0) + ld_row + 128 * q;
+                row_off[op][q] = row < P.rows ? (unsigned)((size_t)row * P.ld + ld_k) * 4u : 0x80000000u;   // outside: zeros
+            }
         }
     constexpr int AHEAD = SDP_XW_AHEAD;
     static_assert(AHEAD % 2 == 0, "the loop unrolls by AHEAD and a slab's LDS buffer is its parity");
@@ -561,34 +610,62 @@ sdp_scores_x6w_kernel(const float *zx, const float *zy, const float *gx, const f
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int op = 0; op < 2; ++op) {
+                const bool colmode = op ? BCOL : ACOL;
                 f32x4 v;
                 if constexpr (SDP_XW_ABL & 16) {
                     v[0] = v[1] = v[2] = v[3] = (float)(k0 + q + op);
                 } else {
-                    const auto w = __builtin_amdgcn_raw_buffer_load_b128(op ? ry : rx, k0 < D ? row_off[op][q] : 0x80000000u, (SDP_XW_ABL & 256) ? 0 : k0 * 4, 0);   // (ablation 256: every slab re-reads slab 0: L1-served)
+                    // k inside the contraction?  FWD: whole slabs (kd a multiple of 16), one uniform test
+                    const bool kok = FWD ? k0 < kd : (colmode ? k0 + 2 * ckq + q < kd : k0 + ld_k < kd);
+                    const int soff = (SDP_XW_ABL & 256) ? 0 : (colmode ? k0 * (op ? Y.ld : X.ld) * 4 : k0 * 4);   // (ablation 256: every slab re-reads slab 0: L1-served)
+                    const auto w = __builtin_amdgcn_raw_buffer_load_b128(op ? ry : rx, kok ? row_off[op][q] : 0x80000000u, soff, 0);
                     v[0] = __uint_as_float(w[0]), v[1] = __uint_as_float(w[1]), v[2] = __uint_as_float(w[2]), v[3] = __uint_as_float(w[3]);
                 }
                 st[op][q] = v;
             }
     };
-    // rows ld_row + 128 q of both operands: cut into pieces, three 8-byte LDS writes each
+    // half q of a slab into LDS, cut into pieces.  ROW mode: rows ld_row + 128 q, four consecutive k -> three 8-byte writes.
+    // COL mode: the thread's r = 4 cg + 2 q, + 1, the k pair (2 ckq, 2 ckq + 1) -> three 4-byte writes per r; row 4 g + e of a
+    // block of 32 goes to position g + 8 e, so that the eight threads of a wave that write together (cg = 8 w .. 8 w + 7,
+    // same e) hit eight consecutive 32-byte rows -- all 64 banks -- instead of every fourth (xw_unperm undoes it in the epilogue)
     auto store_half = [&](int buf, const f32x4 (&st)[2][2], int q) {
 #pragma unroll
         for (int op = 0; op < 2; ++op) {
-            u32x2 piece[3];
-            if constexpr (SDP_XW_ABL & 2) {
-                piece[0][0] = __float_as_uint(st[op][q][0]), piece[0][1] = __float_as_uint(st[op][q][1]);
-                piece[1][0] = __float_as_uint(st[op][q][2]), piece[1][1] = __float_as_uint(st[op][q][3]);
-                piece[2] = piece[0];
-            } else {
-                cut3(st[op][q], piece);
-            }
+            const bool colmode = op ? BCOL : ACOL;
+            if (colmode) {
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
-                if constexpr (SDP_XW_ABL & 64) {
-                    if (piece[pc][0] == 0x12345u) lds_xw[pc] = 1;
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const int e = 2 * q + e2;
+                    const float ve = st[op][0][e], vo = st[op][1][e];
+                    const unsigned h0e = __float_as_uint(ve), h0o = __float_as_uint(vo);
+                    const float r1e = ve - __uint_as_float(h0e & 0xffff0000u), r1o = vo - __uint_as_float(h0o & 0xffff0000u);   // exact
+                    const unsigned h1e = __float_as_uint(r1e), h1o = __float_as_uint(r1o);
+                    const float r2e = r1e - __uint_as_float(h1e & 0xffff0000u), r2o = r1o - __uint_as_float(h1o & 0xffff0000u);
+                    const unsigned h2e = __float_as_uint(r2e), h2o = __float_as_uint(r2o);
+                    const unsigned piece[3] = {__builtin_amdgcn_perm(h0o, h0e, 0x07060302u), __builtin_amdgcn_perm(h1o, h1e, 0x07060302u),
+                                               __builtin_amdgcn_perm(h2o, h2e, 0x07060302u)};
+                    const int pos = 32 * (cg >> 3) + (cg & 7) + 8 * e;                                     // LDS row of r = 4 cg + e
+                    const int col = ((((ckq >> 2) ^ (e & 1)) << 4)) + (ckq & 3) * 4;                        // bytes of k = 2 ckq in that row (halves swapped in rows 8-15 of 16: (pos >> 3) & 1 = e & 1)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc)
+                        *reinterpret_cast<unsigned *>(lds_xw + buf * XW_BUF + (op * 3 + pc) * XW_PLANE + pos * X6_PITCH + col) = piece[pc];
+                }
+            } else {
+                u32x2 piece[3];
+                if constexpr (SDP_XW_ABL & 2) {
+                    piece[0][0] = __float_as_uint(st[op][q][0]), piece[0][1] = __float_as_uint(st[op][q][1]);
+                    piece[1][0] = __float_as_uint(st[op][q][2]), piece[1][1] = __float_as_uint(st[op][q][3]);
+                    piece[2] = piece[0];
                 } else {
-                    *reinterpret_cast<u32x2 *>(lds_xw + buf * XW_BUF + (op * 3 + pc) * XW_PLANE + (ld_row + 128 * q) * X6_PITCH + st_col) = piece[pc];
+                    cut3(st[op][q], piece);
+                }
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    if constexpr (SDP_XW_ABL & 64) {
+                        if (piece[pc][0] == 0x12345u) lds_xw[pc] = 1;
+                    } else {
+                        *reinterpret_cast<u32x2 *>(lds_xw + buf * XW_BUF + (op * 3 + pc) * XW_PLANE + (ld_row + 128 * q) * X6_PITCH + st_col) = piece[pc];
+                    }
                 }
             }
         }
@@ -611,7 +688,7 @@ sdp_scores_x6w_kernel(const float *zx, const float *zy, const float *gx, const f
     // No branch inside the loop body: with one, the compiler's wait-count bookkeeping gives up at the loop header and drains
     // every outstanding load there; the slab count is rounded up to a multiple of AHEAD instead -- the extra slab reads out
     // of range, i.e. zeros, and the cut behind the last slab goes into a buffer nobody reads.
-    const int nslab = D / X6_BK;
+    const int nslab = (kd + X6_BK - 1) / X6_BK;
 #pragma unroll
     for (int u = 0; u < AHEAD; ++u) load_slab(u * X6_BK, stage[u]);
     store_half(0, stage[0], 0);
@@ -672,13 +749,84 @@ sdp_scores_x6w_kernel(const float *zx, const float *zy, const float *gx, const f
 #pragma unroll
             for (int c = 0; c < 2; ++c) sum += acc[a][c][(3 * a + c) & 15];
         if (sum == 12345.f) C[0] = sum;
-    } else {
+    } else if constexpr (FWD) {
 #if SDP_XW_EPI_LDS
         // every wave is past its last fragment read (the phase barriers above): the staging buffers are free
         static_assert(8 * 32 * EPI_PITCH * 4 <= SCORES_X6W_LDS_BYTES, "one 32-row slice per wave");
-        scores_epilogue_lds(acc, reinterpret_cast<float *>(lds_xw) + wave * 32 * EPI_PITCH, C, N, M, i0, j0, wr, wc, lane, kind);
+        scores_epilogue_lds(acc, reinterpret_cast<float *>(lds_xw) + wave * 32 * EPI_PITCH, C, X.rows, Y.rows, i0, j0, wr, wc, lane, kind);
 #else
-        scores_epilogue(acc, C, N, M, i0, j0, wr, wc, lane, kind);
+        scores_epilogue(acc, C, X.rows, Y.rows, i0, j0, wr, wc, lane, kind);
 #endif
+    } else {
+        xw_epilogue_plain<4, ACOL, BCOL>(acc, reinterpret_cast<float *>(lds_xw) + wave * 32 * EPI_PITCH, C, X.rows, Y.rows, i0, j0, wr, wc, lane);
+    }
+}
+}  // namespace sdp
+
+extern "C" __global__ void __launch_bounds__(512)
+sdp_scores_x6w_kernel(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
+                      int M, int D)
+{
+    using namespace sdp;
+    const TileId tile = xcd_tile();
+    const int kind = tile.z >= B;
+    const int b = kind ? tile.z - B : tile.z;
+    const XwOperand X = {(kind ? gx : zx) + ((SDP_XW_ABL & 128) ? 0 : (size_t)b * N * D), N, D};   // (ablation 128: every tile reads pair 0, tile 0: cache-served loads)
+    const XwOperand Y = {(kind ? gy : zy) + ((SDP_XW_ABL & 128) ? 0 : (size_t)b * M * D), M, D};
+    xw_gemm<false, false, true>(X, Y, D, (kind ? A : theta) + (size_t)b * N * M, tile.y * XW_TILE, tile.x * XW_TILE, kind);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Backward of the scores (round 3): with dS = g * dact/ds (sdp_scores_ds_kernel below)
+//     d zx[b, i, d] = sum_j dS[b, i, j] zy[b, j, d]        sdp_scores_bwd_x_kernel: X = dS in ROW mode (k = j), Y = zy in COL mode
+//     d zy[b, j, d] = sum_i dS[b, i, j] zx[b, i, d]        sdp_scores_bwd_y_kernel: X = dS in COL mode (k = i), Y = zx in COL mode
+// and the same with (gx, gy, A) -- the reference gets them from autograd through its two einsums (alignment.py:122-123).
+// The same 256 x 256 three-piece product as the forward: fp32 accuracy on the bf16 pipe; tensors `kind` 0 / 1 in one launch.
+// ----------------------------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(512)
+sdp_scores_bwd_x_kernel(const float *ds0, const float *ds1, const float *y0, const float *y1, float *c0, float *c1, int B, int N, int M, int D)
+{
+    using namespace sdp;
+    const TileId tile = xcd_tile();
+    const int kind = tile.z >= B;
+    const int b = kind ? tile.z - B : tile.z;
+    const XwOperand X = {(kind ? ds1 : ds0) + (size_t)b * N * M, N, M};
+    const XwOperand Y = {(kind ? y1 : y0) + (size_t)b * M * D, D, D};
+    xw_gemm<false, true, false>(X, Y, M, (kind ? c1 : c0) + (size_t)b * N * D, tile.y * XW_TILE, tile.x * XW_TILE, kind);
+}
+
+extern "C" __global__ void __launch_bounds__(512)
+sdp_scores_bwd_y_kernel(const float *ds0, const float *ds1, const float *x0, const float *x1, float *c0, float *c1, int B, int N, int M, int D)
+{
+    using namespace sdp;
+    const TileId tile = xcd_tile();
+    const int kind = tile.z >= B;
+    const int b = kind ? tile.z - B : tile.z;
+    const XwOperand X = {(kind ? ds1 : ds0) + (size_t)b * N * M, M, M};
+    const XwOperand Y = {(kind ? x1 : x0) + (size_t)b * N * D, D, D};
+    xw_gemm<true, true, false>(X, Y, N, (kind ? c1 : c0) + (size_t)b * M * D, tile.y * XW_TILE, tile.x * XW_TILE, kind);
+}
+
+// dS = g * d act / d s from the saved OUTPUTS (no pre-activations were kept): d softplus(s) / ds = sigmoid(s) = 1 - exp(-theta),
+// d logsigmoid(s) / ds = 1 - sigmoid(s) = 1 - exp(A); expm1: no cancellation where the factor is small.  n4 = float4 count.
+extern "C" __global__ void __launch_bounds__(256)
+sdp_scores_ds_kernel(const float *g_theta, const float *g_A, const float *theta, const float *A, float *ds_theta, float *ds_A, size_t n4)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        if (g_theta) {
+            const f4 g = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(g_theta) + i), t = reinterpret_cast<const f4 *>(theta)[i];
+            f4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = g[e] * -expm1f(-t[e]);
+            reinterpret_cast<f4 *>(ds_theta)[i] = o;
+        }
+        if (g_A) {
+            const f4 g = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(g_A) + i), t = reinterpret_cast<const f4 *>(A)[i];
+            f4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = g[e] * -expm1f(t[e]);
+            reinterpret_cast<f4 *>(ds_A)[i] = o;
+        }
     }
 }

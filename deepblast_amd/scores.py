@@ -10,7 +10,9 @@ with one launch of a hand-written batched GEMM on the matrix cores whose epilogu
 (`sdp_scores_f32`, deepblast_amd/csrc/sdp_scores.hip: bf16 MFMA over exact three-piece operands, fp32 accuracy; the
 f32-input MFMA for ragged D).  Differentiable: the backward needs no saved
 pre-activations -- d softplus(s)/ds = sigmoid(s) = 1 - exp(-theta) and d logsigmoid(s)/ds = 1 - exp(A) -- and
-forms the gradients of the embeddings with plain library GEMMs (torch.bmm = rocBLAS/hipBLASLt).
+forms the gradients of the embeddings with the same three-piece product (`sdp_scores_backward_f32`: the two contractions
+per tensor run over the ROWS of the tensors as they lie in memory, no transposed copies); shapes it does not take
+(M or D not a multiple of 4) use library GEMMs (torch.bmm).
 """
 import torch
 
@@ -50,14 +52,51 @@ class _Scores(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_theta, g_A):
         zx, zy, gx, gy, theta, A = ctx.saved_tensors
-        out = [None, None, None, None]
-        if g_theta is not None:
-            ds = g_theta * (-torch.expm1(-theta))            # sigmoid(s) = 1 - exp(-softplus(s)); expm1: no cancellation for small theta
-            out[0], out[1] = torch.bmm(ds, zy), torch.bmm(ds.transpose(1, 2), zx)
-        if g_A is not None:
-            ds = g_A * (-torch.expm1(A))                      # 1 - sigmoid(s) = 1 - exp(logsigmoid(s))
-            out[2], out[3] = torch.bmm(ds, gy), torch.bmm(ds.transpose(1, 2), gx)
-        return tuple(out)
+        if _native_backward_ok(zx, zy, g_theta, g_A):
+            return _native_backward(zx, zy, gx, gy, theta, A, g_theta, g_A)
+        return _torch_backward(zx, zy, gx, gy, theta, A, g_theta, g_A)
+
+
+def _torch_backward(zx, zy, gx, gy, theta, A, g_theta, g_A):
+    """Library GEMMs (torch.bmm) -- shapes the native kernels do not take (M or D not a multiple of 4, unaligned views)."""
+    out = [None, None, None, None]
+    if g_theta is not None:
+        ds = g_theta * (-torch.expm1(-theta))            # sigmoid(s) = 1 - exp(-softplus(s)); expm1: no cancellation for small theta
+        out[0], out[1] = torch.bmm(ds, zy), torch.bmm(ds.transpose(1, 2), zx)
+    if g_A is not None:
+        ds = g_A * (-torch.expm1(A))                      # 1 - sigmoid(s) = 1 - exp(logsigmoid(s))
+        out[2], out[3] = torch.bmm(ds, gy), torch.bmm(ds.transpose(1, 2), gx)
+    return tuple(out)
+
+
+def _native_backward_ok(zx, zy, g_theta, g_A):
+    B, N, D = zx.shape
+    M = zy.shape[1]
+    if M % 4 or D % 4 or 2 * B > 65535 or max(N * M, N * D, M * D) > (1 << 28):
+        return False
+    return all(g is None or (g.dtype == torch.float32 and g.device == zx.device) for g in (g_theta, g_A))
+
+
+def _native_backward(zx, zy, gx, gy, theta, A, g_theta, g_A):
+    """sdp_scores_backward_f32: dS = g * dact/ds in one pass, then the two products per tensor on the bf16 pipe with exact
+    three-piece operands (fp32 accuracy) -- one launch per side for both tensors (deepblast_amd/csrc/sdp_scores.hip)."""
+    eng = get_engine()
+    dev = eng._dev(zx)
+    B, N, D = zx.shape
+    M = zy.shape[1]
+    gt = None if g_theta is None else g_theta.contiguous()
+    ga = None if g_A is None else g_A.contiguous()
+    ws = torch.empty(eng.lib.sdp_scores_backward_ws_bytes(B, N, M) // 4, dtype=torch.float32, device=zx.device)
+    new = lambda like: torch.empty_like(like)
+    dzx, dzy = (new(zx), new(zy)) if gt is not None else (None, None)
+    dgx, dgy = (new(gx), new(gy)) if ga is not None else (None, None)
+    tensors = (gt, ga, theta, A, zx, zy, gx, gy, ws, dzx, dzy, dgx, dgy)
+    if any(t is not None and (t.data_ptr() & 15) for t in tensors):
+        return _torch_backward(zx, zy, gx, gy, theta, A, g_theta, g_A)
+    with torch.cuda.device(dev), eng._bracket("sdp_scores_bwd"):
+        rc = eng.lib.sdp_scores_backward_f32(*[_ptr(t) for t in tensors], B, N, M, D, dev, eng._stream(dev))
+    _lib.check(rc, "sdp_scores_backward_f32")
+    return dzx, dzy, dgx, dgy
 
 
 def alignment_scores(zx, zy, gx, gy):

@@ -64,7 +64,7 @@
 extern "C" {
 #endif
 
-#define SDP_VERSION 101 /* 0.1.1: + sdp_init, sdp_traceback_rule_i32 */
+#define SDP_VERSION 102 /* 0.1.1: + sdp_init, sdp_traceback_rule_i32 */
 
 #define SDP_NW 0
 #define SDP_SW 1
@@ -131,6 +131,19 @@ int sdp_adjoint_backward_f32(const float *E, const float *state, const float *st
  * three-piece kernel an Inf operand gives NaN (Inf - Inf in the cut) where the f32 kernel and torch give Inf. */
 int sdp_scores_f32(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
                    int M, int D, int device, void *stream);
+
+/* Backward of sdp_scores_f32: the gradients of the embeddings from the gradients of theta and A (the reference gets them
+ * from autograd through its two einsums and activations, alignment.py:122-123).  With dS = g * d act / ds formed from the
+ * saved OUTPUTS -- g_theta * (1 - exp(-theta)), g_A * (1 - exp(A)) -- into `ws` (sdp_scores_backward_ws_bytes; caller-owned
+ * scratch):  dzx[b,i,:] = sum_j dS_theta[b,i,j] zy[b,j,:],  dzy[b,j,:] = sum_i dS_theta[b,i,j] zx[b,i,:], and dgx, dgy
+ * from (dS_A, gy, gx).  The same three-piece bf16 product as the forward (fp32 accuracy), 256 x 256 tiles, one launch per
+ * side for both tensors.  (g_A, A, gx, gy, dgx, dgy) may be NULL together (theta only), likewise the theta group.
+ * Needs M and D multiples of 4 and 16-byte aligned tensors: otherwise SDP_E_SHAPE (the Python layer then uses
+ * torch.bmm).  Inputs must be finite. */
+size_t sdp_scores_backward_ws_bytes(int B, int N, int M);
+int sdp_scores_backward_f32(const float *g_theta, const float *g_A, const float *theta, const float *A, const float *zx,
+                            const float *zy, const float *gx, const float *gy, float *ws, float *dzx, float *dzy, float *dgx,
+                            float *dgy, int B, int N, int M, int D, int device, void *stream);
 
 /* Batched traceback (reference: Decoder.traceback, deepblast/nw.py:401-444, called once per pair by
  * NeuralAligner.traceback, alignment.py:165-170).  grad is (B,N,M); states receives, per pair, up to

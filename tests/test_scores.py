@@ -136,3 +136,73 @@ def test_scores_feed_the_dp():
     rt, ra = scores_oracle.scores(*arrs)
     ref = parity.oracle_all(rt, ra, None, None, 0)
     assert parity.abs_err(aln.detach().cpu().numpy(), ref["E"]) <= parity.TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(256, 512, 512, 512), (3, 130, 260, 48), (2, 300, 128, 100), (1, 1, 2048, 8), (5, 257, 516, 20), (4, 600, 36, 64)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_native_backward_matches_float64_autograd(shape):
+    """sdp_scores_backward_f32 (dS pass + two three-piece products per tensor whose contractions run over the rows of the
+    tensors in memory) against float64 autograd through the reference's own ops (alignment.py:122-123) -- fp32 accuracy --
+    and against the library-GEMM path it replaces; one-sided gradients (theta only / A only) go through the same kernels."""
+    import torch
+    import torch.nn.functional as F
+    from deepblast_amd import scores as sc
+    B, N, M, D = shape
+    t = [torch.from_numpy((datagen.normal(800 + i, (B, n, D)) * 2.0 / np.sqrt(D)).astype(np.float32)).cuda() for i, n in enumerate((N, M, N, M))]
+    wt = torch.from_numpy(datagen.normal(810, (B, N, M)).astype(np.float32)).cuda()
+    wa = torch.from_numpy(datagen.normal(811, (B, N, M)).astype(np.float32)).cuda()
+    assert sc._native_backward_ok(t[0], t[1], wt, wa)
+    t64 = [x.double().requires_grad_() for x in t]
+    th64 = F.softplus(torch.einsum("bid,bjd->bij", t64[0], t64[1]))
+    a64 = F.logsigmoid(torch.einsum("bid,bjd->bij", t64[2], t64[3]))
+    ((th64 * wt.double()).sum() + (a64 * wa.double()).sum()).backward()
+    ref = [x.grad for x in t64]
+    calls = []
+    orig = sc._native_backward
+    sc._native_backward = lambda *a: (calls.append(1), orig(*a))[1]
+    try:
+        for mode in ("both", "theta", "A"):
+            tt = [x.clone().requires_grad_() for x in t]
+            theta, A = sc.alignment_scores(*tt)
+            loss = (theta * wt).sum() * (mode != "A") + (A * wa).sum() * (mode != "theta")
+            if mode == "both":
+                loss.backward()
+                got = [x.grad for x in tt]
+            elif mode == "theta":
+                got = list(torch.autograd.grad((theta * wt).sum(), tt[:2])) + [None, None]
+            else:
+                got = [None, None] + list(torch.autograd.grad((A * wa).sum(), tt[2:]))
+            for k, (g, r) in enumerate(zip(got, ref)):
+                if g is None:
+                    continue
+                scale = max(1.0, float(r.abs().max()))
+                err = float((g.double() - r).abs().max()) / scale
+                assert err <= 2e-6, (shape, mode, k, err)   # an fp32 sum of <= 2048 products of this size: ~1e-7 .. 1e-6
+    finally:
+        sc._native_backward = orig
+    assert len(calls) == 3
+    # the path it replaces (torch.bmm) agrees to the same bound
+    th, A = sc.alignment_scores(*t)
+    lib = sc._torch_backward(t[0], t[1], t[2], t[3], th, A, wt, wa)
+    nat = sc._native_backward(t[0], t[1], t[2], t[3], th, A, wt, wa)
+    for k in range(4):
+        scale = max(1.0, float(lib[k].abs().max()))
+        assert float((lib[k] - nat[k]).abs().max()) / scale <= 5e-6, (shape, k)
+
+
+@pytest.mark.gpu
+def test_backward_shapes_the_native_kernels_do_not_take_use_the_library():
+    import torch
+    from deepblast_amd import scores as sc
+    B, N, M, D = 2, 50, 33, 24   # M not a multiple of 4
+    t = [torch.from_numpy((datagen.normal(820 + i, (B, n, D)) / np.sqrt(D)).astype(np.float32)).cuda().requires_grad_() for i, n in enumerate((N, M, N, M))]
+    assert not sc._native_backward_ok(t[0], t[1], None, None)
+    theta, A = sc.alignment_scores(*t)
+    (theta.sum() + A.sum()).backward()
+    assert all(x.grad is not None and torch.isfinite(x.grad).all() for x in t)
+    eng_lib = sc.get_engine().lib
+    ws = torch.empty(8, device="cuda")
+    rc = eng_lib.sdp_scores_backward_f32(theta.data_ptr(), None, theta.data_ptr(), None, t[0].data_ptr(), t[1].data_ptr(), None, None, ws.data_ptr(),
+                                         t[0].data_ptr(), t[1].data_ptr(), None, None, B, N, M, D, 0, None)
+    assert rc != 0   # SDP_E_SHAPE, not a launch

@@ -1,6 +1,7 @@
 #!/bin/bash
 export TMPDIR=/tmp
-timeout 300 python tools/parts_probe2.py 2>&1 | grep -v amdgpu | tail -2
-timeout 300 python tools/ab.py 256x512x512 256x1024x1024 16x1024x1024 | tail -3
-for c in "256 1022 1020" "700 1022 1020" "256 640 640"; do echo "== lens $c"; timeout 300 python tools/parts_probe.py $c lens 2>&1 | grep "^parts"; done
-timeout 1500 python -m pytest tests/test_parity_gpu.py tests/test_robustness_gpu.py -m gpu -x -q 2>&1 | grep -E "passed|failed|FAILED"
+mkdir -p gpurun_out/sbprof
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/sbprof -o sb -- python tools/scores_bwd_probe.py > gpurun_out/sbprof/out.txt 2>&1
+grep -v amdgpu gpurun_out/sbprof/out.txt | grep "us" 
+f=$(find gpurun_out/sbprof -name "*kernel_stats.csv" | head -1); head -12 $f | cut -d, -f1-4 | cut -c1-120
+find gpurun_out/sbprof -name "*kernel_trace.csv" -delete
