@@ -74,6 +74,11 @@ def _native_backward_ok(zx, zy, g_theta, g_A):
     M = zy.shape[1]
     if M % 4 or D % 4 or 2 * B > 65535 or max(N * M, N * D, M * D) > (1 << 28):
         return False
+    # one workgroup per 256 x 256 tile of an output: a few large pairs leave most CUs idle (4 x 2000 x 2000 x 256: 542 us
+    # against 431 us for the library GEMMs; everything else measured was faster or equal, tools/scores_bwd_shapes.py)
+    tiles = 2 * B * min(-(-N // 256), -(-M // 256)) * -(-D // 256)
+    if tiles < torch.cuda.get_device_properties(zx.device).multi_processor_count // 2 and N * M > 512 * 512:
+        return False
     return all(g is None or (g.dtype == torch.float32 and g.device == zx.device) for g in (g_theta, g_A))
 
 

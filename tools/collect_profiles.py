@@ -40,6 +40,7 @@ for name, pattern in (("kernel_stats.csv", "prof/**/*kernel_stats.csv"), ("train
                       ("pmc_train_write_size.csv", "pmc_train_WRITE_SIZE/**/*counter_collection.csv"),
                       ("bench.json", "bench.json"), ("bench_train.json", "bench_train.json"),
                       ("scores_kernel_stats.csv", "prof_scores/**/*kernel_stats.csv"), ("configs_kernel_stats.csv", "prof_cfg/**/*kernel_stats.csv"),
+                      ("scores_bwd_kernel_stats.csv", "prof_scores_bwd/**/*kernel_stats.csv"), ("scores_bwd.txt", "scores_bwd.txt"),
                       ("bench_scores.json", "bench_scores.json"), ("bench_traceback.json", "bench_traceback.json"),
                       ("configs.txt", "configs.txt"), ("parts_configs2.txt", "parts_configs2.txt"),
                       ("ubench_mix.txt", "ubench_mix.txt"), ("ubench_mix2.txt", "ubench_mix2.txt"),

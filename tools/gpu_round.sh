@@ -31,6 +31,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o train -- python bench.py --steps 10 --warmup 2 --mode train --no-cpu-baseline > $OUT/bench_prof_train.json 2>> $OUT/rocprof.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_scores -o scores -- python bench.py --steps 10 --warmup 2 --mode scores+dp --no-cpu-baseline > $OUT/bench_prof_scores.json 2>> $OUT/rocprof.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_cfg -o cfg -- python tools/gpu_configs.py > $OUT/configs_prof.txt 2>> $OUT/rocprof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_scores_bwd -o sb -- python tools/scores_bwd_probe.py 2>> $OUT/rocprof.err | grep ' us' > $OUT/scores_bwd.txt
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o fwdbwd -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$C.err
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_train_$C -o train -- python bench.py --steps 3 --warmup 1 --mode train --no-cpu-baseline > /dev/null 2>> $OUT/pmc_$C.err
@@ -50,4 +51,4 @@ timeout 300 python tools/parts_probe.py 256 1022 1020 lens cfg3 2> /dev/null | g
 for u in mix mix2; do hipcc --offload-arch=gfx950 -O3 -o /tmp/$u tools/ubench/$u.hip 2> /dev/null && timeout 120 /tmp/$u 2>&1 | tee $OUT/ubench_$u.txt; done
 # keep what is merged back small: the per-dispatch traces are large, the stats and counter CSVs are not
 find $OUT -name "*kernel_trace.csv" -size +4M -delete
-for f in $(find $OUT/prof $OUT/prof_train $OUT/prof_scores $OUT/prof_cfg -name "*kernel_stats.csv"); do echo "== $f"; head -8 $f; done
+for f in $(find $OUT/prof $OUT/prof_train $OUT/prof_scores $OUT/prof_cfg $OUT/prof_scores_bwd -name "*kernel_stats.csv"); do echo "== $f"; head -8 $f; done
