@@ -384,9 +384,17 @@ int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state 
         p.nparts_max = parts_per_pair(p.N);
         p.xb = bridge_in_state(state, p.B, p.N, p.M, exact_state);
         p.xb_row = sdp::xb_row_granules(p.M);
-        // every granule "not written yet" (tag 0x7f7f7f7f): enqueued on the caller's stream like the launch itself
-        e = hipMemsetAsync(p.xb, 0x7f, bridge_bytes(p.B, p.N, p.M), (hipStream_t)stream);
-        if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(bridge rows)");
+        // every granule "not written yet" (tag 0x7f7f7f7f): enqueued on the caller's stream like the launch itself.  A
+        // kernel of our own, not hipMemsetAsync: captured into a graph (torch.cuda.graph) the memset node did not take effect
+        // before the sweep on replay -- consumers then took whatever the buffer held for granules (NaN results; tests/
+        // test_robustness_gpu.py::test_sweeps_can_be_captured_in_a_graph).
+        {
+            const size_t n8 = bridge_bytes(p.B, p.N, p.M) / 8;
+            const unsigned blocks = (unsigned)((n8 + 1023) / 1024 < 4096 ? (n8 + 1023) / 1024 : 4096);
+            hipLaunchKernelGGL(sdp_bridge_reset_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p.xb, n8);
+            e = hipGetLastError();
+            if (e != hipSuccess) return fail_hip(e, "sdp_bridge_reset_kernel");
+        }
         grid = (unsigned)p.B * (unsigned)p.nparts_max;
         p.order = nullptr;
         if (p.lens != nullptr) {

@@ -196,6 +196,7 @@ __global__ void sdp_scores_bwd_x_kernel(const float *ds0, const float *ds1, cons
 __global__ void sdp_scores_bwd_y_kernel(const float *ds0, const float *ds1, const float *x0, const float *x1, float *c0, float *c1, int B, int N, int M, int D);
 __global__ void sdp_scores_ds_kernel(const float *g_theta, const float *g_A, const float *theta, const float *A, float *ds_theta, float *ds_A, size_t n4);
 __global__ void sdp_order_kernel(const int *lens, int *order, int B, int N, int M);
+__global__ void sdp_bridge_reset_kernel(unsigned long long *xb, size_t n8);
 __global__ void sdp_parts_map_kernel(const int *lens, int *map, int B, int N, int M, int nparts_max, int strips);
 __global__ void sdp_traceback_kernel(const float *grad, int *states, int *counts, const int *lens, int B, int N, int M, int cap);
 __global__ void sdp_traceback_cuda_kernel(const float *grad, int *states, int *counts, const int *lens, int B, int N, int M, int cap);

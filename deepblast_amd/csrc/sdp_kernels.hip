@@ -2096,6 +2096,15 @@ extern "C" __global__ void __launch_bounds__(256) sdp_order_kernel(const int *le
 }
 
 // ----------------------------------------------------------------------------------
+// bridge rows of a parts launch: every granule "not written yet" (sdp_kernels.h: XB_INVALID in both words)
+// ----------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(256) sdp_bridge_reset_kernel(unsigned long long *xb, size_t n8)
+{
+    const unsigned long long pattern = ((unsigned long long)sdp::XB_INVALID << 32) | sdp::XB_INVALID;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) xb[i] = pattern;
+}
+
+// ----------------------------------------------------------------------------------
 // dispatch order when pairs are spread over several workgroups ("parts") and have their own lengths: map[h] = pair *
 // nparts_max + part for workgroup h.  Workgroups are handed to CUs in index order as CUs free up, and a part that is on
 // a CU before its producer has reached it only waits there.  So: every pair's part 0 first, then the parts 1, ... -- part

@@ -163,3 +163,43 @@ def test_pairs_over_several_workgroups_repeat_and_overlap():
     exp.sdp_set_debug(0)
     torch.cuda.synchronize()
     assert torch.equal(vt, first[0]) and torch.equal(E1, first[1])
+
+
+def test_sweeps_can_be_captured_in_a_graph():
+    """after sdp_init the entry points only enqueue (a memset and up to two kernels per sweep) and can be
+    captured.  Forward + backward of an equal-length batch and of a batch with per-pair lengths whose long pairs are spread
+    over several workgroups are captured once, replayed on new inputs, and must give the bits of the eager calls."""
+    from deepblast_amd._engine import get_engine
+    eng = get_engine()
+    eng.init()
+    for (B, N, M, use_lens) in ((24, 200, 264, False), (96, 704, 512, True)):
+        theta, A = datagen.theta_A(94000 + N, B, N, M)
+        theta2, _ = datagen.theta_A(94001 + N, B, N, M)
+        ln = None
+        if use_lens:
+            lens = datagen.lengths(94002, B, 1, N)
+            lens[:, 1] = np.minimum(lens[:, 1] * M // N + 1, M)
+            lens[0] = (N, M)
+            ln = torch.from_numpy(lens).cuda()
+            assert eng.lib.sdp_plan_parts(0, B, N, M, 1, 0, 256) == 4
+        t, a = torch.from_numpy(theta).cuda(), torch.from_numpy(A).cuda()
+        et = torch.ones(B, device="cuda")
+
+        def sweep():
+            Vt, Q = eng.forward(t, a, 0, ln)
+            return Vt, eng.backward(et, Q, (B, N, M), 0, ln)
+
+        sweep()   # warm-up outside the capture (allocator, lazy module loads)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = sweep()
+        for src in (theta, theta2):
+            t.copy_(torch.from_numpy(src))
+            g.replay()
+            torch.cuda.synchronize()
+            got = (out[0].clone(), out[1].clone())
+            ref = sweep()
+            torch.cuda.synchronize()
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (B, N, M, use_lens)
+    assert eng.check_device()[0] == 0
