@@ -793,7 +793,8 @@ __device__ __forceinline__ void sweep(const Params &p)
         // add and no reliance on how the hardware range-checks the scalar offset)
         // (blocks moved left by up to K-1 columns: one block set later)
         auto block_plain = [&](int bb) { return rows == 64 && bb >= QMAX + (li_unaligned ? 1 : 0) && (bb + 1) * K <= m; };
-        auto load_block_i = [&](int bb, bool plain, int i) {  // instruction i of block set bb -> registers
+        auto load_block_i = [&](int bb, auto plain_tag, int i) {  // instruction i of block set bb -> registers
+            constexpr bool plain = decltype(plain_tag)::value;   // (a compile-time flag: with a run-time one every load sat behind its own branch)
             if constexpr (T::SIN > 0) {
                 const int ubase = (i0 * ld + bb * K) * 4;
                 // non-plain: a group that lies entirely left or right of the row would be a real fetch (of the
@@ -825,9 +826,13 @@ __device__ __forceinline__ void sweep(const Params &p)
             }
         };
         auto load_block = [&](int bb) {  // whole block set at once
-            const bool plain = block_plain(bb);
+            if (block_plain(bb)) {
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) load_block_i(bb, plain, i);
+                for (int i = 0; i < NLD; ++i) load_block_i(bb, std::true_type{}, i);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) load_block_i(bb, std::false_type{}, i);
+            }
         };
         auto write_block = [&](int bb) {  // registers -> LDS ring
             if constexpr (T::SIN > 0 && !ABL_NOLDS) {
