@@ -264,6 +264,122 @@ def main():
     timer.enabled = True
     elapsed, per_step_ms = timed(args.steps)
     timer.enabled = False
+    cells = B * N * M if args.variant == "nw" else B * (N - 1) * (M - 1)
+    per_step_updates = (4 if args.mode.startswith("train") else 2) * cells
+    value = world * per_step_updates * args.steps / elapsed
+    ms = timer.means_ms()
+
+    def emit(e_gather, e_gather_one, paths_gather):
+        """rank 0: the ONE JSON line (called once: after the secondary measurements, or by the watchdog below)."""
+        if rank == 0:
+            # dominant kernel of THIS mode = the sweep / GEMM with the longest mean launch; its algorithmic bytes per cell
+            # follow SURVEY.md 8(d): fwd and bwd 12 B, adjoint fwd (a3) and adjoint bwd (a4) 32 B each (reference layout)
+            def algo_bytes_per_cell(name):
+                return 32 if name.startswith("sdp_adj_") else ALGO_BYTES_PER_CELL_UPDATE
+            cand = {k: v for k, v in ms.items() if k.startswith(("sdp_fwd", "sdp_bwd", "sdp_adj_", "sdp_scores"))}
+            dom = max(cand, key=cand.get) if cand else "sdp_fwd_kernel"
+            dom_ms = ms.get(dom, float("nan"))
+            dom_bytes = cells * algo_bytes_per_cell(dom)
+            achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+            # HBM bytes per launch from the PMC passes (profiles/traffic.json, tools/gpu_round.sh): only if that file was
+            # measured on exactly these kernel sources -- a stale figure is reported as null, not as a number
+            traffic, traffic_stamp = None, None
+            tf = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tf) and (B, N, M, args.variant) == (256, 512, 512, "nw"):
+                try:
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    import source_stamp
+                    tj = json.load(open(tf))
+                    traffic_stamp = tj.get("_stamp", {}).get("source_sha256")
+                    if traffic_stamp == source_stamp.source_sha():
+                        traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
+                    else:
+                        print("[bench] profiles/traffic.json was measured on other kernel sources: roofline.traffic = null", file=sys.stderr)
+                except (OSError, ValueError, ImportError):
+                    traffic = None
+            line = {
+                "metric": {"fwdbwd": "DP cell-updates/sec (fwd+bwd)", "align+traceback": "DP cell-updates/sec (fwd+bwd + batched traceback)", "train": "DP cell-updates/sec (train: fwd+bwd+adjoint pair)",
+                           "scores+dp": "DP cell-updates/sec (scores from embeddings + fwd+bwd)",
+                           "train-mce": "DP cell-updates/sec (train: decode + MatrixCrossEntropy + backward)",
+                           "train-mce-fused": "DP cell-updates/sec (train: fused decode + MatrixCrossEntropy + backward)"}[args.mode],
+                "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": float(np.median(per_step_ms)),
+                "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"{args.variant.upper()} soft-DP " + {"fwdbwd": "fwd+bwd", "align+traceback": "fwd+bwd+traceback", "train": "decode+loss.backward",
+                                                                            "scores+dp": f"scores(D={args.D})+fwd+bwd", "train-mce": "decode+MatrixCrossEntropy.backward",
+                                                                            "train-mce-fused": "fused decode+MatrixCrossEntropy.backward"}[args.mode] +
+                                       f", B={B} per GPU, N={N}, M={M}, random theta/A "
+                                       + ("(BASELINE.json configs[1])" if world == 1 else
+                                          f"(BASELINE.json configs[4] sharding: {B * world} pairs over {world} GPUs)"),
+                           "global_batch": B * world, "N": N, "M": M, "variant": args.variant,
+                           "parallelism": f"batch-sharded x{world}", "gather": args.gather if world > 1 else "none",
+                           "backend": ("rccl" if backend == "nccl" else backend + (" (ranks share one GPU: test mode)" if shared else "")) if world > 1 else "none",
+                           "arith": "fwd: scaled exp-domain f32 (exact power-of-two rescaling); bwd: f32; adjoint pair: f64 carries; f32 storage"},
+                "kernel_ms": ms,
+                "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                             "algorithmic_bytes_per_launch": dom_bytes,
+                             "launch_ms": dom_ms,
+                             "whole_step_frac": (per_step_updates * ALGO_BYTES_PER_CELL_UPDATE * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9)},
+            }
+            if dom.startswith("sdp_scores"):
+                # the GEMM dominates this mode: its bound is the matrix pipe (filled in below as scores_roofline); the
+                # HBM figures above then describe nothing and are replaced
+                line["roofline"] = None
+            if args.mode == "scores+dp" and ("sdp_scores_kernel" in ms or "sdp_scores_x6_kernel" in ms or "sdp_scores_x6w_kernel" in ms):
+                flops = 2.0 * 2.0 * B * N * M * args.D          # two (N,D) x (D,M) products per pair
+                if "sdp_scores_x6_kernel" in ms or "sdp_scores_x6w_kernel" in ms:
+                    # three exact bf16 pieces per operand, six piece products per k: the pipe executes 6x the algorithmic
+                    # flops; `achieved` / `peak` are what ran on the bf16 pipe, `algorithmic` the fp32-equivalent rate
+                    x6name = "sdp_scores_x6w_kernel" if "sdp_scores_x6w_kernel" in ms else "sdp_scores_x6_kernel"
+                    t_ms = ms[x6name]
+                    tf = 6.0 * flops / (t_ms * 1e-3) / 1e12
+                    line["scores_roofline"] = {"bound": "mfma", "kernel": x6name, "achieved": tf, "peak": 2516.6, "unit": "TFLOP/s", "traffic": None,
+                                               "frac": tf / 2516.6, "dtype": "bf16 x 6 piece products (v_mfma_f32_32x32x16_bf16), f32 accumulate",
+                                               "algorithmic": flops / (t_ms * 1e-3) / 1e12, "algorithmic_vs_f32_mfma_peak": flops / (t_ms * 1e-3) / 1e12 / 157.3,
+                                               "D": args.D, "launch_ms": t_ms, "flops_per_launch": flops}
+                else:
+                    tf = flops / (ms["sdp_scores_kernel"] * 1e-3) / 1e12
+                    line["scores_roofline"] = {"bound": "mfma", "kernel": "sdp_scores_kernel", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "traffic": None,
+                                               "frac": tf / 157.3, "dtype": "f32 (v_mfma_f32_32x32x2_f32)", "D": args.D,
+                                               "launch_ms": ms["sdp_scores_kernel"], "flops_per_launch": flops}
+            if args.mode == "scores+dp":
+                # the stated baseline for the scores: the reference's own two lines (alignment.py:122-123) as PyTorch runs
+                # them on this box (rocBLAS/hipBLASLt batched GEMM + elementwise kernels), same inputs, outside the timed region
+                import torch.nn.functional as F
+
+                def ref_scores():
+                    return (F.softplus(torch.einsum('bid,bjd->bij', emb[0], emb[1])),
+                            F.logsigmoid(torch.einsum('bid,bjd->bij', emb[2], emb[3])))
+                ref_scores()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    ref_scores()
+                e1.record()
+                torch.cuda.synchronize()
+                line["scores_torch_baseline"] = {"ms": e0.elapsed_time(e1) / 5, "what": "F.softplus(torch.einsum('bid,bjd->bij', zx, zy)), "
+                                                 "F.logsigmoid(torch.einsum(...gx, gy)) (deepblast/alignment.py:122-123), fp32, this box"}
+            if line["roofline"] is None:
+                line["roofline"] = line.get("scores_roofline")
+            if e_gather is not None:
+                line["with_e_gather"] = {"ms_per_step": e_gather * 1e3, "value": world * per_step_updates / e_gather,
+                                         "bytes_into_each_gpu": (world - 1) * B * N * M * 4,
+                                         "overlap": "chunked" if args.e_chunks > 1 else "none", "e_chunks": args.e_chunks}
+                if e_gather_one is not None:
+                    line["with_e_gather"]["one_collective_ms_per_step"] = e_gather_one * 1e3
+            if paths_gather is not None:
+                line["with_paths_gather"] = {"ms_per_step": paths_gather * 1e3, "value": world * per_step_updates / paths_gather,
+                                             "bytes_into_each_gpu": (world - 1) * B * (N + M + 4) * 4}
+            if "sdp_traceback_kernel" in ms:
+                line["traceback_ms"] = ms["sdp_traceback_kernel"]
+            if world == 1 and not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(args)
+                line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+            print(json.dumps(line), flush=True)
+
     # N > 1: the same job with the expected-alignment matrices gathered as well (SURVEY 8e: report scaling with
     # and without the E gather); a secondary figure, never `value`
     e_gather = e_gather_one = None
@@ -283,6 +399,23 @@ def main():
             aligner.gather = args.gather
             aligner.e_chunks = args.e_chunks
 
+    # A secondary figure must not cost the primary one either by HANGING: a rank that fails alone leaves the others
+    # inside a collective.  A watchdog on every rank lets rank 0 print the line without the secondary fields and ends the
+    # process if the secondary measurements have not finished in time (nothing here has ever run on more than one GPU).
+    import threading
+    emitted = threading.Lock()
+
+    def watchdog():
+        print(f"[bench] rank {rank}: secondary measurements did not finish in time: the line goes out without them", file=sys.stderr, flush=True)
+        if emitted.acquire(blocking=False):
+            emit(None, None, None)
+        os._exit(0)
+
+    dog = None
+    if world > 1 and args.mode == "fwdbwd" and not os.environ.get("BENCH_NO_SECONDARY"):
+        dog = threading.Timer(max(60.0, 200.0 * elapsed), watchdog)
+        dog.daemon = True
+        dog.start()
     if world > 1 and args.mode == "fwdbwd" and args.gather != "e" and not os.environ.get("BENCH_NO_SECONDARY"):
         e_gather = secondary("e")                 # backward sweep + gather in --e-chunks pieces
         e_gather_one = secondary("e", e_chunks=1) if args.e_chunks > 1 else None   # one collective after the sweep
@@ -291,119 +424,10 @@ def main():
     if world > 1 and args.mode == "fwdbwd" and args.gather != "paths" and not os.environ.get("BENCH_NO_SECONDARY"):
         paths_gather = secondary("paths")
 
-    cells = B * N * M if args.variant == "nw" else B * (N - 1) * (M - 1)
-    per_step_updates = (4 if args.mode.startswith("train") else 2) * cells
-    value = world * per_step_updates * args.steps / elapsed
-    ms = timer.means_ms()
-
-    if rank == 0:
-        # dominant kernel of THIS mode = the sweep / GEMM with the longest mean launch; its algorithmic bytes per cell
-        # follow SURVEY.md 8(d): fwd and bwd 12 B, adjoint fwd (a3) and adjoint bwd (a4) 32 B each (reference layout)
-        def algo_bytes_per_cell(name):
-            return 32 if name.startswith("sdp_adj_") else ALGO_BYTES_PER_CELL_UPDATE
-        cand = {k: v for k, v in ms.items() if k.startswith(("sdp_fwd", "sdp_bwd", "sdp_adj_", "sdp_scores"))}
-        dom = max(cand, key=cand.get) if cand else "sdp_fwd_kernel"
-        dom_ms = ms.get(dom, float("nan"))
-        dom_bytes = cells * algo_bytes_per_cell(dom)
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC passes (profiles/traffic.json, tools/gpu_round.sh): only if that file was
-        # measured on exactly these kernel sources -- a stale figure is reported as null, not as a number
-        traffic, traffic_stamp = None, None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf) and (B, N, M, args.variant) == (256, 512, 512, "nw"):
-            try:
-                sys.path.insert(0, os.path.join(ROOT, "tools"))
-                import source_stamp
-                tj = json.load(open(tf))
-                traffic_stamp = tj.get("_stamp", {}).get("source_sha256")
-                if traffic_stamp == source_stamp.source_sha():
-                    traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
-                else:
-                    print("[bench] profiles/traffic.json was measured on other kernel sources: roofline.traffic = null", file=sys.stderr)
-            except (OSError, ValueError, ImportError):
-                traffic = None
-        line = {
-            "metric": {"fwdbwd": "DP cell-updates/sec (fwd+bwd)", "align+traceback": "DP cell-updates/sec (fwd+bwd + batched traceback)", "train": "DP cell-updates/sec (train: fwd+bwd+adjoint pair)",
-                       "scores+dp": "DP cell-updates/sec (scores from embeddings + fwd+bwd)",
-                       "train-mce": "DP cell-updates/sec (train: decode + MatrixCrossEntropy + backward)",
-                       "train-mce-fused": "DP cell-updates/sec (train: fused decode + MatrixCrossEntropy + backward)"}[args.mode],
-            "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": float(np.median(per_step_ms)),
-            "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.variant.upper()} soft-DP " + {"fwdbwd": "fwd+bwd", "align+traceback": "fwd+bwd+traceback", "train": "decode+loss.backward",
-                                                                        "scores+dp": f"scores(D={args.D})+fwd+bwd", "train-mce": "decode+MatrixCrossEntropy.backward",
-                                                                        "train-mce-fused": "fused decode+MatrixCrossEntropy.backward"}[args.mode] +
-                                   f", B={B} per GPU, N={N}, M={M}, random theta/A "
-                                   + ("(BASELINE.json configs[1])" if world == 1 else
-                                      f"(BASELINE.json configs[4] sharding: {B * world} pairs over {world} GPUs)"),
-                       "global_batch": B * world, "N": N, "M": M, "variant": args.variant,
-                       "parallelism": f"batch-sharded x{world}", "gather": args.gather if world > 1 else "none",
-                       "backend": ("rccl" if backend == "nccl" else backend + (" (ranks share one GPU: test mode)" if shared else "")) if world > 1 else "none",
-                       "arith": "fwd: scaled exp-domain f32 (exact power-of-two rescaling); bwd: f32; adjoint pair: f64 carries; f32 storage"},
-            "kernel_ms": ms,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": dom_bytes,
-                         "launch_ms": dom_ms,
-                         "whole_step_frac": (per_step_updates * ALGO_BYTES_PER_CELL_UPDATE * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9)},
-        }
-        if dom.startswith("sdp_scores"):
-            # the GEMM dominates this mode: its bound is the matrix pipe (filled in below as scores_roofline); the
-            # HBM figures above then describe nothing and are replaced
-            line["roofline"] = None
-        if args.mode == "scores+dp" and ("sdp_scores_kernel" in ms or "sdp_scores_x6_kernel" in ms or "sdp_scores_x6w_kernel" in ms):
-            flops = 2.0 * 2.0 * B * N * M * args.D          # two (N,D) x (D,M) products per pair
-            if "sdp_scores_x6_kernel" in ms or "sdp_scores_x6w_kernel" in ms:
-                # three exact bf16 pieces per operand, six piece products per k: the pipe executes 6x the algorithmic
-                # flops; `achieved` / `peak` are what ran on the bf16 pipe, `algorithmic` the fp32-equivalent rate
-                x6name = "sdp_scores_x6w_kernel" if "sdp_scores_x6w_kernel" in ms else "sdp_scores_x6_kernel"
-                t_ms = ms[x6name]
-                tf = 6.0 * flops / (t_ms * 1e-3) / 1e12
-                line["scores_roofline"] = {"bound": "mfma", "kernel": x6name, "achieved": tf, "peak": 2516.6, "unit": "TFLOP/s", "traffic": None,
-                                           "frac": tf / 2516.6, "dtype": "bf16 x 6 piece products (v_mfma_f32_32x32x16_bf16), f32 accumulate",
-                                           "algorithmic": flops / (t_ms * 1e-3) / 1e12, "algorithmic_vs_f32_mfma_peak": flops / (t_ms * 1e-3) / 1e12 / 157.3,
-                                           "D": args.D, "launch_ms": t_ms, "flops_per_launch": flops}
-            else:
-                tf = flops / (ms["sdp_scores_kernel"] * 1e-3) / 1e12
-                line["scores_roofline"] = {"bound": "mfma", "kernel": "sdp_scores_kernel", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "traffic": None,
-                                           "frac": tf / 157.3, "dtype": "f32 (v_mfma_f32_32x32x2_f32)", "D": args.D,
-                                           "launch_ms": ms["sdp_scores_kernel"], "flops_per_launch": flops}
-        if args.mode == "scores+dp":
-            # the stated baseline for the scores: the reference's own two lines (alignment.py:122-123) as PyTorch runs
-            # them on this box (rocBLAS/hipBLASLt batched GEMM + elementwise kernels), same inputs, outside the timed region
-            import torch.nn.functional as F
-
-            def ref_scores():
-                return (F.softplus(torch.einsum('bid,bjd->bij', emb[0], emb[1])),
-                        F.logsigmoid(torch.einsum('bid,bjd->bij', emb[2], emb[3])))
-            ref_scores()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                ref_scores()
-            e1.record()
-            torch.cuda.synchronize()
-            line["scores_torch_baseline"] = {"ms": e0.elapsed_time(e1) / 5, "what": "F.softplus(torch.einsum('bid,bjd->bij', zx, zy)), "
-                                             "F.logsigmoid(torch.einsum(...gx, gy)) (deepblast/alignment.py:122-123), fp32, this box"}
-        if line["roofline"] is None:
-            line["roofline"] = line.get("scores_roofline")
-        if e_gather is not None:
-            line["with_e_gather"] = {"ms_per_step": e_gather * 1e3, "value": world * per_step_updates / e_gather,
-                                     "bytes_into_each_gpu": (world - 1) * B * N * M * 4,
-                                     "overlap": "chunked" if args.e_chunks > 1 else "none", "e_chunks": args.e_chunks}
-            if e_gather_one is not None:
-                line["with_e_gather"]["one_collective_ms_per_step"] = e_gather_one * 1e3
-        if paths_gather is not None:
-            line["with_paths_gather"] = {"ms_per_step": paths_gather * 1e3, "value": world * per_step_updates / paths_gather,
-                                         "bytes_into_each_gpu": (world - 1) * B * (N + M + 4) * 4}
-        if "sdp_traceback_kernel" in ms:
-            line["traceback_ms"] = ms["sdp_traceback_kernel"]
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args)
-            line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
-        print(json.dumps(line), flush=True)
+    if dog is not None:
+        dog.cancel()
+    if emitted.acquire(blocking=False):
+        emit(e_gather, e_gather_one, paths_gather)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
