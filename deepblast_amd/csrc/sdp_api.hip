@@ -443,6 +443,28 @@ int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state 
     return 0;
 }
 
+// dynamic-LDS limits of the scores kernels, once per (thread, device): sticky attributes, set before any launch that
+// may be captured (sdp_init) or lazily by the first call
+int raise_scores_limits(int device)
+{
+    static thread_local unsigned long long raised = 0;
+    if (device < 64 && (raised >> device & 1ull)) return 0;
+    const struct { const void *f; int bytes; const char *what; } ks[] = {
+        {(const void *)sdp_scores_kernel, sdp::SCORES_LDS_BYTES, "hipFuncSetAttribute(sdp_scores_kernel)"},
+        {(const void *)sdp_scores_x6_kernel, sdp::SCORES_X6_LDS_BYTES, "hipFuncSetAttribute(sdp_scores_x6_kernel)"},
+        {(const void *)sdp_scores_x6s_kernel, sdp::SCORES_X6_LDS_BYTES, "hipFuncSetAttribute(sdp_scores_x6s_kernel)"},
+        {(const void *)sdp_scores_x6w_kernel, sdp::SCORES_X6W_LDS_BYTES, "hipFuncSetAttribute(sdp_scores_x6w_kernel)"},
+        {(const void *)sdp_scores_bwd_x_kernel, sdp::SCORES_X6W_LDS_BYTES, "hipFuncSetAttribute(sdp_scores_bwd_x_kernel)"},
+        {(const void *)sdp_scores_bwd_y_kernel, sdp::SCORES_X6W_LDS_BYTES, "hipFuncSetAttribute(sdp_scores_bwd_y_kernel)"},
+    };
+    for (const auto &k : ks) {
+        const hipError_t e = hipFuncSetAttribute(k.f, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes);
+        if (e != hipSuccess) return fail_hip(e, k.what);
+    }
+    if (device < 64) raised |= 1ull << device;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -495,12 +517,12 @@ int sdp_init(int device)
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
     if (device >= 0 && device < MAX_DEV && !status_words(device)) return fail(SDP_E_SELFTEST, "sdp_init: could not create the host-pinned status words");
-    for (int id = 0; id <= 20; ++id) {
+    for (int id = 0; id <= 28; ++id) {   // (21-28: the parts instantiations)
         const Variant v = variant(id);
         if (v.id != id) continue;   // ids without a build of their own map to the default
         if (int rc = raise_lds_limit(v, device)) return rc;
     }
-    return 0;
+    return raise_scores_limits(device);
 }
 
 int sdp_device_status(int device, int32_t info[4])
@@ -665,18 +687,7 @@ int sdp_scores_f32(const float *zx, const float *zy, const float *gx, const floa
     if (nz > 65535) return fail(SDP_E_TOOBIG, "too many pairs for one launch (grid.z)");
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
-    static thread_local unsigned long long raised = 0;
-    if (device >= 64 || !(raised >> device & 1ull)) {
-        e = hipFuncSetAttribute((const void *)sdp_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sdp::SCORES_LDS_BYTES);
-        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(sdp_scores_kernel)");
-        e = hipFuncSetAttribute((const void *)sdp_scores_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sdp::SCORES_X6_LDS_BYTES);
-        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(sdp_scores_x6_kernel)");
-        e = hipFuncSetAttribute((const void *)sdp_scores_x6s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sdp::SCORES_X6_LDS_BYTES);
-        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(sdp_scores_x6s_kernel)");
-        e = hipFuncSetAttribute((const void *)sdp_scores_x6w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sdp::SCORES_X6W_LDS_BYTES);
-        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(sdp_scores_x6w_kernel)");
-        if (device < 64) raised |= 1ull << device;
-    }
+    if (int rc = raise_scores_limits(device)) return rc;
     // whole 16-deep slabs of 16-byte aligned rows: the three-piece bf16 product (sdp_scores.hip); anything else: the
     // f32-input MFMA kernel, which takes ragged D and unaligned rows
     auto aligned16 = [](const void *q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -727,14 +738,7 @@ int sdp_scores_backward_f32(const float *g_theta, const float *g_A, const float 
     if (nz > 65535) return fail(SDP_E_TOOBIG, "too many pairs for one launch (grid.z)");
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
-    static thread_local unsigned long long raised = 0;
-    if (device >= 64 || !(raised >> device & 1ull)) {
-        e = hipFuncSetAttribute((const void *)sdp_scores_bwd_x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sdp::SCORES_X6W_LDS_BYTES);
-        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(sdp_scores_bwd_x_kernel)");
-        e = hipFuncSetAttribute((const void *)sdp_scores_bwd_y_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sdp::SCORES_X6W_LDS_BYTES);
-        if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(sdp_scores_bwd_y_kernel)");
-        if (device < 64) raised |= 1ull << device;
-    }
+    if (int rc = raise_scores_limits(device)) return rc;
     const size_t plane = (size_t)B * N * M;
     float *ds_t = ws, *ds_a = ws + plane;
     hipLaunchKernelGGL(sdp_scores_ds_kernel, dim3(num_cus(device) * 8), dim3(256), 0, (hipStream_t)stream, g_theta, g_A, theta, A, ds_t, ds_a, plane / 4);

@@ -203,3 +203,39 @@ def test_sweeps_can_be_captured_in_a_graph():
             torch.cuda.synchronize()
             assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (B, N, M, use_lens)
     assert eng.check_device()[0] == 0
+
+
+def test_first_launch_of_a_process_can_be_a_captured_one():
+    """sdp_init does everything a first launch would otherwise do lazily (status words, the LDS limit of every kernel build,
+    the parts instantiations included): in a FRESH process, init -> capture -> replay, with no eager launch before the
+    capture, gives the eager results."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "tests")
+import datagen
+from deepblast_amd._engine import get_engine
+eng = get_engine(); eng.init()
+B, N, M = 96, 704, 512
+theta, A = datagen.theta_A(95001, B, N, M)
+lens = datagen.lengths(95002, B, 1, N); lens[:, 1] = np.minimum(lens[:, 1] * M // N + 1, M); lens[0] = (N, M)
+t, a, ln = torch.from_numpy(theta).cuda(), torch.from_numpy(A).cuda(), torch.from_numpy(lens).cuda()
+et = torch.ones(B, device="cuda")
+def sweep():
+    Vt, Q = eng.forward(t, a, 0, ln)
+    return Vt, eng.backward(et, Q, (B, N, M), 0, ln)
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    out = sweep()
+g.replay(); torch.cuda.synchronize()
+got = (out[0].clone(), out[1].clone())
+ref = sweep(); torch.cuda.synchronize()
+assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+assert eng.check_device()[0] == 0
+print("captured-first-launch ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "captured-first-launch ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
