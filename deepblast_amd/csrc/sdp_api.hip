@@ -456,6 +456,7 @@ int raise_scores_limits(int device)
         {(const void *)sdp_scores_x6w_kernel, sdp::SCORES_X6W_LDS_BYTES, "hipFuncSetAttribute(sdp_scores_x6w_kernel)"},
         {(const void *)sdp_scores_bwd_x_kernel, sdp::SCORES_X6W_LDS_BYTES, "hipFuncSetAttribute(sdp_scores_bwd_x_kernel)"},
         {(const void *)sdp_scores_bwd_y_kernel, sdp::SCORES_X6W_LDS_BYTES, "hipFuncSetAttribute(sdp_scores_bwd_y_kernel)"},
+        {(const void *)sdp_scores_bwd_yf_kernel, sdp::SCORES_X6W_LDS_BYTES, "hipFuncSetAttribute(sdp_scores_bwd_yf_kernel)"},
     };
     for (const auto &k : ks) {
         const hipError_t e = hipFuncSetAttribute(k.f, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes);
@@ -674,6 +675,14 @@ static bool scores_force_narrow()
     return false;
 #endif
 }
+bool scores_unfused()
+{
+#ifdef SDP_EXPERIMENTS
+    return (g_dbg.load() & 2048) != 0;   // sdp_set_debug(2048): backward of the scores with dS in a pass of its own (A/B timing, parity)
+#else
+    return false;
+#endif
+}
 
 int sdp_scores_f32(const float *zx, const float *zy, const float *gx, const float *gy, float *theta, float *A, int B, int N,
                    int M, int D, int device, void *stream)
@@ -741,21 +750,33 @@ int sdp_scores_backward_f32(const float *g_theta, const float *g_A, const float 
     if (int rc = raise_scores_limits(device)) return rc;
     const size_t plane = (size_t)B * N * M;
     float *ds_t = ws, *ds_a = ws + plane;
-    hipLaunchKernelGGL(sdp_scores_ds_kernel, dim3(num_cus(device) * 8), dim3(256), 0, (hipStream_t)stream, g_theta, g_A, theta, A, ds_t, ds_a, plane / 4);
-    e = hipGetLastError();
-    if (e != hipSuccess) return fail_hip(e, "sdp_scores_ds_kernel");
     // tensor 0 / 1 of a launch: theta's operands first when both are asked for
     const float *d0 = has_t ? ds_t : ds_a, *d1 = ds_a;
     const float *y0 = has_t ? zy : gy, *y1 = gy, *x0 = has_t ? zx : gx, *x1 = gx;
     float *cx0 = has_t ? dzx : dgx, *cx1 = dgx, *cy0 = has_t ? dzy : dgy, *cy1 = dgy;
-    hipLaunchKernelGGL(sdp_scores_bwd_x_kernel, dim3((D + 255) / 256, (N + 255) / 256, (unsigned)nz), dim3(512), sdp::SCORES_X6W_LDS_BYTES,
-                       (hipStream_t)stream, d0, d1, y0, y1, cx0, cx1, B, N, M, D);
+    const dim3 grid_y((D + 255) / 256, (M + 255) / 256, (unsigned)nz), grid_x((D + 255) / 256, (N + 255) / 256, (unsigned)nz);
+    if (scores_unfused()) {
+        // (experiments build, sdp_set_debug(2048): dS in a pass of its own, then the plain product -- what the fused kernel replaced)
+        hipLaunchKernelGGL(sdp_scores_ds_kernel, dim3(num_cus(device) * 8), dim3(256), 0, (hipStream_t)stream, g_theta, g_A, theta, A, ds_t, ds_a, plane / 4);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail_hip(e, "sdp_scores_ds_kernel");
+        hipLaunchKernelGGL(sdp_scores_bwd_y_kernel, grid_y, dim3(512), sdp::SCORES_X6W_LDS_BYTES, (hipStream_t)stream, d0, d1, x0, x1, cy0, cy1, B, N, M, D);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail_hip(e, "sdp_scores_bwd_y_kernel");
+    } else {
+        // dzy / dgy first: this product reads (g, act) and forms dS on the way into LDS; its first column of tiles writes dS
+        // to `ws` for the other product, which follows on the same stream
+        const float *g0 = has_t ? g_theta : g_A, *g1 = g_A, *a0 = has_t ? theta : A, *a1 = A;
+        const float sg0 = has_t ? -1.0f : 1.0f, sg1 = 1.0f;
+        float *w0 = has_t ? ds_t : ds_a, *w1 = ds_a;
+        hipLaunchKernelGGL(sdp_scores_bwd_yf_kernel, grid_y, dim3(512), sdp::SCORES_X6W_LDS_BYTES, (hipStream_t)stream, g0, g1, a0, a1, sg0, sg1, x0, x1, w0, w1,
+                           cy0, cy1, B, N, M, D);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail_hip(e, "sdp_scores_bwd_yf_kernel");
+    }
+    hipLaunchKernelGGL(sdp_scores_bwd_x_kernel, grid_x, dim3(512), sdp::SCORES_X6W_LDS_BYTES, (hipStream_t)stream, d0, d1, y0, y1, cx0, cx1, B, N, M, D);
     e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "sdp_scores_bwd_x_kernel");
-    hipLaunchKernelGGL(sdp_scores_bwd_y_kernel, dim3((D + 255) / 256, (M + 255) / 256, (unsigned)nz), dim3(512), sdp::SCORES_X6W_LDS_BYTES,
-                       (hipStream_t)stream, d0, d1, x0, x1, cy0, cy1, B, N, M, D);
-    e = hipGetLastError();
-    if (e != hipSuccess) return fail_hip(e, "sdp_scores_bwd_y_kernel");
     return 0;
 }
 

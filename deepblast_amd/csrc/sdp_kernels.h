@@ -194,6 +194,8 @@ __global__ void sdp_scores_x6w_kernel(const float *zx, const float *zy, const fl
                                       int M, int D);
 __global__ void sdp_scores_bwd_x_kernel(const float *ds0, const float *ds1, const float *y0, const float *y1, float *c0, float *c1, int B, int N, int M, int D);
 __global__ void sdp_scores_bwd_y_kernel(const float *ds0, const float *ds1, const float *x0, const float *x1, float *c0, float *c1, int B, int N, int M, int D);
+__global__ void sdp_scores_bwd_yf_kernel(const float *g0, const float *g1, const float *act0, const float *act1, float sg0, float sg1, const float *x0,
+                                         const float *x1, float *ds0, float *ds1, float *c0, float *c1, int B, int N, int M, int D);
 __global__ void sdp_scores_ds_kernel(const float *g_theta, const float *g_A, const float *theta, const float *A, float *ds_theta, float *ds_A, size_t n4);
 __global__ void sdp_order_kernel(const int *lens, int *order, int B, int N, int M);
 __global__ void sdp_bridge_reset_kernel(unsigned long long *xb, size_t n8);

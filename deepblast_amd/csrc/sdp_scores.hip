@@ -532,6 +532,8 @@ namespace sdp {
 struct XwOperand {
     const float *p;
     int rows, ld;
+    const float *act = nullptr;   // AFUSE (operand X only): the saved activation output; the operand is p * (1 - exp(sg * act))
+    float sg = 0.f;               //   sg = -1: p = g_theta, act = theta (d softplus = 1 - exp(-theta)); +1: p = g_A, act = A (d logsigmoid = 1 - exp(A))
 };
 
 // unpermute an index within its block of 32: COL-mode operands sit in LDS with row 4 g + e of a block at position g + 8 e
@@ -572,14 +574,20 @@ __device__ __forceinline__ void xw_epilogue_plain(const f32x16 (&acc)[NA][2], fl
 // The 256 x 256 three-piece product  C[r, c] = sum_k X(r, k) Y(c, k)  of one tile (i0, j0).  FWD: both operands in ROW mode,
 // kd a multiple of 16, softplus / logsigmoid epilogue (the forward scores).  Otherwise: the operand modes given, any kd,
 // plain epilogue with output pitch Y.rows (the backward products).
-template <bool ACOL, bool BCOL, bool FWD>
-__device__ __forceinline__ void xw_gemm(const XwOperand X, const XwOperand Y, int kd, float *C, int i0, int j0, int kind)
+// AFUSE (with ACOL): operand X is dS = g * d act / ds, formed from (g, act) on its way into LDS; the workgroups of the first
+// column of tiles (j0 == 0) -- which between them see every element of X exactly once -- also write it to `ds_out`, in X's
+// own layout, for the product that needs it in ROW mode (sdp_scores_bwd_x_kernel).
+template <bool ACOL, bool BCOL, bool FWD, bool AFUSE = false>
+__device__ __forceinline__ void xw_gemm(const XwOperand X, const XwOperand Y, int kd, float *C, int i0, int j0, int kind, float *ds_out = nullptr)
 {
+    static_assert(!AFUSE || (ACOL && !FWD), "the fused activation derivative is written for the column-mode operand of the backward product");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_xw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li0 = (SDP_XW_ABL & 128) ? 0 : i0, lj0 = (SDP_XW_ABL & 128) ? 0 : j0;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X.p), 0, (ACOL ? kd : X.rows) * X.ld * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Y.p), 0, (BCOL ? kd : Y.rows) * Y.ld * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(AFUSE ? X.act : X.p), 0, (ACOL ? kd : X.rows) * X.ld * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rds = __builtin_amdgcn_make_buffer_rsrc((AFUSE && ds_out) ? ds_out : C, 0, (AFUSE && ds_out && j0 == 0) ? kd * X.ld * 4 : 0, 0x00020000);
 
     // staging, ROW mode: a slab is 256 rows x 16 k per operand = 1024 float4; thread t moves rows t / 4 and t / 4 + 128, k = 4 (t % 4)
     const int ld_row = tid >> 2, ld_k = (tid & 3) * 4;
@@ -605,7 +613,8 @@ __device__ __forceinline__ void xw_gemm(const XwOperand X, const XwOperand Y, in
     constexpr int AHEAD = SDP_XW_AHEAD;
     static_assert(AHEAD % 2 == 0, "the loop unrolls by AHEAD and a slab's LDS buffer is its parity");
     f32x4 stage[AHEAD][2][2];
-    auto load_slab = [&](int k0, f32x4 (&st)[2][2]) {
+    f32x4 stage_act[AFUSE ? AHEAD : 1][2];   // AFUSE: the activation outputs that go with stage[.][0][.]
+    auto load_slab = [&](int k0, f32x4 (&st)[2][2], f32x4 (&sa)[2]) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -620,6 +629,12 @@ __device__ __forceinline__ void xw_gemm(const XwOperand X, const XwOperand Y, in
                     const int soff = (SDP_XW_ABL & 256) ? 0 : (colmode ? k0 * (op ? Y.ld : X.ld) * 4 : k0 * 4);   // (ablation 256: every slab re-reads slab 0: L1-served)
                     const auto w = __builtin_amdgcn_raw_buffer_load_b128(op ? ry : rx, kok ? row_off[op][q] : 0x80000000u, soff, 0);
                     v[0] = __uint_as_float(w[0]), v[1] = __uint_as_float(w[1]), v[2] = __uint_as_float(w[2]), v[3] = __uint_as_float(w[3]);
+                    if constexpr (AFUSE) {
+                        if (op == 0) {
+                            const auto w2 = __builtin_amdgcn_raw_buffer_load_b128(rx2, kok ? row_off[op][q] : 0x80000000u, soff, 0);
+                            sa[q][0] = __uint_as_float(w2[0]), sa[q][1] = __uint_as_float(w2[1]), sa[q][2] = __uint_as_float(w2[2]), sa[q][3] = __uint_as_float(w2[3]);
+                        }
+                    }
                 }
                 st[op][q] = v;
             }
@@ -628,15 +643,25 @@ __device__ __forceinline__ void xw_gemm(const XwOperand X, const XwOperand Y, in
     // COL mode: the thread's r = 4 cg + 2 q, + 1, the k pair (2 ckq, 2 ckq + 1) -> three 4-byte writes per r; row 4 g + e of a
     // block of 32 goes to position g + 8 e, so that the eight threads of a wave that write together (cg = 8 w .. 8 w + 7,
     // same e) hit eight consecutive 32-byte rows -- all 64 banks -- instead of every fourth (xw_unperm undoes it in the epilogue)
-    auto store_half = [&](int buf, const f32x4 (&st)[2][2], int q) {
+    auto store_half = [&](int buf, const f32x4 (&st)[2][2], const f32x4 (&sa)[2], int q, int k0) {
 #pragma unroll
         for (int op = 0; op < 2; ++op) {
             const bool colmode = op ? BCOL : ACOL;
             if (colmode) {
+                float dsv[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // AFUSE: [k row][e2] of this half, for the side store
 #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2) {
                     const int e = 2 * q + e2;
-                    const float ve = st[op][0][e], vo = st[op][1][e];
+                    float ve = st[op][0][e], vo = st[op][1][e];
+                    if constexpr (AFUSE) {
+                        if (op == 0) {
+                            // g * (1 - exp(sg * act)): absolute error ~1e-7 |g| (the factor is in [0, 1]); out-of-range loads gave 0 * (1 - 1)
+                            const float c = 1.44269504088896340736f * X.sg;
+                            ve *= 1.0f - __builtin_amdgcn_exp2f(c * sa[0][e]);
+                            vo *= 1.0f - __builtin_amdgcn_exp2f(c * sa[1][e]);
+                            dsv[0][e2] = ve, dsv[1][e2] = vo;
+                        }
+                    }
                     const unsigned h0e = __float_as_uint(ve), h0o = __float_as_uint(vo);
                     const float r1e = ve - __uint_as_float(h0e & 0xffff0000u), r1o = vo - __uint_as_float(h0o & 0xffff0000u);   // exact
                     const unsigned h1e = __float_as_uint(r1e), h1o = __float_as_uint(r1o);
@@ -649,6 +674,16 @@ __device__ __forceinline__ void xw_gemm(const XwOperand X, const XwOperand Y, in
 #pragma unroll
                     for (int pc = 0; pc < 3; ++pc)
                         *reinterpret_cast<unsigned *>(lds_xw + buf * XW_BUF + (op * 3 + pc) * XW_PLANE + pos * X6_PITCH + col) = piece[pc];
+                }
+                if constexpr (AFUSE) {
+                    if (op == 0) {   // (the descriptor is empty unless this workgroup is in the first column of tiles: stores dropped)
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) {
+                            const int k = k0 + 2 * ckq + kk, r = li0 + 4 * cg + 2 * q;
+                            const u32x2 w = {__float_as_uint(dsv[kk][0]), __float_as_uint(dsv[kk][1])};
+                            __builtin_amdgcn_raw_buffer_store_b64(w, rds, (k < kd && r < X.rows) ? (unsigned)((size_t)k * X.ld + r) * 4u : 0x80000000u, 0, 0);
+                        }
+                    }
                 }
             } else {
                 u32x2 piece[3];
@@ -690,16 +725,16 @@ __device__ __forceinline__ void xw_gemm(const XwOperand X, const XwOperand Y, in
     // of range, i.e. zeros, and the cut behind the last slab goes into a buffer nobody reads.
     const int nslab = (kd + X6_BK - 1) / X6_BK;
 #pragma unroll
-    for (int u = 0; u < AHEAD; ++u) load_slab(u * X6_BK, stage[u]);
-    store_half(0, stage[0], 0);
-    store_half(0, stage[0], 1);
+    for (int u = 0; u < AHEAD; ++u) load_slab(u * X6_BK, stage[u], stage_act[AFUSE ? u : 0]);
+    store_half(0, stage[0], stage_act[0], 0, 0);
+    store_half(0, stage[0], stage_act[0], 1, 0);
     __syncthreads();
     for (int s0 = 0; s0 < nslab; s0 += AHEAD) {
 #pragma unroll
         for (int u = 0; u < AHEAD; ++u) {
             const int s = s0 + u;
             const int buf = u & 1;   // = s & 1 (AHEAD is even)
-            load_slab((s + AHEAD) * X6_BK, stage[u]);   // slab s went to LDS in the previous iteration
+            load_slab((s + AHEAD) * X6_BK, stage[u], stage_act[AFUSE ? u : 0]);   // slab s went to LDS in the previous iteration
             const unsigned char *base = lds_xw + buf * XW_BUF;
             bf16x8 fb[2][3], fa[2][2][3];
             auto read_fa = [&](int h, bf16x8 (&f)[2][3]) {   // rows 64 h .. 64 h + 63 of this wave's 128: two 32-row blocks
@@ -737,8 +772,8 @@ __device__ __forceinline__ void xw_gemm(const XwOperand X, const XwOperand Y, in
                             }
                         }
             }
-            store_half(buf ^ 1, stage[(u + 1) % AHEAD], 0);   // slab s + 1
-            store_half(buf ^ 1, stage[(u + 1) % AHEAD], 1);
+            store_half(buf ^ 1, stage[(u + 1) % AHEAD], stage_act[AFUSE ? (u + 1) % AHEAD : 0], 0, (s + 1) * X6_BK);   // slab s + 1
+            store_half(buf ^ 1, stage[(u + 1) % AHEAD], stage_act[AFUSE ? (u + 1) % AHEAD : 0], 1, (s + 1) * X6_BK);
             __syncthreads();
         }
     }
@@ -793,6 +828,22 @@ sdp_scores_bwd_x_kernel(const float *ds0, const float *ds1, const float *y0, con
     const XwOperand X = {(kind ? ds1 : ds0) + (size_t)b * N * M, N, M};
     const XwOperand Y = {(kind ? y1 : y0) + (size_t)b * M * D, D, D};
     xw_gemm<false, true, false>(X, Y, M, (kind ? c1 : c0) + (size_t)b * N * D, tile.y * XW_TILE, tile.x * XW_TILE, kind);
+}
+
+// ... and the variant that forms dS itself: X = (g, act) fused in COL mode, written out once for sdp_scores_bwd_x_kernel (which
+// then runs after it); sg0 / sg1 = -1 for (g_theta, theta), +1 for (g_A, A)
+extern "C" __global__ void __launch_bounds__(512)
+sdp_scores_bwd_yf_kernel(const float *g0, const float *g1, const float *act0, const float *act1, float sg0, float sg1, const float *x0, const float *x1,
+                         float *ds0, float *ds1, float *c0, float *c1, int B, int N, int M, int D)
+{
+    using namespace sdp;
+    const TileId tile = xcd_tile();
+    const int kind = tile.z >= B;
+    const int b = kind ? tile.z - B : tile.z;
+    const XwOperand X = {(kind ? g1 : g0) + (size_t)b * N * M, M, M, (kind ? act1 : act0) + (size_t)b * N * M, kind ? sg1 : sg0};
+    const XwOperand Y = {(kind ? x1 : x0) + (size_t)b * N * D, D, D};
+    xw_gemm<true, true, false, true>(X, Y, N, (kind ? c1 : c0) + (size_t)b * M * D, tile.y * XW_TILE, tile.x * XW_TILE, kind,
+                                     (kind ? ds1 : ds0) + (size_t)b * N * M);
 }
 
 extern "C" __global__ void __launch_bounds__(512)

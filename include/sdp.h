@@ -134,10 +134,10 @@ int sdp_scores_f32(const float *zx, const float *zy, const float *gx, const floa
 
 /* Backward of sdp_scores_f32: the gradients of the embeddings from the gradients of theta and A (the reference gets them
  * from autograd through its two einsums and activations, alignment.py:122-123).  With dS = g * d act / ds formed from the
- * saved OUTPUTS -- g_theta * (1 - exp(-theta)), g_A * (1 - exp(A)) -- into `ws` (sdp_scores_backward_ws_bytes; caller-owned
- * scratch):  dzx[b,i,:] = sum_j dS_theta[b,i,j] zy[b,j,:],  dzy[b,j,:] = sum_i dS_theta[b,i,j] zx[b,i,:], and dgx, dgy
- * from (dS_A, gy, gx).  The same three-piece bf16 product as the forward (fp32 accuracy), 256 x 256 tiles, one launch per
- * side for both tensors.  (g_A, A, gx, gy, dgx, dgy) may be NULL together (theta only), likewise the theta group.
+ * saved OUTPUTS -- g_theta * (1 - exp(-theta)), g_A * (1 - exp(A)):  dzx[b,i,:] = sum_j dS_theta[b,i,j] zy[b,j,:],
+ * dzy[b,j,:] = sum_i dS_theta[b,i,j] zx[b,i,:], and dgx, dgy from (dS_A, gy, gx).  The same three-piece bf16 product as the
+ * forward (fp32 accuracy), 256 x 256 tiles, one launch per side for both tensors: the dzy / dgy product forms dS on its way
+ * into LDS and leaves a copy in `ws` (sdp_scores_backward_ws_bytes; caller-owned scratch) for the dzx / dgx product.  (g_A, A, gx, gy, dgx, dgy) may be NULL together (theta only), likewise the theta group.
  * Needs M and D multiples of 4 and 16-byte aligned tensors: otherwise SDP_E_SHAPE (the Python layer then uses
  * torch.bmm).  Inputs must be finite. */
 size_t sdp_scores_backward_ws_bytes(int B, int N, int M);
@@ -239,7 +239,8 @@ int sdp_plan_parts(int pass, int B, int N, int M, int has_lens, int exact_state,
 /* Only in libraries built with -DSDP_EXPERIMENTS (never the shipped one): timing experiments that produce WRONG
  * results.  bit0/1/2: inputs / outputs / state of every pair alias pair 0 (all traffic cache-served); bit3: strips
  * never publish their progress, so every hand-off times out (tests the SDP_E_HANDOFF path); 16 / 32: scores kernel choice;
- * 64: never spread a pair over several workgroups (128 / 256: not in the backward / forward sweep); 512: wherever possible.  Returns the old mask. */
+ * 64: never spread a pair over several workgroups (128 / 256: not in the backward / forward sweep); 512: wherever possible;
+ * 2048: backward of the scores with dS in a pass of its own.  Returns the old mask. */
 int sdp_set_debug(int mask);
 /* Cycle stamps of the forward sweep (tools/fwd_trace.py): a device buffer of >= 40 KiB, or NULL to switch it off. */
 int sdp_set_trace(void *buf);

@@ -25,3 +25,17 @@ from deepblast_amd import scores as sc
 nb = lambda: sc._native_backward(zx, zy, gx, gy, theta, A, g1, g2)
 print(f"native backward (sdp_scores_backward_f32, both tensors): {t(nb):8.1f} us")
 print(f"library backward (torch expm1 / mul / 4 x bmm)          : {t(lambda: sc._torch_backward(zx, zy, gx, gy, theta, A, g1, g2)):8.1f} us")
+exp = gpu_tune.load(os.path.join(ROOT, "deepblast_amd", "libsdp_hip_exp.so"))
+ws = torch.empty(exp.sdp_scores_backward_ws_bytes(B, N, M) // 4, device="cuda")
+outs = [torch.empty_like(x) for x in (zx, zy, gx, gy)]
+stream = torch.cuda.current_stream().cuda_stream
+call = lambda: exp.sdp_scores_backward_f32(g1.data_ptr(), g2.data_ptr(), theta.data_ptr(), A.data_ptr(), zx.data_ptr(), zy.data_ptr(), gx.data_ptr(), gy.data_ptr(),
+                                           ws.data_ptr(), *[o.data_ptr() for o in outs], B, N, M, D, 0, stream)
+res = {}
+for mask, name in ((0, "dS formed inside the dzy / dgy product"), (2048, "dS in a pass of its own")):
+    gpu_tune.set_debug(exp, mask)
+    assert call() == 0
+    print(f"experiments build, {name:40s}: {t(call):8.1f} us")
+    res[mask] = [o.clone() for o in outs]
+gpu_tune.set_debug(exp, 0)
+print("max |difference| between the two:", [float((x - y).abs().max()) for x, y in zip(res[0], res[2048])])
