@@ -45,7 +45,7 @@ for name, pattern in (("kernel_stats.csv", "prof/**/*kernel_stats.csv"), ("train
                       ("configs.txt", "configs.txt"), ("parts_configs2.txt", "parts_configs2.txt"),
                       ("ubench_mix.txt", "ubench_mix.txt"), ("ubench_mix2.txt", "ubench_mix2.txt"),
                       ("pytest_multigpu.txt", "pytest_multigpu.txt"), ("multigpu_skipped.txt", "multigpu_skipped.txt"),
-                      ("pytest_gpu.txt", "pytest_gpu.txt"), ("smoke.txt", "smoke.txt"), ("fuzz2.txt", "fuzz2.txt")):
+                      ("pytest_gpu.txt", "pytest_gpu.txt"), ("smoke.txt", "smoke.txt"), ("fuzz2.txt", "fuzz2.txt"), ("parts_fuzz.txt", "parts_fuzz.txt")):
     f = first(pattern)
     if f:
         out = os.path.join(dst, f"{tag}_{name}")

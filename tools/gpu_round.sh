@@ -16,6 +16,8 @@ if [ "$2" != "quick" ]; then
   # the harsher fuzz (steep / flat scores, forbidden gaps, tiny and thin shapes, many pairs, per-pair lengths): the
   # suite did not catch the one kernel bug of round 2, this did
   timeout 900 python tools/fuzz2.py 300 2>&1 | tail -4 | tee $OUT/fuzz2.txt
+  # the schedule that spreads a pair over several workgroups, forced on over random shapes / lengths: bit-identical to one workgroup per pair
+  timeout 900 python tools/parts_fuzz.py 150 2>&1 | grep -v amdgpu | tail -6 | tee $OUT/parts_fuzz.txt
 fi
 # multi-GPU dry run: the 2-rank RCCL tests and bench.py --gpus 2/4/8 in one go wherever more than one GPU is visible
 NGPU=$(python -c "import torch; print(torch.cuda.device_count())")
