@@ -151,6 +151,7 @@ def spawn_ranks(args):
 
 def main():
     args = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL between ranks); before the first device call
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback)"
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return spawn_ranks(args)   # `python bench.py --gpus N`: create the N ranks ourselves
