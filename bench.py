@@ -151,7 +151,10 @@ def spawn_ranks(args):
 
 def main():
     args = parse()
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL between ranks); before the first device call
+    # RCCL exchanges buffer handles between the ranks of a node through HIP IPC, and the host driver of this fleet only
+    # supports the dmabuf kind: with the legacy mode ncclCommInit / the first collective fails with
+    # "hipIpcGetMemHandle: invalid argument".  Must be set before the first device call; a caller's own setting wins.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback)"
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return spawn_ranks(args)   # `python bench.py --gpus N`: create the N ranks ourselves
@@ -189,7 +192,10 @@ def main():
     A = torch.from_numpy(A_np).to(dev)
     Zl = torch.from_numpy(datagen.normal(7, (B, N, M))).to(dev) if args.mode == "train" else None
     dec = (NeedlemanWunschDecoder if args.variant == "nw" else SmithWatermanDecoder)("softmax")
-    aligner = ShardedAligner(dec, gather=args.gather if world > 1 else "none", e_chunks=args.e_chunks)
+    # the headline step is the metric's own idiom, literally: Vt = dec(theta, A); Vt.sum().backward(); the
+    # same sweeps with the cotangent handed to torch.autograd.grad directly are reported next to it (`direct_cotangent`)
+    aligner = ShardedAligner(dec, gather=args.gather if world > 1 else "none", e_chunks=args.e_chunks,
+                             idiom="sum_backward" if args.mode == "fwdbwd" else "grad")
     eng = get_engine()
     timer = KernelTimer()
     eng.launch_hook = None if os.environ.get("BENCH_NO_KERNEL_EVENTS") else timer   # (experiment: cost of the event pairs)
@@ -223,7 +229,7 @@ def main():
             th, ga = alignment_scores(*emb)     # one MFMA launch: both GEMMs + softplus / logsigmoid
             return aligner.align(th, ga)["E_local"]
         if args.mode == "fwdbwd":
-            out = aligner.align(theta, A)      # Vt = dec(theta, A); dVt.sum()/dtheta; all-gather Vt
+            out = aligner.align(theta, A)      # Vt = dec(theta, A); Vt.sum().backward(); all-gather Vt under the backward sweep
             return out["E_local"]
         if args.mode == "align+traceback":     # inference: the alignment matrix and its arg-max walk (alignment.py:165-170, batched)
             out = aligner.align(theta, A)
@@ -270,7 +276,7 @@ def main():
     value = world * per_step_updates * args.steps / elapsed
     ms = timer.means_ms()
 
-    def emit(e_gather, e_gather_one, paths_gather):
+    def emit(e_gather, e_gather_one, paths_gather, direct=None):
         """rank 0: the ONE JSON line (called once: after the secondary measurements, or by the watchdog below)."""
         if rank == 0:
             # dominant kernel of THIS mode = the sweep / GEMM with the longest mean launch; its algorithmic bytes per cell
@@ -365,6 +371,12 @@ def main():
                                                  "F.logsigmoid(torch.einsum(...gx, gy)) (deepblast/alignment.py:122-123), fp32, this box"}
             if line["roofline"] is None:
                 line["roofline"] = line.get("scores_roofline")
+            if args.mode == "fwdbwd":
+                line["config"]["step"] = "Vt = dec(theta, A); Vt.sum().backward()  (public API, autograd, .grad accumulation included)"
+            if direct is not None:
+                # the same two sweeps asked for with torch.autograd.grad(Vt, theta, ones): no sum / fill kernels, no .grad
+                line["direct_cotangent"] = {"ms_per_step": direct * 1e3, "value": world * per_step_updates / direct,
+                                            "step": "Vt = dec(theta, A); torch.autograd.grad(Vt, theta, ones)"}
             if e_gather is not None:
                 line["with_e_gather"] = {"ms_per_step": e_gather * 1e3, "value": world * per_step_updates / e_gather,
                                          "bytes_into_each_gpu": (world - 1) * B * N * M * 4,
@@ -386,10 +398,13 @@ def main():
     e_gather = e_gather_one = None
     # (a secondary figure must not cost the primary one: an error here -- the same on every rank, e.g. out of memory for
     # the gathered E -- is reported on stderr and the line goes out without that field)
-    def secondary(kind, e_chunks=None):
+    def secondary(kind, e_chunks=None, idiom=None):
         try:
             aligner.gather = kind
             aligner.e_chunks = args.e_chunks if e_chunks is None else e_chunks
+            aligner.idiom = idiom or aligner.idiom
+            if os.environ.get("BENCH_TEST_HANG_RANK") == str(rank):   # test hook: this rank never reaches the collective
+                time.sleep(3600)
             step()
             dt_s, _ = timed(min(args.steps, 5))
             return dt_s / min(args.steps, 5)
@@ -399,6 +414,7 @@ def main():
         finally:
             aligner.gather = args.gather
             aligner.e_chunks = args.e_chunks
+            aligner.idiom = "sum_backward" if args.mode == "fwdbwd" else "grad"
 
     # A secondary figure must not cost the primary one either by HANGING: a rank that fails alone leaves the others
     # inside a collective.  A watchdog on every rank lets rank 0 print the line without the secondary fields and ends the
@@ -410,13 +426,18 @@ def main():
         print(f"[bench] rank {rank}: secondary measurements did not finish in time: the line goes out without them", file=sys.stderr, flush=True)
         if emitted.acquire(blocking=False):
             emit(None, None, None)
+        sys.stdout.flush()
         os._exit(0)
 
     dog = None
     if world > 1 and args.mode == "fwdbwd" and not os.environ.get("BENCH_NO_SECONDARY"):
-        dog = threading.Timer(max(60.0, 200.0 * elapsed), watchdog)
+        # (BENCH_WATCHDOG_S: test hook, tests/test_multirank_one_gpu.py fires the watchdog on purpose)
+        dog = threading.Timer(float(os.environ.get("BENCH_WATCHDOG_S") or max(60.0, 200.0 * elapsed)), watchdog)
         dog.daemon = True
         dog.start()
+    direct = None
+    if args.mode == "fwdbwd" and not os.environ.get("BENCH_NO_SECONDARY"):
+        direct = secondary(args.gather if world > 1 else "none", idiom="grad")
     if world > 1 and args.mode == "fwdbwd" and args.gather != "e" and not os.environ.get("BENCH_NO_SECONDARY"):
         e_gather = secondary("e")                 # backward sweep + gather in --e-chunks pieces
         e_gather_one = secondary("e", e_chunks=1) if args.e_chunks > 1 else None   # one collective after the sweep
@@ -428,7 +449,7 @@ def main():
     if dog is not None:
         dog.cancel()
     if emitted.acquire(blocking=False):
-        emit(e_gather, e_gather_one, paths_gather)
+        emit(e_gather, e_gather_one, paths_gather, direct)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

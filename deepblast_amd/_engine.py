@@ -28,6 +28,7 @@ def _ptr(t):
 
 
 EXACT_STATE = 0x100  # include/sdp.h: SDP_EXACT_STATE
+ET_BROADCAST = 0x200  # include/sdp.h: SDP_ET_BROADCAST
 TRACEBACK_RULES = {"cpu": 0, "cuda": 1}  # include/sdp.h: SDP_TRACEBACK_CPU / SDP_TRACEBACK_CUDA
 
 
@@ -124,9 +125,8 @@ class HipEngine:
         return Vt, state
 
     def state_pair_bytes(self, N, M, exact_state=False):
-        """Bytes one pair occupies in the (contiguous) state buffer: pair b's records start b times this into it."""
-        f = self.lib.sdp_state_d_bytes if exact_state else self.lib.sdp_state_bytes
-        return f(2, N, M) - f(1, N, M)
+        """Bytes between the records of consecutive pairs in the state buffer (include/sdp.h: sdp_state_pair_stride)."""
+        return self.lib.sdp_state_pair_stride(N, M, 1 if exact_state else 0)
 
     def backward(self, Et, state, shape, variant, lens=None, exact_state=False, pair_range=None, out=None):
         """-> E (B,N,M).  Replaces _backward_pass_kernel (nw_cuda.py:98-102).
@@ -134,33 +134,42 @@ class HipEngine:
         exact_state: `state` came from forward(..., exact_state=True).
         pair_range=(lo, hi), out=(B,N,M) tensor: sweep only pairs lo..hi-1 of the batch, writing out[lo:hi] (the
         other rows of `out` are not touched) -- the backward sweep of a batch in pieces, so that a collective on
-        piece k can run under the sweep of piece k+1 (distributed.py).  Needs lens=None (a pair's state is then
-        a fixed-size contiguous record, and there is no launch order in the buffer's tail)."""
+        piece k can run under the sweep of piece k+1 (distributed.py).  Needs lens=None.  The library finds the
+        pairs' records in `state` itself (sdp_backward_range_f32 takes the whole batch's buffers and the range)."""
         dev = self._dev(state)
         B, N, M = shape
         if Et.device != state.device:
             raise ValueError(f"Et is on {Et.device}, expected {state.device}")
-        Et = Et.to(torch.float32).expand(B).contiguous()
+        Et, bcast = self._et(Et, B)
         lens = self._lens(lens, B, state.device)
         E = torch.empty((B, N, M), dtype=torch.float32, device=state.device) if out is None else out
         if tuple(E.shape) != (B, N, M) or E.dtype != torch.float32 or not E.is_contiguous() or E.device != state.device:
             raise ValueError("out must be a contiguous float32 (B, N, M) tensor on the state's device")
-        lo, hi = (0, B) if pair_range is None else pair_range
-        if pair_range is not None:
-            if lens is not None:
-                raise ValueError("pair_range needs lens=None")
-            if not (0 <= lo < hi <= B):
-                raise ValueError(f"pair_range {pair_range} outside the batch of {B}")
-        st_ptr = state.data_ptr() + lo * self.state_pair_bytes(N, M, exact_state or self._always_exact(N, M))
+        v = self._v(1, variant) | (EXACT_STATE if exact_state else 0) | (ET_BROADCAST if bcast else 0)
         with torch.cuda.device(dev), self._bracket("sdp_bwd_kernel"):
-            rc = self.lib.sdp_backward_f32(Et.data_ptr() + 4 * lo, st_ptr, E.data_ptr() + 4 * lo * N * M, hi - lo, N, M, _ptr(lens),
-                                           self._v(1, variant) | (EXACT_STATE if exact_state else 0), dev, self._stream(dev))
+            if pair_range is None:
+                rc = self.lib.sdp_backward_f32(_ptr(Et), _ptr(state), _ptr(E), B, N, M, _ptr(lens), v, dev, self._stream(dev))
+            else:
+                lo, hi = pair_range
+                if lens is not None:
+                    raise ValueError("pair_range needs lens=None")
+                if not (0 <= lo < hi <= B):
+                    raise ValueError(f"pair_range {pair_range} outside the batch of {B}")
+                rc = self.lib.sdp_backward_range_f32(_ptr(Et), _ptr(state), _ptr(E), B, N, M, lo, hi - lo, v, dev, self._stream(dev))
         _lib.check(rc, "sdp_backward_f32")
         return E
 
-    def _always_exact(self, N, M):
-        """Problems beyond the packed state's path-length limit use the float2 state whatever the flag (include/sdp.h)."""
-        return self.lib.sdp_state_bytes(1, N, M) == self.lib.sdp_state_d_bytes(1, N, M)
+    @staticmethod
+    def _et(Et, B):
+        """-> (tensor whose data_ptr the kernel reads, broadcast flag).  The usual (B,) fp32 contiguous cotangent goes as
+        it is.  A broadcast scalar -- what `Vt.sum().backward()` hands over: a stride-0 expand of one element -- goes as
+        that one element with SDP_ET_BROADCAST instead of being expanded into B floats by a kernel of its own."""
+        if Et.dtype == torch.float32 and Et.dim() <= 1:
+            if Et.numel() == 1 or (Et.shape == (B,) and Et.stride(0) == 0):
+                return Et, True
+            if Et.shape == (B,) and Et.is_contiguous():
+                return Et, False
+        return Et.to(torch.float32).expand(B).contiguous(), False
 
     def adjoint_forward(self, state, Ztheta, ZA, variant, lens=None):
         """-> (Vtd (B,), state_d).  Replaces _adjoint_forward_pass_kernel (nw_cuda.py:134-139)."""

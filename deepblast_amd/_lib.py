@@ -28,6 +28,8 @@ SIGNATURES = {
                                        ctypes.c_int, _c_i32p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "sdp_backward_f32": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         _c_i32p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "sdp_state_pair_stride": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "sdp_backward_range_f32": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p] + [ctypes.c_int] * 7 + [ctypes.c_void_p]),
     "sdp_adjoint_forward_f32": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int, _c_i32p, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_void_p]),

@@ -311,7 +311,7 @@ unsigned long long *bridge_in_state(const void *state, int B, int N, int M, bool
 // flags or-ed into `variant` (include/sdp.h): SDP_EXACT_STATE, SDP_WAVES(w)
 struct VariantBits {
     int variant, waves;
-    bool exact;
+    bool exact, et_bcast;
 };
 // The packed state keeps two 24-bit weights per cell; a saturated weight that the forward sweep leaves one step
 // below 1 costs 1.7e-8 of E on average, which stays inside the 1e-4 parity bound up to ~5000 steps of a fully
@@ -325,8 +325,9 @@ VariantBits split_variant(int variant)
 {
     VariantBits v;
     v.exact = (variant & SDP_EXACT_STATE) != 0;
+    v.et_bcast = (variant & SDP_ET_BROADCAST) != 0;
     v.waves = (variant >> 12) & 0xf;
-    v.variant = variant & ~(SDP_EXACT_STATE | (0xf << 12));
+    v.variant = variant & ~(SDP_EXACT_STATE | SDP_ET_BROADCAST | (0xf << 12));
     return v;
 }
 
@@ -588,12 +589,44 @@ int sdp_backward_f32(const float *Et, const float *state, float *E, int B, int N
     if (int rc = check_shape(B, N, M, variant)) return rc;
     sdp::Params p = {};
     p.vin = Et;
+    p.vin_bcast = vb.et_bcast ? 1 : 0;
     p.qin = reinterpret_cast<const uint32_t *>(state);
     p.sout = E;
     p.lens = lens;
     p.B = B, p.N = N, p.M = M, p.variant = variant;
     if (lens != nullptr && B > num_cus(device)) p.order = order_in_state(state, B, N, M, exact);
     return launch(sdp::PASS_BWD, p, device, stream, exact, vb.waves, false, state);
+}
+
+size_t sdp_state_pair_stride(int N, int M, int exact_state)
+{
+    if (N <= 0 || M <= 0) return 0;
+    // the body of the state buffer is B equal records, one per pair: nstrips streams of tpad / 32 units
+    // (state_layout); order, bridge rows and dispatch map live behind the LAST pair's record, not between records
+    const size_t units = (size_t)sdp::state_nstrips(N) * (sdp::state_tpad(M) / sdp::STATE_UNIT_STEPS);
+    return units * (exact_for(exact_state != 0, N, M) ? sdp::STATE2_UNIT_BYTES : sdp::STATEQ_UNIT_BYTES);
+}
+
+int sdp_backward_range_f32(const float *Et, const float *state, float *E, int B, int N, int M, int first, int count,
+                           int variant, int device, void *stream)
+{
+    if (!Et || !state || !E) return fail(SDP_E_NULLPTR, "sdp_backward_range_f32: null pointer");
+    const VariantBits vb = split_variant(variant);
+    const bool exact = exact_for(vb.exact, N, M);
+    variant = vb.variant;
+    if (int rc = check_shape(B, N, M, variant)) return rc;
+    if (first < 0 || count <= 0 || first > B - count) return fail(SDP_E_SHAPE, "sdp_backward_range_f32: [first, first + count) is not inside the batch");
+    if (SDP_STATE_MARCH) return fail(SDP_E_SHAPE, "sdp_backward_range_f32: not available with the marching state layout");
+    sdp::Params p = {};
+    p.vin = vb.et_bcast ? Et : Et + first;
+    p.vin_bcast = vb.et_bcast ? 1 : 0;
+    p.qin = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(state) + (size_t)first * sdp_state_pair_stride(N, M, exact));
+    p.sout = E + (size_t)first * N * M;
+    p.B = count, p.N = N, p.M = M, p.variant = variant;
+    // state = nullptr: a launch over part of the batch never spreads pairs over several workgroups -- the bridge rows
+    // live behind the record of the batch's LAST pair, and located from a sub-range they would fall into the records of
+    // the pairs that follow it
+    return launch(sdp::PASS_BWD, p, device, stream, exact, vb.waves, false, nullptr);
 }
 
 int sdp_adjoint_forward_f32(const float *state, const float *Ztheta, const float *ZA, float *Vtd, float *state_d,

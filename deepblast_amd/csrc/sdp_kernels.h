@@ -93,6 +93,7 @@ struct Params {
     const float2 *din;   // skewed state in: Qd
     void *dout;          // skewed state out: Q (packed | float2) | Qd (float2)
     const float *vin;    // Et
+    int vin_bcast;       // backward sweep: Et is ONE float that applies to every pair (SDP_ET_BROADCAST)
     float *vout;         // Vt | Vtd
     const int32_t *lens; // (B,2) or null
     int B, N, M;

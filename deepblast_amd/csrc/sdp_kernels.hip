@@ -557,7 +557,7 @@ __device__ __forceinline__ void sweep(const Params &p)
     const int ld = p.M;
     const int lane_off = (r_l * ld + s_l - r_l) * 4;   // byte offset of this lane's element for k = 0, i0 = t0 = 0
 
-    const float et = (PASS == PASS_BWD) ? p.vin[b] : 0.f;
+    const float et = (PASS == PASS_BWD) ? p.vin[p.vin_bcast ? 0 : b] : 0.f;
     const float seed_scale = (PASS == PASS_AFWD && QX) ? p.vin[b] : 0.f;   // fused loss seed: per-pair factor of dLoss/dE
 
     for (int sidx = wave; sidx < nstrips_wg; sidx += W) {

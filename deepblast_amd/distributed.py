@@ -131,11 +131,17 @@ class ShardedAligner:
               1 = one collective after the whole sweep.  `out["e_overlap"]` says which happened ("chunked" / "none").
     """
 
-    def __init__(self, decoder, group=None, gather="vt", async_e=False, e_chunks=1):
+    def __init__(self, decoder, group=None, gather="vt", async_e=False, e_chunks=1, idiom="grad"):
         if gather not in ("vt", "e", "paths", "none"):
             raise ValueError("gather must be 'vt', 'e', 'paths' or 'none'")
         if int(e_chunks) < 1:
             raise ValueError("e_chunks must be >= 1")
+        if idiom not in ("grad", "sum_backward"):
+            raise ValueError("idiom must be 'grad' or 'sum_backward'")
+        # how E = dVt.sum()/dtheta is asked for: "grad" hands autograd a cached (B,) cotangent of ones
+        # (torch.autograd.grad: no reduction kernel, no .grad accumulation); "sum_backward" is the reference user's own
+        # two lines, `Vt = dec(theta, A); Vt.sum().backward()` (SURVEY 8d: the idiom the headline metric is defined on)
+        self.idiom = idiom
         self.decoder = decoder
         self.group = group
         self.gather = gather
@@ -148,7 +154,8 @@ class ShardedAligner:
 
     def align(self, theta, A, lengths=None, plan=None):
         """theta, A: this rank's (B_local, N, M) shard.  Every rank must hold the same B_local -- the all-gather
-        is a single fixed-size collective (use `pad_shard` or a BalancedPlan, which pads by itself).
+        is a single fixed-size collective (use `pad_shard` or a BalancedPlan, which pads by itself); with e_chunks > 1
+        the number of collectives follows from B_local too, so unequal shards would not only gather garbage but hang.
 
         lengths : (B_local, 2) per-pair sizes of a padded shard (lengths-aware decode), or None.
         plan    : a BalancedPlan; theta/A/lengths are then this rank's `plan.indices(rank)` pairs (in that order),
@@ -167,21 +174,26 @@ class ShardedAligner:
             return self._align_chunked_e(theta.detach(), A.detach(), n_real)
         theta = theta.detach().requires_grad_(True)
         Vt = self.decoder(theta, A, lengths) if lengths is not None else self.decoder(theta, A)
-        # dVt.sum()/dtheta with the cotangent handed over directly: no reduction kernel and no expand/copy of
-        # its gradient on the way to the backward sweep
-        if self._ones is None or self._ones.shape != Vt.shape or self._ones.device != Vt.device:
+        # idiom "grad": dVt.sum()/dtheta with the cotangent handed over directly -- no reduction kernel, no fill
+        if self.idiom == "grad" and (self._ones is None or self._ones.shape != Vt.shape or self._ones.device != Vt.device):
             self._ones = torch.ones_like(Vt)
         pending = None
         if gathering:
             # the scores are final after the forward sweep: their all-gather (RCCL's own stream) runs while the
             # backward sweep computes E
             pending = _all_gather_cat(Vt.detach(), self.group, async_op=True)
-        (E,) = torch.autograd.grad(Vt, theta, grad_outputs=self._ones)
+        if self.idiom == "sum_backward":
+            Vt.sum().backward()
+            E = theta.grad
+        else:
+            (E,) = torch.autograd.grad(Vt, theta, grad_outputs=self._ones)
         out = {"Vt_local": Vt.detach()[:n_real], "E_local": E[:n_real], "Vt": None, "E": None, "paths": None, "e_overlap": "none"}
         if gathering:
             if self.gather == "paths":
                 from . import _engine
-                states, counts = _engine.get_engine().traceback(E, lengths)
+                # the walk rule is the decoder's (Decoder(operator, traceback_rule=...)): the gathered walks must be the
+                # ones decoder.traceback_batch would return for the same matrices
+                states, counts = _engine.get_engine().traceback(E, lengths, rule=getattr(self.decoder, "traceback_rule", "cpu"))
                 packed = pack_paths(states, counts, theta.shape[2])
                 got = PendingGather(*_all_gather_cat(packed, self.group, async_op=True), plan=plan)
             out["Vt"] = PendingGather(*pending, plan=plan).wait()
@@ -198,14 +210,15 @@ class ShardedAligner:
         like the one-collective gather's ((world * B_local, N, M)); this rank's sweep writes its pieces straight into
         its own rows of that tensor, and each piece's all-gather fills the same rows of the other ranks' blocks (the
         collective's output list are views of the result: no staging copy on our side)."""
-        from . import _engine
+        from . import _dp, _engine
         from .sw import SmithWatermanDecoder
+        # this path calls the engine directly, so it repeats what decoder.forward checks on the way in (operator, dtype,
+        # A's shape and device: the kernels take B, N, M from theta and read A through a raw pointer)
+        _dp._validate(theta, A, getattr(self.decoder, "operator", "softmax"), False)
         eng = _engine.get_engine()
         variant = _engine.SW if isinstance(self.decoder, SmithWatermanDecoder) else _engine.NW
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         Bl, N, M = theta.shape
-        if getattr(self.decoder, "operator", "softmax") != "softmax":
-            raise NotImplementedError("only the softmax operator is implemented (as in the reference's batched path)")
         Vt, state = eng.forward(theta, A, variant)     # the same two sweeps decoder(theta, A) + autograd.grad launch
         vt_pending = _all_gather_cat(Vt, self.group, async_op=True)
         if self._ones is None or self._ones.shape != Vt.shape or self._ones.device != Vt.device:

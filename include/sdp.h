@@ -64,7 +64,7 @@
 extern "C" {
 #endif
 
-#define SDP_VERSION 102 /* 0.1.1: + sdp_init, sdp_traceback_rule_i32 */
+#define SDP_VERSION 103 /* 0.1.2: + sdp_backward_range_f32, sdp_state_pair_stride */
 
 #define SDP_NW 0
 #define SDP_SW 1
@@ -74,6 +74,11 @@ extern "C" {
  * decode() + loss.backward()) runs forward and backward with the flag and shares the one state; a caller that
  * only needs E (inference) uses the default compact state, which the backward sweep reads faster. */
 #define SDP_EXACT_STATE 0x100
+
+/* or-ed into `variant` of sdp_backward_f32 / sdp_backward_range_f32: `Et` points at ONE float that applies to every
+ * pair -- the cotangent `Vt.sum().backward()` hands over is a broadcast scalar, and expanding it into (B,) floats first
+ * would be a kernel launch of its own between the two sweeps. */
+#define SDP_ET_BROADCAST 0x200
 
 #define SDP_E_NULLPTR (-1)  /* a required pointer is NULL */
 #define SDP_E_SHAPE (-2)    /* B, N or M non-positive */
@@ -107,6 +112,18 @@ int sdp_forward_f32(const float *theta, const float *A, float *state, float *Vt,
 /* E = dVt/dtheta * Et  (expected alignment matrix), from the saved state. */
 int sdp_backward_f32(const float *Et, const float *state, float *E, int B, int N, int M,
                      const int32_t *lens, int variant, int device, void *stream);
+
+/* The backward sweep over pairs first .. first + count - 1 of the batch only: Et, state and E are the WHOLE batch's
+ * buffers (B pairs, no per-pair lengths), E[first .. first + count) is written and nothing else is touched.  Bit-identical
+ * to the same rows of one sdp_backward_f32 over the batch.  For callers that hand E on in pieces -- the chunked all-gather
+ * of deepblast_amd/distributed.py: the collective on piece k runs under the sweep of piece k + 1.  The library
+ * locates a pair's records itself (sdp_state_pair_stride: bytes between the records of consecutive pairs in `state`, for
+ * callers that want to know -- NOT sdp_state_bytes(2) - sdp_state_bytes(1), which also counts the per-pair share of the
+ * buffer's tail); launches over part of a batch never spread a pair over several workgroups (sdp_plan_parts), whose
+ * bridge rows live in that tail.  variant: SDP_NW / SDP_SW, | SDP_EXACT_STATE as for sdp_backward_f32, | SDP_WAVES(w). */
+size_t sdp_state_pair_stride(int N, int M, int exact_state);
+int sdp_backward_range_f32(const float *Et, const float *state, float *E, int B, int N, int M, int first, int count,
+                           int variant, int device, void *stream);
 
 /* Directional derivative through the DP: Vtd (B,), state_d <- Qd.  ZA may be NULL (= zeros).
  * `state` must come from sdp_forward_f32(..., variant | SDP_EXACT_STATE, ...). */

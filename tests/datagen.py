@@ -19,11 +19,12 @@ def _splitmix64(x):
     return z ^ (z >> np.uint64(31))
 
 
-def uniform(seed, shape, dtype=np.float32):
-    """U[0,1) with 24 random bits per element (exact in float32)."""
+def uniform(seed, shape, dtype=np.float32, offset=0):
+    """U[0,1) with 24 random bits per element (exact in float32).  `offset`: first element of the stream to take --
+    uniform(s, (hi - lo,) + tail, offset=lo * prod(tail)) is rows lo..hi-1 of uniform(s, (B,) + tail)."""
     n = int(np.prod(shape))
     with np.errstate(over="ignore"):
-        k = np.arange(n, dtype=np.uint64) + (np.uint64(seed) << np.uint64(32))
+        k = np.arange(n, dtype=np.uint64) + np.uint64(offset) + (np.uint64(seed) << np.uint64(32))
         bits = _splitmix64(k) >> np.uint64(40)
     return (bits.astype(np.float64) * (1.0 / (1 << 24))).astype(dtype).reshape(shape)
 
@@ -34,9 +35,11 @@ def normal(seed, shape, dtype=np.float32):
     return ((u - 2.0) * np.sqrt(3.0)).astype(dtype)
 
 
-def theta_A(seed, B, N, M, dtype=np.float32):
-    theta = uniform(2 * seed, (B, N, M), dtype)
-    A = (-uniform(2 * seed + 1, (B, N, M), dtype)).astype(dtype)
+def theta_A(seed, B, N, M, dtype=np.float32, rows=None):
+    """rows=(lo, hi): only pairs lo..hi-1 of the (B, N, M) batch (a rank's shard, without generating the rest)."""
+    lo, hi = (0, B) if rows is None else rows
+    theta = uniform(2 * seed, (hi - lo, N, M), dtype, offset=lo * N * M)
+    A = (-uniform(2 * seed + 1, (hi - lo, N, M), dtype, offset=lo * N * M)).astype(dtype)
     return theta, A
 
 

@@ -88,7 +88,7 @@ class OracleEngine:
             Ed[b, :n, :m] = ed[0, 1:-1, 1:-1]
         return torch.from_numpy(Ed)
 
-    def traceback(self, grad, lens=None):
+    def traceback(self, grad, lens=None, rule="cpu"):
         """Per-pair host walks (deepblast_amd/_dp.py::traceback) in the device kernel's output format."""
         from deepblast_amd._dp import traceback
         g = self._np(grad)
@@ -98,7 +98,7 @@ class OracleEngine:
         counts = np.zeros(B, np.int32)
         for b, (n, m) in enumerate(self._slices(B, N, M, lens)):
             try:
-                path = traceback(g[b, :n, :m])
+                path = traceback(g[b, :n, :m], rule=rule)
             except IndexError:
                 counts[b] = -1
                 continue

@@ -153,7 +153,7 @@ def test_balanced_plan_world2_restores_batch_order(tmp_path):
     assert sorted(seen) == list(range(7))
 
 
-def _worker_paths(rank, world, port, outdir):
+def _worker_paths(rank, world, port, outdir, rule="cpu"):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "tests")):
         if p not in sys.path:
@@ -164,38 +164,49 @@ def _worker_paths(rank, world, port, outdir):
     from deepblast_amd import _engine, NeedlemanWunschDecoder
     from deepblast_amd.distributed import BalancedPlan, ShardedAligner
     from fake_engine import OracleEngine
-    _engine._ENGINE = OracleEngine()
+    seen = []
+
+    class Recording(OracleEngine):
+        def traceback(self, grad, lens=None, rule="cpu"):
+            seen.append(rule)
+            return super().traceback(grad, lens, rule)
+    _engine._ENGINE = Recording()
     B, N, M = 7, 30, 26
     theta, A = datagen.theta_A(45, B, N, M)
     theta = (theta * 6).astype(np.float32)   # peaked alignments: the walk follows a real path
     lens = datagen.lengths(46, B, 3, 26)
     plan = BalancedPlan(lens, world)
     mine = plan.indices(rank)
-    al = ShardedAligner(NeedlemanWunschDecoder("softmax"), gather="paths")
+    al = ShardedAligner(NeedlemanWunschDecoder("softmax", traceback_rule=rule), gather="paths")
     out = al.align(torch.from_numpy(theta[mine]), torch.from_numpy(A[mine]), torch.from_numpy(lens[mine]), plan=plan)
     states, counts = out["paths"]
-    np.savez(os.path.join(outdir, f"r{rank}.npz"), states=states.numpy(), counts=counts.numpy(), Vt=out["Vt"].numpy())
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), states=states.numpy(), counts=counts.numpy(), Vt=out["Vt"].numpy(), rules=np.array(seen))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gathered_paths_world2_match_per_pair_tracebacks(tmp_path):
+@pytest.mark.parametrize("rule", ["cpu", "cuda"])
+def test_gathered_paths_world2_match_per_pair_tracebacks(tmp_path, rule):
     """gather="paths": every rank ends up with the traceback of every pair, in batch order, equal to the reference's
-    per-item decode + traceback (alignment.py:165-170) -- (N+M+2) int32 per pair over the wire instead of N x M floats."""
+    per-item decode + traceback (alignment.py:165-170) -- (N+M+2) int32 per pair over the wire instead of N x M floats.
+    The walk is the DECODER's rule (traceback_rule="cuda": nw_cuda.py:273-317, stop as soon as one neighbour is off the
+    matrix).  On alignment matrices the two rules give the same list whenever the CPU rule's walk stays on the matrix, so
+    the test also checks which rule the engine was asked for."""
     import parity
     from deepblast_amd._dp import traceback
     world = 2
-    mp.spawn(_worker_paths, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_paths, args=(world, _free_port(), str(tmp_path), rule), nprocs=world, join=True)
     theta, A = datagen.theta_A(45, 7, 30, 26)
     theta = (theta * 6).astype(np.float32)
     lens = datagen.lengths(46, 7, 3, 26)
     ref = parity.oracle_lens(theta, A, None, None, 0, lens)
     for r in range(world):
         d = np.load(tmp_path / f"r{r}.npz")
+        assert d["rules"].tolist() == [rule]
         assert d["states"].shape == (7, 30 + 26 + 2, 3) and np.array_equal(d["Vt"], ref["Vt"])
         for b in range(7):
             n, m = lens[b]
-            want = traceback(ref["E"][b, :n, :m])
+            want = traceback(ref["E"][b, :n, :m], rule=rule)
             assert d["counts"][b] == len(want)
             assert [tuple(int(v) for v in row) for row in d["states"][b, :len(want)]] == want
 

@@ -144,25 +144,55 @@ def test_gathered_paths_two_ranks_rccl(tmp_path):
     _check_paths(tmp_path, 2)
 
 
-def test_backward_sweep_in_pieces_is_bit_identical():
-    """The backward sweep of a batch launched in pieces (HipEngine.backward(pair_range=, out=): what the chunked E
-    gather does) writes exactly what one launch writes, packed and exact state, and leaves the other rows alone."""
+@pytest.mark.parametrize("B,N,M,pieces", [(37, 130, 200, ((0, 5), (5, 6), (6, 30))),
+                                          (12, 512, 512, ((0, 3), (3, 4), (4, 11))),       # N > 256: a pair's share of the buffer's TAIL (bridge rows) is not part of its record
+                                          (16, 1024, 1024, ((0, 4), (4, 8), (8, 12), (12, 16))),   # the whole-batch launch spreads pairs over workgroups, the pieces must not
+                                          (5, 1100, 300, ((0, 2), (2, 5)))])
+def test_backward_sweep_in_pieces_is_bit_identical(B, N, M, pieces):
+    """The backward sweep of a batch launched in pieces (HipEngine.backward(pair_range=, out=) -> sdp_backward_range_f32:
+    what the chunked E gather does) writes exactly what one launch writes, packed and exact state, leaves the other rows
+    alone -- and leaves the STATE alone: a second whole-batch sweep after the pieces still gives the same E (round 3
+    located the pieces' records by sdp_state_bytes(2) - sdp_state_bytes(1), 5440 bytes per pair off at 512 x 512, and a
+    piece that chose the several-workgroups schedule reset "its" bridge rows inside the next pairs' records)."""
     from deepblast_amd._engine import get_engine
     eng = get_engine()
-    B, N, M = 37, 130, 200
     theta, A = datagen.theta_A(49, B, N, M)
     t, a = torch.from_numpy(theta).cuda(), torch.from_numpy(A).cuda()
     et = torch.from_numpy((0.5 + datagen.uniform(50, (B,))).astype(np.float32)).cuda()
+    covered = max(hi for _, hi in pieces)
     for exact in (False, True):
         for variant in (0, 1):
             Vt, Q = eng.forward(t, a, variant, exact_state=exact)
             whole = eng.backward(et, Q, (B, N, M), variant, exact_state=exact)
             out = torch.full((B, N, M), -7.0, device="cuda")
-            for lo, hi in ((0, 5), (5, 6), (6, 30)):
+            for lo, hi in pieces:
                 eng.backward(et, Q, (B, N, M), variant, exact_state=exact, pair_range=(lo, hi), out=out)
-            assert torch.equal(out[:30], whole[:30]) and bool((out[30:] == -7.0).all())
+            assert torch.equal(out[:covered], whole[:covered]) and bool((out[covered:] == -7.0).all())
+            assert torch.equal(eng.backward(et, Q, (B, N, M), variant, exact_state=exact), whole)
+    assert eng.state_pair_bytes(N, M) * B <= eng.lib.sdp_state_bytes(B, N, M)
     with pytest.raises(ValueError):
         eng.backward(et, Q, (B, N, M), 0, lens=torch.ones(B, 2, dtype=torch.int32, device="cuda"), pair_range=(0, 2), out=out)
+    with pytest.raises(ValueError):
+        eng.backward(et, Q, (B, N, M), 0, pair_range=(B - 1, B + 1), out=out)
+
+
+def test_broadcast_cotangent_equals_expanded():
+    """SDP_ET_BROADCAST: a one-element Et (what Vt.sum().backward() hands over, as a stride-0 view) gives the same E as the
+    expanded (B,) tensor, without the expand-and-copy kernel in between."""
+    from deepblast_amd._engine import get_engine
+    eng = get_engine()
+    B, N, M = 9, 70, 130
+    theta, A = datagen.theta_A(51, B, N, M)
+    t, a = torch.from_numpy(theta).cuda(), torch.from_numpy(A).cuda()
+    _, Q = eng.forward(t, a, 0)
+    one = torch.full((1,), 0.75, device="cuda")
+    want = eng.backward(one.expand(B).contiguous(), Q, (B, N, M), 0)
+    assert torch.equal(eng.backward(one.expand(B), Q, (B, N, M), 0), want)
+    assert torch.equal(eng.backward(one[0], Q, (B, N, M), 0), want)
+    out = torch.zeros_like(want)
+    eng.backward(one.expand(B), Q, (B, N, M), 0, pair_range=(0, 4), out=out)
+    eng.backward(one.expand(B), Q, (B, N, M), 0, pair_range=(4, B), out=out)
+    assert torch.equal(out, want)
 
 
 def test_bench_refuses_more_gpus_than_present():
