@@ -153,3 +153,24 @@ def test_aligned_flush_covers_every_cell_once(N, M, K, beta):
                     assert ring[r, idx] == col, (c, r, e)
                     seen[r, col] += 1
     assert (seen == 1).all()
+
+
+def test_no_time_slicing_of_strips_beats_run_to_completion():
+    """DESIGN.md section 4 ("ramps"): with W waves per pair the pipeline of strips has to fill and drain -- during the
+    k-th lag after the start only strips 0..k can have begun, and symmetrically before the end -- so
+    T >= S L / W + (W - 1) lag steps for ANY assignment / interleaving of strips, and the kernel's schedule (wave w runs
+    strips w, w + W, ... to completion) attains it: 1387 steps at the headline shape, not the max(work, critical path)
+    = 1150 that time-slicing at block granularity was hoped to approach (tools/ramp_bound.py)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import ramp_bound as rb
+    for S, M, W, lag in ((8, 512, 4, 79), (8, 512, 4, 95), (16, 1024, 4, 79), (8, 512, 2, 79), (12, 300, 4, 79)):
+        L = M + 63
+        lb, rtc = rb.lower_bound(S, L, lag, W), rb.run_to_completion(S, L, lag, W)
+        assert rtc == lb == S * L // W + (W - 1) * lag, (S, M, W, lag, lb, rtc)
+    assert rb.run_to_completion(8, 575, 79, 4) == 1387
+    res = rb.best_found(8, 575, 79, 4, blk=16)
+    # (the simulator runs whole 16-step blocks: its run-to-completion figure is the formula's rounded up to blocks)
+    assert min(res.values()) == res[("lowest strip first (= run to completion)", "w, w+W")] >= 1387
+    assert min(res.values()) <= 1387 + 16
