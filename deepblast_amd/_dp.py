@@ -87,8 +87,9 @@ def make_functions(variant, prefix, allow_none_operator=False):
             if Ztheta is None:
                 Ztheta = torch.zeros_like(E)
             _same_device(E, Ztheta=Ztheta, ZA=ZA)
-            Vtd, Qd = eng.adjoint_forward(Q, Ztheta, ZA, variant, lens)
-            Ed = eng.adjoint_backward(E, Q, Qd, variant, lens)
+            ref = exact_state == _engine.REF
+            Vtd, Qd = eng.adjoint_forward(Q, Ztheta, ZA, variant, lens, ref=ref)
+            Ed = eng.adjoint_backward(E, Q, Qd, variant, lens, ref=ref)
             return Ed, None, Vtd, None, None, None, None
 
     class Function(torch.autograd.Function):
@@ -169,20 +170,30 @@ class _Decoder(nn.Module):
 
     _function = None
 
-    def __init__(self, operator, traceback_rule="cpu"):
+    def __init__(self, operator, traceback_rule="cpu", arithmetic="fast"):
         """traceback_rule (extension): "cpu" = the walk of the reference's CPU decoders (nw.py:401-444, the parity
-        oracle), "cuda" = the walk of its GPU decoders (nw_cuda.py:273-317), for callers that switch over from those."""
+        oracle), "cuda" = the walk of its GPU decoders (nw_cuda.py:273-317), for callers that switch over from those.
+        arithmetic (extension): "fast" = the tuned sweeps (fp32 exp-domain forward, float64 products in the second-order
+        pair: within 1e-4 of the reference wherever the reference is within 1e-4 of its own float64 run, and closer to
+        that float64 run than the reference is); "reference" = the reference's arithmetic rounding for rounding
+        (include/sdp.h: SDP_REF_ROUNDING) -- unoptimised, for callers who need nw.py's numbers on long saturated
+        alignments, where nw.py's own fp32 roundings move the second-order results by 1-2e-4."""
         super().__init__()
         if traceback_rule not in ("cpu", "cuda"):
             raise ValueError(f"traceback_rule must be 'cpu' or 'cuda', got {traceback_rule!r}")
+        if arithmetic not in ("fast", "reference"):
+            raise ValueError(f"arithmetic must be 'fast' or 'reference', got {arithmetic!r}")
         self.operator = operator
         self.traceback_rule = traceback_rule
+        self.arithmetic = arithmetic
 
     def forward(self, theta, A, lengths=None):
         """theta, A: (B, N, M) fp32 on a ROCm device -> Vt (B,) on the same device.
 
         `lengths` (optional, (B,2) int) is an extension: per-pair true sizes of a padded
         batch; None reproduces the reference (DP over the full padded matrix)."""
+        if self.arithmetic == "reference":
+            return self._function.apply(theta, A, self.operator, lengths, _engine.REF)
         if lengths is None:
             return self._function.apply(theta, A, self.operator)
         return self._function.apply(theta, A, self.operator, lengths)
@@ -190,7 +201,7 @@ class _Decoder(nn.Module):
     def _forward_for_decode(self, theta, A, lengths):
         # decode() is differentiated again by its callers (training: loss on the alignment matrix): save the
         # state in the exact form all four sweeps can share
-        return self._function.apply(theta, A, self.operator, lengths, True)
+        return self._function.apply(theta, A, self.operator, lengths, _engine.REF if self.arithmetic == "reference" else True)
 
     def traceback(self, grad):
         return traceback(grad, self.traceback_rule)

@@ -29,6 +29,8 @@ def _ptr(t):
 
 EXACT_STATE = 0x100  # include/sdp.h: SDP_EXACT_STATE
 ET_BROADCAST = 0x200  # include/sdp.h: SDP_ET_BROADCAST
+REF_ROUNDING = 0x400  # include/sdp.h: SDP_REF_ROUNDING
+REF = "ref"           # value of `exact_state` that selects it: the state is then the reference's own (B, N, M, 3) fp32
 TRACEBACK_RULES = {"cpu": 0, "cuda": 1}  # include/sdp.h: SDP_TRACEBACK_CPU / SDP_TRACEBACK_CUDA
 
 
@@ -89,10 +91,23 @@ class HipEngine:
     def max_cols(self):
         return self.lib.sdp_max_cols()
 
-    def new_state(self, B, N, M, device, derivative=False):
-        """Opaque buffer for Q (6 bytes per cell) or, with derivative=True, for Qd (float2 per cell)."""
-        nbytes = (self.lib.sdp_state_d_bytes if derivative else self.lib.sdp_state_bytes)(B, N, M)
+    def new_state(self, B, N, M, device, derivative=False, ref=False):
+        """Opaque buffer for Q (6 bytes per cell) or, with derivative=True, for Qd (float2 per cell); ref: the
+        reference-rounding mode's (B, N, M, 3) fp32 for either."""
+        if ref:
+            nbytes = self.lib.sdp_state_bytes_v(B, N, M, REF_ROUNDING)
+        else:
+            nbytes = (self.lib.sdp_state_d_bytes if derivative else self.lib.sdp_state_bytes)(B, N, M)
         return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+
+    @staticmethod
+    def _state_flags(exact_state):
+        """`exact_state` of forward / backward -> flag bits: False = packed, True = float2, "ref" = reference rounding."""
+        if isinstance(exact_state, str):
+            if exact_state != REF:
+                raise ValueError(f"exact_state must be False, True or {REF!r}, got {exact_state!r}")
+            return REF_ROUNDING
+        return EXACT_STATE if exact_state else 0
 
     @staticmethod
     def _lens(lens, B, device):
@@ -108,15 +123,15 @@ class HipEngine:
         """-> (Vt (B,), state).  Replaces _forward_pass_kernel (nw_cuda.py:74-79).
 
         exact_state=False: the compact state the backward sweep reads; True: Q as float2, which the two
-        adjoint sweeps need (include/sdp.h, SDP_EXACT_STATE)."""
+        adjoint sweeps need (include/sdp.h, SDP_EXACT_STATE); "ref": the reference's arithmetic and its own
+        (B,N,M,3) fp32 Q (SDP_REF_ROUNDING) -- the other three sweeps must then be asked for the same."""
         dev = self._dev(theta)
         self._check(theta, theta=theta, A=A)
         theta, A = theta.contiguous(), A.contiguous()
         B, N, M = theta.shape
         lens = self._lens(lens, B, theta.device)
-        state = self.new_state(B, N, M, theta.device, derivative=exact_state)
-        if exact_state:
-            variant = variant | EXACT_STATE
+        state = self.new_state(B, N, M, theta.device, derivative=bool(exact_state), ref=exact_state == REF)
+        variant = variant | self._state_flags(exact_state)
         Vt = torch.empty(B, dtype=torch.float32, device=theta.device)
         with torch.cuda.device(dev), self._bracket("sdp_fwd_kernel"):
             rc = self.lib.sdp_forward_f32(_ptr(theta), _ptr(A), _ptr(state), _ptr(Vt), B, N, M, _ptr(lens),
@@ -145,7 +160,7 @@ class HipEngine:
         E = torch.empty((B, N, M), dtype=torch.float32, device=state.device) if out is None else out
         if tuple(E.shape) != (B, N, M) or E.dtype != torch.float32 or not E.is_contiguous() or E.device != state.device:
             raise ValueError("out must be a contiguous float32 (B, N, M) tensor on the state's device")
-        v = self._v(1, variant) | (EXACT_STATE if exact_state else 0) | (ET_BROADCAST if bcast else 0)
+        v = self._v(1, variant) | self._state_flags(exact_state) | (ET_BROADCAST if bcast else 0)
         with torch.cuda.device(dev), self._bracket("sdp_bwd_kernel"):
             if pair_range is None:
                 rc = self.lib.sdp_backward_f32(_ptr(Et), _ptr(state), _ptr(E), B, N, M, _ptr(lens), v, dev, self._stream(dev))
@@ -171,8 +186,9 @@ class HipEngine:
                 return Et, False
         return Et.to(torch.float32).expand(B).contiguous(), False
 
-    def adjoint_forward(self, state, Ztheta, ZA, variant, lens=None):
-        """-> (Vtd (B,), state_d).  Replaces _adjoint_forward_pass_kernel (nw_cuda.py:134-139)."""
+    def adjoint_forward(self, state, Ztheta, ZA, variant, lens=None, ref=False):
+        """-> (Vtd (B,), state_d).  Replaces _adjoint_forward_pass_kernel (nw_cuda.py:134-139).
+        ref: `state` came from forward(..., exact_state="ref"); the Hessian product is rounded as numpy rounds it."""
         dev = self._dev(state)
         for name, t in (("Ztheta", Ztheta), ("ZA", ZA)):
             if t is not None and t.device != state.device:
@@ -182,11 +198,11 @@ class HipEngine:
         if ZA is not None:
             ZA = ZA.to(torch.float32).contiguous()
         lens = self._lens(lens, B, state.device)
-        state_d = self.new_state(B, N, M, state.device, derivative=True)
+        state_d = self.new_state(B, N, M, state.device, derivative=True, ref=ref)
         Vtd = torch.empty(B, dtype=torch.float32, device=state.device)
         with torch.cuda.device(dev), self._bracket("sdp_adj_fwd_kernel"):
             rc = self.lib.sdp_adjoint_forward_f32(_ptr(state), _ptr(Ztheta), _ptr(ZA), _ptr(Vtd), _ptr(state_d),
-                                                  B, N, M, _ptr(lens), self._v(2, variant), dev, self._stream(dev))
+                                                  B, N, M, _ptr(lens), self._v(2, variant) | (REF_ROUNDING if ref else 0), dev, self._stream(dev))
         _lib.check(rc, "sdp_adjoint_forward_f32")
         return Vtd, state_d
 
@@ -207,8 +223,8 @@ class HipEngine:
         _lib.check(rc, "sdp_adjoint_forward_loss_f32")
         return Vtd, state_d
 
-    def adjoint_backward(self, E, state, state_d, variant, lens=None):
-        """-> Ed (B,N,M).  Replaces _adjoint_backward_pass_kernel (nw_cuda.py:160-165)."""
+    def adjoint_backward(self, E, state, state_d, variant, lens=None, ref=False):
+        """-> Ed (B,N,M).  Replaces _adjoint_backward_pass_kernel (nw_cuda.py:160-165).  ref: as for adjoint_forward."""
         dev = self._dev(state)
         self._check(state, E=E, state_d=state_d)
         E = E.contiguous()
@@ -217,7 +233,7 @@ class HipEngine:
         Ed = torch.empty((B, N, M), dtype=torch.float32, device=state.device)
         with torch.cuda.device(dev), self._bracket("sdp_adj_bwd_kernel"):
             rc = self.lib.sdp_adjoint_backward_f32(_ptr(E), _ptr(state), _ptr(state_d), _ptr(Ed), B, N, M,
-                                                   _ptr(lens), self._v(3, variant), dev, self._stream(dev))
+                                                   _ptr(lens), self._v(3, variant) | (REF_ROUNDING if ref else 0), dev, self._stream(dev))
         _lib.check(rc, "sdp_adjoint_backward_f32")
         return Ed
 

@@ -22,6 +22,8 @@ SIGNATURES = {
     "sdp_max_cols": (ctypes.c_int, []),
     "sdp_state_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "sdp_state_d_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "sdp_state_bytes_v": (ctypes.c_size_t, [ctypes.c_int] * 4),
+    "sdp_state_d_bytes_v": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "sdp_plan": (ctypes.c_int, [ctypes.c_int] * 7 + [ctypes.POINTER(ctypes.c_int)] * 3 + [ctypes.POINTER(ctypes.c_size_t)]),
     "sdp_plan_parts": (ctypes.c_int, [ctypes.c_int] * 7),
     "sdp_forward_f32": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int,

@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", "sdp_kernels.hip"), os.path.join(HERE, "csrc", "sdp_scores.hip"),
+SRC = [os.path.join(HERE, "csrc", "sdp_kernels.hip"), os.path.join(HERE, "csrc", "sdp_scores.hip"), os.path.join(HERE, "csrc", "sdp_ref.hip"),
        os.path.join(HERE, "csrc", "sdp_comm.hip"), os.path.join(HERE, "csrc", "sdp_api.hip")]
 HDR = [os.path.join(HERE, "csrc", "sdp_kernels.h"), os.path.join(ROOT, "include", "sdp.h")]
 OUT = os.path.join(HERE, "libsdp_hip.so")

@@ -311,7 +311,7 @@ unsigned long long *bridge_in_state(const void *state, int B, int N, int M, bool
 // flags or-ed into `variant` (include/sdp.h): SDP_EXACT_STATE, SDP_WAVES(w)
 struct VariantBits {
     int variant, waves;
-    bool exact, et_bcast;
+    bool exact, et_bcast, ref;
 };
 // The packed state keeps two 24-bit weights per cell; a saturated weight that the forward sweep leaves one step
 // below 1 costs 1.7e-8 of E on average, which stays inside the 1e-4 parity bound up to ~5000 steps of a fully
@@ -327,7 +327,8 @@ VariantBits split_variant(int variant)
     v.exact = (variant & SDP_EXACT_STATE) != 0;
     v.et_bcast = (variant & SDP_ET_BROADCAST) != 0;
     v.waves = (variant >> 12) & 0xf;
-    v.variant = variant & ~(SDP_EXACT_STATE | SDP_ET_BROADCAST | (0xf << 12));
+    v.ref = (variant & SDP_REF_ROUNDING) != 0;
+    v.variant = variant & ~(SDP_EXACT_STATE | SDP_ET_BROADCAST | SDP_REF_ROUNDING | (0xf << 12));
     return v;
 }
 
@@ -467,6 +468,21 @@ int raise_scores_limits(int device)
     return 0;
 }
 
+// variant | SDP_REF_ROUNDING (sdp_ref.hip): one workgroup of 256 threads per pair, three rolling anti-diagonals of float64
+size_t ref_lds(int M) { return (size_t)3 * (M + 2) * sizeof(double); }
+size_t ref_state_bytes(int B, int N, int M) { return (size_t)B * N * M * 3 * sizeof(float); }
+int ref_prepare(int device)
+{
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    return pending_handoff_error(device);
+}
+int ref_launched(const char *what)
+{
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail_hip(e, what);
+}
+
 }  // namespace
 
 extern "C" {
@@ -490,6 +506,19 @@ size_t sdp_state_d_bytes(int B, int N, int M)
 {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
     return (size_t)B * sdp::state_rows2(N, M) * 64 * sizeof(float2) + sdp::state_order_bytes(B) + bridge_bytes(B, N, M) + parts_map_bytes(B, N);
+}
+
+size_t sdp_state_bytes_v(int B, int N, int M, int variant)
+{
+    if (B <= 0 || N <= 0 || M <= 0) return 0;
+    if (variant & SDP_REF_ROUNDING) return ref_state_bytes(B, N, M);
+    return (variant & SDP_EXACT_STATE) ? sdp_state_d_bytes(B, N, M) : sdp_state_bytes(B, N, M);
+}
+
+size_t sdp_state_d_bytes_v(int B, int N, int M, int variant)
+{
+    if (B <= 0 || N <= 0 || M <= 0) return 0;
+    return (variant & SDP_REF_ROUNDING) ? ref_state_bytes(B, N, M) : sdp_state_d_bytes(B, N, M);
 }
 
 int sdp_plan(int pass, int B, int N, int M, int has_lens, int exact_state, int cus, int *kernel_id, int *chunk,
@@ -560,6 +589,11 @@ int sdp_forward_f32(const float *theta, const float *A, float *state, float *Vt,
     const bool exact = exact_for(vb.exact, N, M);
     variant = vb.variant;
     if (int rc = check_shape(B, N, M, variant)) return rc;
+    if (vb.ref) {
+        if (int rc = ref_prepare(device)) return rc;
+        hipLaunchKernelGGL(sdp_ref_fwd_kernel, dim3(B), dim3(256), ref_lds(M), (hipStream_t)stream, theta, A, state, Vt, lens, N, M, variant == SDP_SW);
+        return ref_launched("sdp_ref_fwd_kernel");
+    }
     sdp::Params p = {};
     p.sin0 = theta;
     p.sin1 = A;
@@ -587,6 +621,11 @@ int sdp_backward_f32(const float *Et, const float *state, float *E, int B, int N
     const bool exact = exact_for(vb.exact, N, M);
     variant = vb.variant;
     if (int rc = check_shape(B, N, M, variant)) return rc;
+    if (vb.ref) {
+        if (int rc = ref_prepare(device)) return rc;
+        hipLaunchKernelGGL(sdp_ref_bwd_kernel, dim3(B), dim3(256), ref_lds(M), (hipStream_t)stream, Et, state, E, lens, N, M, variant == SDP_SW, vb.et_bcast ? 1 : 0);
+        return ref_launched("sdp_ref_bwd_kernel");
+    }
     sdp::Params p = {};
     p.vin = Et;
     p.vin_bcast = vb.et_bcast ? 1 : 0;
@@ -616,6 +655,13 @@ int sdp_backward_range_f32(const float *Et, const float *state, float *E, int B,
     variant = vb.variant;
     if (int rc = check_shape(B, N, M, variant)) return rc;
     if (first < 0 || count <= 0 || first > B - count) return fail(SDP_E_SHAPE, "sdp_backward_range_f32: [first, first + count) is not inside the batch");
+    if (vb.ref) {
+        if (int rc = ref_prepare(device)) return rc;
+        const size_t plane = (size_t)N * M;
+        hipLaunchKernelGGL(sdp_ref_bwd_kernel, dim3(count), dim3(256), ref_lds(M), (hipStream_t)stream, vb.et_bcast ? Et : Et + first,
+                           state + (size_t)first * plane * 3, E + (size_t)first * plane, (const int *)nullptr, N, M, variant == SDP_SW, vb.et_bcast ? 1 : 0);
+        return ref_launched("sdp_ref_bwd_kernel");
+    }
     if (SDP_STATE_MARCH) return fail(SDP_E_SHAPE, "sdp_backward_range_f32: not available with the marching state layout");
     sdp::Params p = {};
     p.vin = vb.et_bcast ? Et : Et + first;
@@ -636,6 +682,11 @@ int sdp_adjoint_forward_f32(const float *state, const float *Ztheta, const float
     const VariantBits vb = split_variant(variant);
     variant = vb.variant;
     if (int rc = check_shape(B, N, M, variant)) return rc;
+    if (vb.ref) {
+        if (int rc = ref_prepare(device)) return rc;
+        hipLaunchKernelGGL(sdp_ref_adj_fwd_kernel, dim3(B), dim3(256), ref_lds(M), (hipStream_t)stream, state, Ztheta, ZA, Vtd, state_d, lens, N, M);
+        return ref_launched("sdp_ref_adj_fwd_kernel");
+    }
     sdp::Params p = {};
     p.qin = reinterpret_cast<const uint32_t *>(state);
     p.sin0 = Ztheta;
@@ -657,6 +708,7 @@ int sdp_adjoint_forward_loss_f32(const float *state, const float *ref, const flo
     if (kind < 0 || kind > 2) return fail(SDP_E_VARIANT, "loss kind must be 0 (cross entropy), 1 (path) or 2 (alignment)");
     const VariantBits vb = split_variant(variant);
     variant = vb.variant;
+    if (vb.ref) return fail(SDP_E_VARIANT, "sdp_adjoint_forward_loss_f32: the fused loss seed has no reference-rounding form (use sdp_loss_backward_f32 + sdp_adjoint_forward_f32)");
     if (int rc = check_shape(B, N, M, variant)) return rc;
     sdp::Params p = {};
     p.qin = reinterpret_cast<const uint32_t *>(state);
@@ -680,6 +732,11 @@ int sdp_adjoint_backward_f32(const float *E, const float *state, const float *st
     const VariantBits vb = split_variant(variant);
     variant = vb.variant;
     if (int rc = check_shape(B, N, M, variant)) return rc;
+    if (vb.ref) {
+        if (int rc = ref_prepare(device)) return rc;
+        hipLaunchKernelGGL(sdp_ref_adj_bwd_kernel, dim3(B), dim3(256), ref_lds(M), (hipStream_t)stream, E, state, state_d, Ed, lens, N, M);
+        return ref_launched("sdp_ref_adj_bwd_kernel");
+    }
     sdp::Params p = {};
     p.sin0 = E;
     p.qin = reinterpret_cast<const uint32_t *>(state);

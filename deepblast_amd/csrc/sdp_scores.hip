@@ -655,10 +655,19 @@ __device__ __forceinline__ void xw_gemm(const XwOperand X, const XwOperand Y, in
                     float ve = st[op][0][e], vo = st[op][1][e];
                     if constexpr (AFUSE) {
                         if (op == 0) {
-                            // g * (1 - exp(sg * act)): absolute error ~1e-7 |g| (the factor is in [0, 1]); out-of-range loads gave 0 * (1 - 1)
-                            const float c = 1.44269504088896340736f * X.sg;
-                            ve *= 1.0f - __builtin_amdgcn_exp2f(c * sa[0][e]);
-                            vo *= 1.0f - __builtin_amdgcn_exp2f(c * sa[1][e]);
+                            // g * (1 - exp(sg * act)); out-of-range loads gave 0 * (1 - 1).  1 - 2^(c act) alone is good to ~1e-7
+                            // ABSOLUTE (the factor is in [0, 1]), i.e. tens of percent of a factor of 1e-7 -- a strongly
+                            // negative score, whose sigmoid the reference (and the expm1 of the unfused pass and of the
+                            // torch fallback) gets to full relative accuracy.  Small arguments therefore take the series
+                            // -x (1 + x/2 + x^2/6 + x^3/24): relative error x^4 / 120 < 1e-8 below 2^-5.
+                            auto one_minus_exp = [&](float act) {
+                                const float x = X.sg * act;
+                                const float big = 1.0f - __builtin_amdgcn_exp2f(1.44269504088896340736f * x);
+                                const float sm = -x * __builtin_fmaf(x, __builtin_fmaf(x, __builtin_fmaf(x, 1.0f / 24.0f, 1.0f / 6.0f), 0.5f), 1.0f);
+                                return __builtin_fabsf(x) < 0.03125f ? sm : big;
+                            };
+                            ve *= one_minus_exp(sa[0][e]);
+                            vo *= one_minus_exp(sa[1][e]);
                             dsv[0][e2] = ve, dsv[1][e2] = vo;
                         }
                     }

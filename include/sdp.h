@@ -64,7 +64,7 @@
 extern "C" {
 #endif
 
-#define SDP_VERSION 103 /* 0.1.2: + sdp_backward_range_f32, sdp_state_pair_stride */
+#define SDP_VERSION 103 /* 0.1.2: + sdp_backward_range_f32, sdp_state_pair_stride, SDP_ET_BROADCAST, SDP_REF_ROUNDING */
 
 #define SDP_NW 0
 #define SDP_SW 1
@@ -79,6 +79,17 @@ extern "C" {
  * pair -- the cotangent `Vt.sum().backward()` hands over is a broadcast scalar, and expanding it into (B,) floats first
  * would be a kernel launch of its own between the two sweeps. */
 #define SDP_ET_BROADCAST 0x200
+
+/* or-ed into `variant` of the four sweeps: the REFERENCE's arithmetic, rounding for rounding (csrc/sdp_ref.hip) --
+ * float64 exp / log / division and one rounding of Q to fp32 in the forward sweep (deepblast/nw.py:10-27, 115), all three
+ * weights kept; the soft-max Hessian product and the Qd * E products formed in fp32 exactly where numpy forms them
+ * (nw.py:30-43, 261-266); everything else float64.  The default sweeps keep those products in float64 and are the more
+ * accurate ones; on long saturated alignments (N + M beyond ~2500 with |theta| beyond ~50, or positive gap scores on long
+ * thin problems) the reference's own fp32 roundings move Ed by 1-2e-4, and only this mode reproduces that (to ~1e-7).
+ * All four sweeps of a problem must use the flag or none: the states are then the reference's, (B, N, M, 3) fp32 each
+ * (sdp_state_bytes_v / sdp_state_d_bytes_v).  Unoptimised: milliseconds where the default path takes a fraction of one.
+ * Not available for sdp_adjoint_forward_loss_f32. */
+#define SDP_REF_ROUNDING 0x400
 
 #define SDP_E_NULLPTR (-1)  /* a required pointer is NULL */
 #define SDP_E_SHAPE (-2)    /* B, N or M non-positive */
@@ -104,6 +115,11 @@ int sdp_max_cols(void);
 /* Bytes of the opaque buffers that hold Q (`state`) and Qd (`state_d`) for a (B,N,M) problem; 0 on bad shape. */
 size_t sdp_state_bytes(int B, int N, int M);
 size_t sdp_state_d_bytes(int B, int N, int M);
+
+/* ... the same for a given `variant` word (SDP_EXACT_STATE, SDP_REF_ROUNDING): what the sweeps called with that word
+ * read and write. */
+size_t sdp_state_bytes_v(int B, int N, int M, int variant);
+size_t sdp_state_d_bytes_v(int B, int N, int M, int variant);
 
 /* Vt[b] = V[n_b, m_b]; state <- softmax weights of every cell. */
 int sdp_forward_f32(const float *theta, const float *A, float *state, float *Vt, int B, int N,

@@ -110,6 +110,34 @@ def engine_all(theta, A, Et, Z, variant, lens=None, ZA=None, device="cuda"):
     return out
 
 
+def engine_ref(theta, A, Et, Z, variant, lens=None, ZA=None, device="cuda"):
+    """The four sweeps in the REFERENCE's arithmetic (variant | SDP_REF_ROUNDING, csrc/sdp_ref.hip) through the C ABI."""
+    import torch
+    from deepblast_amd._engine import REF, get_engine
+    eng = get_engine()
+    t = torch.from_numpy(np.ascontiguousarray(theta)).to(device)
+    a = torch.from_numpy(np.ascontiguousarray(A)).to(device)
+    B = t.shape[0]
+    et = torch.ones(B, device=device) if Et is None else torch.from_numpy(Et).to(device)
+    ln = None if lens is None else torch.from_numpy(np.ascontiguousarray(lens, dtype=np.int32)).to(device)
+    Vt, Q = eng.forward(t, a, variant, ln, exact_state=REF)
+    E = eng.backward(et, Q, tuple(t.shape), variant, ln, exact_state=REF)
+    out = {"Vt": Vt.cpu().numpy(), "E": E.cpu().numpy()}
+    if Z is not None:
+        z = torch.from_numpy(np.ascontiguousarray(Z)).to(device)
+        za = None if ZA is None else torch.from_numpy(np.ascontiguousarray(ZA)).to(device)
+        Vtd, Qd = eng.adjoint_forward(Q, z, za, variant, ln, ref=True)
+        Ed = eng.adjoint_backward(E, Q, Qd, variant, ln, ref=True)
+        out["Ed"], out["Vtd"] = Ed.cpu().numpy(), Vtd.cpu().numpy()
+    torch.cuda.synchronize()
+    return out
+
+
+def unscaled(got, ref, key="Ed"):
+    """max |got - ref| with no scaling at all (SURVEY 8c states the Ed bound as a plain max-abs)."""
+    return abs_err(got[key], ref[key], scale=False)
+
+
 def compare(got, ref):
     """-> dict of errors, already normalised so that each must be <= TOL."""
     errs = {"Vt": rel_err(got["Vt"], ref["Vt"]), "E": abs_err(got["E"], ref["E"])}

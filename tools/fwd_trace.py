@@ -36,5 +36,10 @@ for pair in ((0,) if B < 129 else (0, 2)):
             odd = x[7:nb - 2:2]
             if False:
                 print(f"     odd blocks: start->check {(odd[:, 4] - odd[:, 0]).mean():.0f}  write_block {(odd[:, 5] - odd[:, 4]).mean():.0f}  load_block {(odd[:, 6] - odd[:, 5]).mean():.0f}  prefetch issue {(odd[:, 7] - odd[:, 6]).mean():.0f}  ->compute {(odd[:, 1] - odd[:, 7]).mean():.0f};  even blocks wait {(x[6:nb - 2:2, 1] - x[6:nb - 2:2, 0]).mean():.0f}")
+            if os.environ.get("TRACE_BLOCKS"):
+                print(f"    wave {w} round {rd} per block: wait " + " ".join(str(int(v)) for v in wait))
+                print(f"    wave {w} round {rd} per block: comp " + " ".join(str(int(v)) for v in comp))
+                print(f"    wave {w} round {rd} per block: publ " + " ".join(str(int(v)) for v in pub))
+                print(f"    wave {w} round {rd} per block: gap  " + " ".join(str(int(v)) for v in gap))
             print(f"  wave {w} round/part {rd}: {x[0, 0] - t0:8d} .. {x[-1, 3] - t0:8d}  blocks {nb}  "
                   f"wait {wait[mid].mean():6.0f} compute {comp[mid].mean():6.0f} publish {pub[mid].mean():5.0f} gap(even->odd block, odd->next chunk) {gap[6:-2:2].mean():6.0f} {gap[7:-2:2].mean():6.0f}")
