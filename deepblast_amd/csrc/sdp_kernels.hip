@@ -318,12 +318,22 @@ __device__ __forceinline__ unsigned hi32(u64 x) { return (unsigned)(x >> 32); }
 //     reciprocal is a normal float too.  A = -inf (2^A = 0) is fine.
 // A chunk that fails a test is redone in the per-step-normalised form; nothing was committed before the test.
 // WF_HI also leaves room for the consumers of published values (value * 2^A * 2 + ... stays below 2^128).
-// Values mostly grow along a row (fastest in the lower left corner of the matrix, ~5 bits per step), so a lane's
-// frame is placed WF_BIAS bits above the exponent of its current value: it starts the chunk at 2^-40.
+// Values mostly grow along a row (fastest in the lower left corner of the matrix: ~5 bits per step, and 10-20 in a row's first
+// columns), so a lane's frame is placed WF_BIAS bits above the exponent of its current value: it starts the block at
+// 2^-WF_BIAS, with 110 + WF_BIAS bits of room upwards and 100 - WF_BIAS downwards.  Round 4: 40 -> 64.  With 40 the head
+// blocks of the two bottom strips of a 512 x 512 pair failed the range test (rows 400+ gain 152-158 bits in the 16 steps
+// after their first column; cycle stamps: 6 + 5 blocks at 7-10k cycles instead of 2k, all on the pair's critical path --
+// strip 7 cannot start before strip 6's head is through), ~11 % of the launch.  Blocks that fail, by bias (40 / 56 / 64 /
+// 80) on 512 x 512: benchmark scores 8 / 0 / 0 / 0; theta x 8: 191 / 127 / 110 / 73; theta - 2: 0 / 0 / 0 / 159; theta x 8 - 4:
+// 47 / 38 / 35 / 76; A + 0.5: 10 / 0 / 0 / 0 (emulated from the float64 V).  Which form a block runs in does not change a
+// cell's value, and only in the packed state whether its weights are sharpened (see norm_block).
 constexpr unsigned WF_HI = 0x76800000u;  // 2^110
 constexpr unsigned WF_LO = 0x0d800000u;  // 2^-100
 constexpr unsigned WF_FMAX = 0x45800000u;  // 2^12
-constexpr int WF_BIAS = 40;
+#ifndef SDP_WF_BIAS
+#define SDP_WF_BIAS 64
+#endif
+constexpr int WF_BIAS = SDP_WF_BIAS;
 constexpr int WB = 16;  // steps per frame (every chunk length is a multiple)
 constexpr int FRAME_NONE = (int)0x80000000;  // published chunk is not in one frame (per-value exponents apply)
 constexpr float EXP_ONE_A = 0.5f;
@@ -732,7 +742,15 @@ __device__ __forceinline__ void sweep(const Params &p)
         if constexpr (T::SIN > 0) {
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
-                const int r = i * RPL + r4_l;
+                // rows of load instruction i.  Latency builds: 8 consecutive rows.  LINES: the rows r with r mod 4 == i mod 4 of
+                // one half of the strip -- a loaded group of four columns lands at ring positions p0 .. p0 + 3 with p0 = r mod 4
+                // (mod 4), so with this assignment every lane of an instruction cuts its group the same way, known at compile
+                // time, into the largest ALIGNED pieces: one 16-byte write (r mod 4 = 0), two 8-byte writes (2), or 4 + 8 + 4
+                // bytes (1, 3) -- 36 LDS writes per chunk instead of 64 dword writes.  (An LDS instruction costs a wave ~17
+                // issue cycles whatever its width -- round 4 cycle stamps: the 64 dword writes of a chunk took 1100 cycles
+                // of the ~8000 a chunk takes.)
+                const int r = LINES ? ((i & 3) + 32 * (i >> 2) + 4 * r4_l) : (i * RPL + r4_l);
+                static_assert(!LINES || (K == 32 && NLD == 8 && RPL == 8), "row assignment of the line-aligned staging is written for K = 32");
                 if constexpr (LINES) {
                     const int beta = GEN ? (int)(((uintptr_t)(p.sin0 + b_in * plane_elems) >> 2) & (uintptr_t)(K - 1)) : 0;
                     li_unaligned = GEN && (beta != 0 || (ld & (K - 1)) != 0);
@@ -841,7 +859,21 @@ __device__ __forceinline__ void sweep(const Params &p)
                 for (int i = 0; i < NLD; ++i)
 #pragma unroll
                     for (int q = 0; q < T::SIN; ++q) {
-                        if constexpr (LINES) {
+                        if constexpr (LINES && !GEN) {
+                            // aligned planes and pitch: ring position of the group's first column = r mod 4 = i mod 4 (mod 4)
+                            float *dst = lds_in + q * PLANE;
+                            const float v0 = rs[q][4 * i], v1 = rs[q][4 * i + 1], v2 = rs[q][4 * i + 2], v3 = rs[q][4 * i + 3];
+                            if ((i & 3) == 0) {
+                                *reinterpret_cast<float4 *>(dst + (li_w[i][0] ^ flip)) = make_float4(v0, v1, v2, v3);
+                            } else if ((i & 3) == 2) {
+                                *reinterpret_cast<float2 *>(dst + (li_w[i][0] ^ flip)) = make_float2(v0, v1);
+                                *reinterpret_cast<float2 *>(dst + (li_w[i][2] ^ flip)) = make_float2(v2, v3);
+                            } else {
+                                dst[li_w[i][0] ^ flip] = v0;
+                                *reinterpret_cast<float2 *>(dst + (li_w[i][1] ^ flip)) = make_float2(v1, v2);
+                                dst[li_w[i][3] ^ flip] = v3;
+                            }
+                        } else if constexpr (LINES) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) lds_in[q * PLANE + (li_w[i][j] ^ flip)] = rs[q][4 * i + j];
                         } else {
@@ -1114,6 +1146,22 @@ __device__ __forceinline__ void sweep(const Params &p)
                     int frame_pub = FRAME_NONE;
                     stamp(1);
 
+                    // ---- parts: the block's 16 columns (c_lo ..) to the bridge row as well, one granule per lane (columns outside
+                    // the matrix: a valid dummy -- the consumer waits for whole blocks); frame_r: the publishing lane's frame ----
+                    auto export_block = [&](int c_lo, int frame_r) {
+                        const int col = c_lo + lane;
+                        const bool colok = lane < WB && col >= 0 && col < m;
+                        unsigned gv = __float_as_uint(EXP_ONE_A), ge = (unsigned)EXP_ONE_E;
+                        const int fpub = __builtin_amdgcn_readlane(frame_r, PUB_LANE);   // (every lane has a frame of its own: the publishing lane's)
+                        if (colok) {
+                            gv = __float_as_uint(bv_out[col]);
+                            ge = fpub != FRAME_NONE ? (unsigned)fpub : (unsigned)be_out[col];
+                        }
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        if (!(SDP_EXP_BUILD && (p.dbg & 8)))
+                            __builtin_amdgcn_raw_buffer_store_b64(lane == WB ? (u32x2){(unsigned)fpub, 0u} : (u32x2){gv, ge}, rs_xo,
+                                                                  lane < WB ? (unsigned)((tb + lane) * 8) : (lane == WB ? (unsigned)((xb_frm0 + tb / WB) * 8) : OOB), 0, XB_AUX);
+                    };
                     // ---- publish the block: 16 boundary values, their frame word, then the progress word.  Called at the end of
                     // whichever form computed the block -- NOT once behind both: with the 16 values (32 registers) flowing
                     // from two code paths into one publishing site the compiler shuffled them into common registers
@@ -1154,22 +1202,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                             // LDS executes a wave's DS instructions in order, so the data written above is visible to any
                             // wave that observes this word (the asm statements also stop compiler reordering)
                             if (lane == PUB_LANE && !(SDP_EXP_BUILD && (p.dbg & 8))) lds_store_i32(prog + 4 * oword, obase + pub_done);
-                            if (exported) {
-                                // the same 16 columns to the bridge row, one granule per lane (columns outside the matrix: a
-                                // valid dummy -- the consumer waits for whole blocks)
-                                const int col = c_lo + lane;
-                                const bool colok = lane < WB && col >= 0 && col < m;
-                                unsigned gv = __float_as_uint(EXP_ONE_A), ge = (unsigned)EXP_ONE_E;
-                                const int fpub = __builtin_amdgcn_readlane(frame_pub, PUB_LANE);   // (every lane has a frame of its own: the publishing lane's)
-                                if (colok) {
-                                    gv = __float_as_uint(bv_out[col]);
-                                    ge = fpub != FRAME_NONE ? (unsigned)fpub : (unsigned)be_out[col];
-                                }
-                                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                                if (!(SDP_EXP_BUILD && (p.dbg & 8)))
-                                    __builtin_amdgcn_raw_buffer_store_b64(lane == WB ? (u32x2){(unsigned)fpub, 0u} : (u32x2){gv, ge}, rs_xo,
-                                                                          lane < WB ? (unsigned)((tb + lane) * 8) : (lane == WB ? (unsigned)((xb_frm0 + tb / WB) * 8) : OOB), 0, XB_AUX);
-                            }
+                            if (exported) export_block(c_lo, frame_pub);
                         }
                     };
 
@@ -1468,11 +1501,22 @@ __device__ __forceinline__ void sweep(const Params &p)
             // block set that chunk c+dir needs in addition; its loads are issued one per step below
             // (the last chunk re-reads its own set: harmless, keeps the step body branch-free)
             const int bb_new = more ? (REV ? c - 1 : c + 2) : c;
+            // experiments build, sdp_set_trace: stamps 4..7 of a chunk's two block slots bracket the chunk's memory pipeline
+            auto stamp_chunk = [&](int blk, int k) {
+                if constexpr (SDP_EXP_BUILD != 0 && PASS == PASS_FWD) {
+                    if (p.trace && (b & 63) == 0 && b < 256 && lane == 0 && (parts ? part < 4 : sidx / W < 2) && blk < 40)
+                        p.trace[((((b >> 6) * 4 + wave) * 4 + (parts ? part : sidx / W)) * 40 + blk) * 8 + k] = __builtin_readcyclecounter();
+                }
+            };
+            stamp_chunk(t0 / WB, 4);
             load_block(bb_new);
+            stamp_chunk(t0 / WB, 5);
 
             if constexpr (FWD_SUB) {
                 fwd_blocks(c, t0);
+                stamp_chunk(t0 / WB + 1, 4);
                 if (more) write_block(bb_new);
+                stamp_chunk(t0 / WB + 1, 5);
                 continue;
             }
 

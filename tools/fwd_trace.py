@@ -34,6 +34,10 @@ for pair in ((0,) if B < 129 else (0, 2)):
             gap = x[1:, 0] - x[:-1, 3]
             mid = slice(6, nb - 2)   # interior blocks
             odd = x[7:nb - 2:2]
+            if os.environ.get("TRACE_CHUNK"):
+                ev, od = x[6:nb - 2:2], x[7:nb - 2:2]
+                print(f"     chunk pipeline: load_block issue {(ev[:, 5] - ev[:, 4]).mean():.0f}  (odd block end -> write_block start {(od[:, 4] - od[:, 3]).mean():.0f})  write_block {(od[:, 5] - od[:, 4]).mean():.0f}  "
+                      f"write_block end -> next load_block start {(x[8:nb - 2:2, 4] - x[7:nb - 3:2, 5]).mean():.0f}  load_block end -> block start {(ev[:, 0] - ev[:, 5]).mean():.0f}")
             if False:
                 print(f"     odd blocks: start->check {(odd[:, 4] - odd[:, 0]).mean():.0f}  write_block {(odd[:, 5] - odd[:, 4]).mean():.0f}  load_block {(odd[:, 6] - odd[:, 5]).mean():.0f}  prefetch issue {(odd[:, 7] - odd[:, 6]).mean():.0f}  ->compute {(odd[:, 1] - odd[:, 7]).mean():.0f};  even blocks wait {(x[6:nb - 2:2, 1] - x[6:nb - 2:2, 0]).mean():.0f}")
             if os.environ.get("TRACE_BLOCKS"):
