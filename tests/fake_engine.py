@@ -59,7 +59,7 @@ class OracleEngine:
         out[lo:hi] = torch.from_numpy(E)   # like the real engine: only the swept rows are written
         return out
 
-    def adjoint_forward(self, state, Ztheta, ZA, variant, lens=None):
+    def adjoint_forward(self, state, Ztheta, ZA, variant, lens=None, ref=False):
         Z = self._np(Ztheta)
         B = Z.shape[0]
         Vtd = np.zeros(B, np.float32)
@@ -76,7 +76,7 @@ class OracleEngine:
         sd._oracle_Qd = Qds
         return torch.from_numpy(Vtd), sd
 
-    def adjoint_backward(self, E, state, state_d, variant, lens=None):
+    def adjoint_backward(self, E, state, state_d, variant, lens=None, ref=False):
         B, N, M = E.shape
         Ed = np.zeros((B, N, M), np.float32)
         En = self._np(E)
