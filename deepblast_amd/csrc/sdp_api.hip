@@ -276,7 +276,7 @@ int pending_handoff_error(int device)
 // and must be given the same lengths -- read it from there.
 size_t packed_body_bytes(int B, int N, int M)
 {
-    return (size_t)B * sdp::state_nstrips(N) * sdp::state_tpad(M) * 64 * 6;
+    return (size_t)B * sdp::state_nstrips(N) * (sdp::state_tpad(M) / sdp::STATE_UNIT_STEPS) * sdp::STATEQ_UNIT_BYTES;
 }
 bool wants_order(int B, int N, const int32_t *lens, int device)
 {

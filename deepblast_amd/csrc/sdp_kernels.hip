@@ -250,6 +250,44 @@ __device__ __forceinline__ float2 q_unpack(const unsigned *w, int second)
     return make_float2(q_field(w[0]), q_field(__builtin_amdgcn_perm(w[1], w[0], 0x0c050403u)));
 }
 
+// Round 4, SDP_Q20: two 20-bit fields per cell (5 bytes).  A field is the low 20 bits of the float f = 8 + q * (1 - 2^-19):
+// in [8, 16) one ulp is 2^-20, so the fma's own rounding puts q on a grid of 2^-20 (absolute error <= 2^-21 = 4.8e-7 per
+// weight; emulated on the float64 oracle's weights, tools/emu_state_formats.py: max |dE| 9e-7 on the benchmark's scores,
+// 3.4e-6 on peaked ones at 512 x 512 -- the 1e-4 bound is 30x away, and problems with N + M > 4096 take the exact state
+// as before).  The factor keeps the field below 2^20 for q <= 1 + 9e-7; a saturated weight (anything within 2^-21 of 1)
+// decodes to exactly 1, a weight below 2^-21 to exactly 0, so a saturated path loses nothing -- the 24-bit format kept 1 -
+// 2^-23 as it was and lost 1.7e-8 of E per step.  Four cells -- eight fields, x0 y0 x1 y1 x2 y2 x3 y3 from bit 0 up -- fill
+// five dwords; dwords 0-3 go to plane A of the unit, dword 4 to plane B (sdp_kernels.h).
+constexpr bool Q20 = SDP_Q20 != 0;
+constexpr float Q20_SCALE = 0.99999809265136718750f;    // 1 - 2^-19
+constexpr float Q20_UNSCALE = 1.0000019073486328125f;   // 1 + 2^-19 = 1 / (1 - 2^-19) to fp32
+constexpr float QF_SCALE = Q20 ? Q20_SCALE : Q_SCALE, QF_UNSCALE = Q20 ? Q20_UNSCALE : Q_UNSCALE, QF_BASE = Q20 ? 8.0f : 1.0f;
+// raw bits fx[k], fy[k] of the four cells' biased floats (0x41000000 | field) -> five dwords
+__device__ __forceinline__ void q20_pack4(const unsigned *fx, const unsigned *fy, unsigned *w)
+{
+    // (a left shift pushes the exponent byte out of the dword, and bits 20-23 of a biased float are zero, so only fields
+    //  that stay below bit 24 after their shift need masking)
+    w[0] = (fx[0] & 0xfffffu) | (fy[0] << 20);
+    w[1] = __builtin_amdgcn_ubfe(fy[0], 12, 8) | (fx[1] << 8) | (fy[1] << 28);
+    w[2] = __builtin_amdgcn_ubfe(fy[1], 4, 16) | (fx[2] << 16);
+    w[3] = __builtin_amdgcn_ubfe(fx[2], 16, 4) | ((fy[2] & 0xfffffu) << 4) | (fx[3] << 24);
+    w[4] = __builtin_amdgcn_ubfe(fx[3], 8, 12) | (fy[3] << 12);
+}
+__device__ __forceinline__ float q20_field(unsigned u)  // field in the low 20 bits of u, anything above -> f - 8
+{
+    return __uint_as_float((u & 0xfffffu) | 0x41000000u) - 8.0f;
+}
+// (f - 8) of both weights of cell `sub` (0..3) of a five-dword record; the caller multiplies by Q20_UNSCALE
+__device__ __forceinline__ float2 q20_unpack(const unsigned *w, int sub)
+{
+    switch (sub) {
+    case 0: return make_float2(q20_field(w[0]), q20_field(__builtin_amdgcn_alignbit(w[1], w[0], 20)));
+    case 1: return make_float2(q20_field(w[1] >> 8), q20_field(__builtin_amdgcn_alignbit(w[2], w[1], 28)));
+    case 2: return make_float2(q20_field(__builtin_amdgcn_alignbit(w[3], w[2], 16)), q20_field(w[3] >> 4));
+    default: return make_float2(q20_field(__builtin_amdgcn_alignbit(w[4], w[3], 24)), q20_field(w[4] >> 12));
+    }
+}
+
 // Exact-state weights: the largest of the three is formed as 1 - (the other two).  c/sum*u goes through an
 // approximate reciprocal and two products (~1.5 ulp): harmless for a weight of 0.3, but a weight that the reference
 // -- which divides in float64 and rounds once (nw.py:21-22,115) -- stores as exactly 1.0 would come out as
@@ -620,28 +658,48 @@ __device__ __forceinline__ void sweep(const Params &p)
         // host keeps a marching state below 2^31 bytes -- and nothing here relies on the check.)
         constexpr unsigned ST_RECORDS = 0x7fffffffu;
         const size_t ps_idx = b_st * p.nstrips_max + s;
-        const unsigned q_lane = lane * 12;
+        const unsigned q_lane = lane * (Q20 ? 16 : 12);
         __amdgpu_buffer_rsrc_t rs_q = make_rsrc(T::QIN == Q_PACKED ? (const void *)(reinterpret_cast<const char *>(p.qin) + ps_idx * p.st_ps)
                                                 : (T::QOUT == Q_PACKED ? (const void *)(static_cast<char *>(p.dout) + ps_idx * p.st_ps) : (const void *)p.vout),
                                                 (T::QIN == Q_PACKED || T::QOUT == Q_PACKED) ? ST_RECORDS : 0u);
-        // scalar offset of record row t_base/2 + g4 (g4 = 0, 4, 8, 12; t_base a multiple of the chunk length)
+        // 24-bit fields: scalar offset of record row t_base/2 + g4 (g4 = 0, 4, 8, 12; t_base a multiple of the chunk length)
         auto q_soff = [&](int t_base, int g4) { return (unsigned)(t_base >> 5) * p.st_us + (unsigned)((((t_base >> 1) & 15) + g4) * 768); };
+        // 20-bit fields: scalar offsets of row t_base/4 + g4 (g4 = 0, 4) of plane A (1024-byte rows) and of plane B (256-byte rows,
+        // behind the eight rows of plane A)
+        auto q20_soff_a = [&](int t_base, int g4) { return (unsigned)(t_base >> 5) * p.st_us + (unsigned)((((t_base >> 2) & 7) + g4) * 1024); };
+        auto q20_soff_b = [&](int t_base, int g4) { return (unsigned)(t_base >> 5) * p.st_us + 8192u + (unsigned)((((t_base >> 2) & 7) + g4) * 256); };
         typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
-        auto load_q = [&](int t_base, int g, unsigned *dst) {  // steps t_base + 2g, + 1
-            const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs_q, q_lane + (g & 3) * 768, q_soff(t_base, g & ~3), AUX_ST_LOAD);
-            const unsigned v0 = v[0], v1 = v[1], v2 = v[2];
-            dst[0] = v0, dst[1] = v1, dst[2] = v2;
+        typedef unsigned u32x4q __attribute__((ext_vector_type(4)));
+        auto load_q = [&](int t_base, int g, unsigned *dst) {  // 24-bit: steps t_base + 2g, + 1 (3 dwords); 20-bit: steps t_base + 4g .. + 3 (5 dwords)
+            if constexpr (Q20) {
+                const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_q, q_lane + (g & 3) * 1024, q20_soff_a(t_base, g & ~3), AUX_ST_LOAD);
+                const unsigned v4 = __builtin_amdgcn_raw_buffer_load_b32(rs_q, lane * 4 + (g & 3) * 256, q20_soff_b(t_base, g & ~3), AUX_ST_LOAD);
+                const unsigned v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+                dst[0] = v0, dst[1] = v1, dst[2] = v2, dst[3] = v3, dst[4] = v4;
+            } else {
+                const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs_q, q_lane + (g & 3) * 768, q_soff(t_base, g & ~3), AUX_ST_LOAD);
+                const unsigned v0 = v[0], v1 = v[1], v2 = v[2];
+                dst[0] = v0, dst[1] = v1, dst[2] = v2;
+            }
         };
         auto store_q = [&](int t_base, int g, const unsigned *src) {
-            u32x3 v;
-            v[0] = src[0], v[1] = src[1], v[2] = src[2];
-            __builtin_amdgcn_raw_buffer_store_b96(v, rs_q, q_lane + (g & 3) * 768, q_soff(t_base, g & ~3), AUX_ST_STORE);
             // A VALU instruction that overwrites a data register of a store wider than 64 bits in the very next
             // issue slot corrupts the stored value for part of the wave on gfx950 (seen: lanes 12-15 of every
             // 16).  The compiler only inserts the wait state for stores without a scalar offset register, so it
             // is forced here: the no-op "reads" the data registers (nothing that overwrites them can move above
             // it) and is ordered after the store as a memory operation.
-            asm volatile("s_nop 1" : : "v"(v) : "memory");
+            if constexpr (Q20) {
+                u32x4q v;
+                v[0] = src[0], v[1] = src[1], v[2] = src[2], v[3] = src[3];
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_q, q_lane + (g & 3) * 1024, q20_soff_a(t_base, g & ~3), AUX_ST_STORE);
+                asm volatile("s_nop 1" : : "v"(v) : "memory");
+                __builtin_amdgcn_raw_buffer_store_b32(src[4], rs_q, lane * 4 + (g & 3) * 256, q20_soff_b(t_base, g & ~3), AUX_ST_STORE);
+            } else {
+                u32x3 v;
+                v[0] = src[0], v[1] = src[1], v[2] = src[2];
+                __builtin_amdgcn_raw_buffer_store_b96(v, rs_q, q_lane + (g & 3) * 768, q_soff(t_base, g & ~3), AUX_ST_STORE);
+                asm volatile("s_nop 1" : : "v"(v) : "memory");
+            }
         };
         // float2 states (Qd, and Q in its exact form).  Cells outside the matrix are stored like any other (their
         // values are never used: every reader masks them).
@@ -669,10 +727,39 @@ __device__ __forceinline__ void sweep(const Params &p)
             __builtin_amdgcn_raw_buffer_store_b64(v, rs, st_lane + (k & 7) * 512, f2_soff(t_base, k & ~7), AUX_ST_STORE);
         };
         auto load_d = [&](int t_base, int k) { return load_f2(rs_d, t_base, k); };
+        // packed state, forward: the two biased fields of a cell (bits of QF_BASE + q * QF_SCALE) arrive per step.  24-bit
+        // fields: every second step three byte-permutes assemble the 12-byte record of the pair and one dwordx3 store moves
+        // it.  20-bit fields: every fourth step 13 shift / mask / or instructions assemble the 20-byte record of four cells,
+        // stored as dwordx4 + dword.
+        unsigned qbits_x = 0, qbits_y = 0;
+        unsigned qb_x[3] = {0, 0, 0}, qb_y[3] = {0, 0, 0};
+        auto store_state_bits = [&](int t_base, int k, unsigned fx, unsigned fy) {
+            if constexpr (Q20) {
+                if ((k & 3) == 0) qb_x[0] = fx, qb_y[0] = fy;
+                else if ((k & 3) == 1) qb_x[1] = fx, qb_y[1] = fy;
+                else if ((k & 3) == 2) qb_x[2] = fx, qb_y[2] = fy;
+                else {
+                    const unsigned ax[4] = {qb_x[0], qb_x[1], qb_x[2], fx}, ay[4] = {qb_y[0], qb_y[1], qb_y[2], fy};
+                    unsigned w[5];
+                    q20_pack4(ax, ay, w);
+                    store_q(t_base, k >> 2, w);
+                }
+            } else if ((k & 1) == 0) {
+                qbits_x = fx, qbits_y = fy;
+            } else {
+                unsigned w[3];
+                w[0] = __builtin_amdgcn_perm(qbits_y, qbits_x, 0x04020100u);
+                w[1] = __builtin_amdgcn_perm(fx, qbits_y, 0x05040201u);
+                w[2] = __builtin_amdgcn_perm(fy, fx, 0x06050402u);
+                store_q(t_base, k >> 1, w);
+            }
+        };
         float2 qhold;  // forward: weights of the even step of the current pair of steps
         // the state this pass produces, step t_base + k
         auto store_state = [&](int t_base, int k, float2 qq) {
-            if constexpr (T::QOUT == Q_PACKED) {
+            if constexpr (T::QOUT == Q_PACKED && Q20) {
+                store_state_bits(t_base, k, __float_as_uint(__builtin_fmaf(qq.x, Q20_SCALE, 8.0f)), __float_as_uint(__builtin_fmaf(qq.y, Q20_SCALE, 8.0f)));
+            } else if constexpr (T::QOUT == Q_PACKED) {
                 if ((k & 1) == 0) {
                     qhold = qq;
                 } else {
@@ -687,21 +774,6 @@ __device__ __forceinline__ void sweep(const Params &p)
             }
         };
 
-        // packed state, forward: the two biased fields of a cell (bits of 1 + q * Q_SCALE) arrive per step; every
-        // second step three byte-permutes assemble the 12-byte record of the pair and one dwordx3 store moves it
-        unsigned qbits_x = 0, qbits_y = 0;
-        auto store_state_bits = [&](int t_base, int k, unsigned fx, unsigned fy) {
-            if ((k & 1) == 0) {
-                qbits_x = fx, qbits_y = fy;
-            } else {
-                unsigned w[3];
-                w[0] = __builtin_amdgcn_perm(qbits_y, qbits_x, 0x04020100u);
-                w[1] = __builtin_amdgcn_perm(fx, qbits_y, 0x05040201u);
-                w[2] = __builtin_amdgcn_perm(fy, fx, 0x06050402u);
-                store_q(t_base, k >> 1, w);
-            }
-        };
-
         Carry cy;
         cy.a = cy.b = cy.c = 0.0;
         cy.fa = cy.fb = cy.fc = 0.f;
@@ -710,7 +782,8 @@ __device__ __forceinline__ void sweep(const Params &p)
         u64 vt_keep = edge_zero<KIND>();  // fwd passes: terminal cell's value, captured when this lane reaches it
 
         float rs[NS][K];   // staged inputs of the NEXT chunk (registers)
-        unsigned rq[3 * K / 2];  // packed Q of the current chunk, three dwords per pair of steps; a pair is refilled
+        constexpr int QREC_STEPS = Q20 ? 4 : 2, QREC_DW = Q20 ? 5 : 3;   // steps and dwords of one packed record
+        unsigned rq[QREC_DW * K / QREC_STEPS];  // packed Q of the current chunk, one record per 2 (4) steps; a record is refilled
                                  // with the same steps of the next chunk as soon as both have been consumed
         float2 rqx[K];     // exact Q rows / Qd rows: slot k holds step t0+k and is refilled right after it is consumed
         float2 rdd[K];
@@ -897,11 +970,11 @@ __device__ __forceinline__ void sweep(const Params &p)
         }
         if constexpr (T::QIN == Q_PACKED) {
 #pragma unroll
-            for (int g = 0; g < K / 2; ++g) {
+            for (int g = 0; g < K / QREC_STEPS; ++g) {
                 if constexpr (ABL_NOLOAD) {
-                    for (int j = 0; j < 3; ++j) rq[3 * g + j] = 0x20003000u + 64 * g + lane;
+                    for (int j = 0; j < QREC_DW; ++j) rq[QREC_DW * g + j] = 0x20003000u + 64 * g + lane;
                 } else {
-                    load_q(c_first * K, g, rq + 3 * g);
+                    load_q(c_first * K, g, rq + QREC_DW * g);
                 }
             }
         }
@@ -1281,7 +1354,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                             } else {
                                 // both weights with one packed multiply, their biased fields with one packed fma
                                 const f32x2 w = (f32x2){u, x} * (f32x2){tq, tq};
-                                const f32x2 f = __builtin_elementwise_fma(w, (f32x2){Q_SCALE, Q_SCALE}, (f32x2){1.0f, 1.0f});
+                                const f32x2 f = __builtin_elementwise_fma(w, (f32x2){QF_SCALE, QF_SCALE}, (f32x2){QF_BASE, QF_BASE});
                                 if constexpr (ABL_NOSTORE) { float fx = f[0], fy = f[1]; keep(fx); keep(fy); }
                                 else store_state_bits(tb, j, __float_as_uint(f[0]), __float_as_uint(f[1]));
                             }
@@ -1379,8 +1452,8 @@ __device__ __forceinline__ void sweep(const Params &p)
                                 q_sharpen(qq.x, qq.y, d * rinv);
                                 if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); }
                                 else if constexpr (QX) store_state(tb, j, qq);
-                                else store_state_bits(tb, j, __float_as_uint(__builtin_fmaf(qq.x, Q_SCALE, 1.0f)),
-                                                      __float_as_uint(__builtin_fmaf(qq.y, Q_SCALE, 1.0f)));
+                                else store_state_bits(tb, j, __float_as_uint(__builtin_fmaf(qq.x, QF_SCALE, QF_BASE)),
+                                                      __float_as_uint(__builtin_fmaf(qq.y, QF_SCALE, QF_BASE)));
                             }
                             const float an = ct * ssum;
                             float na = __builtin_amdgcn_frexp_mantf(an);
@@ -1666,10 +1739,11 @@ __device__ __forceinline__ void sweep(const Params &p)
                         if constexpr (!ABL_NOLOAD) rqx[k] = load_f2(rs_qx, t0_next, k);
                     }
                     if constexpr (T::QIN == Q_PACKED) {
-                        q0 = q_unpack(rq + 3 * (k >> 1), k & 1);
-                        q0.x *= Q_UNSCALE, q0.y *= Q_UNSCALE;
-                        if constexpr (!ABL_NOLOAD) {
-                            if ((k & 1) == (REV ? 0 : 1)) load_q(t0_next, k >> 1, rq + 3 * (k >> 1));
+                        if constexpr (Q20) q0 = q20_unpack(rq + 5 * (k >> 2), k & 3);
+                        else q0 = q_unpack(rq + 3 * (k >> 1), k & 1);
+                        q0.x *= QF_UNSCALE, q0.y *= QF_UNSCALE;
+                        if constexpr (!ABL_NOLOAD) {   // the record's last step in processing order has been consumed: refill it
+                            if ((k & (QREC_STEPS - 1)) == (REV ? 0 : QREC_STEPS - 1)) load_q(t0_next, k / QREC_STEPS, rq + QREC_DW * (k / QREC_STEPS));
                         }
                     }
                     if constexpr (T::DIN) {

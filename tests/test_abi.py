@@ -47,16 +47,15 @@ def test_version_and_limits(lib):
 
 
 def test_state_bytes(lib):
-    # Q: 6 B (two 23-bit weights) per cell of the skewed layout; Qd: float2 per cell
-    # Q: 6 B (two 23-bit weights) per cell of the skewed, padded layout (+ a tail for the launch order of
+    # Q: 5 B (two 20-bit weights) per cell of the skewed, padded layout; Qd: float2 per cell (+ a tail for the launch order of
     # variable-length batches: B ints, 256-byte granules)
     # ... and, for pairs of more than four strips, the bridge rows between the parts a pair may be cut into: per pair
     # (ceil(strips / 4) - 1) rows of roundup(M + 63, 64) + 64 granules of 8 bytes
     bridge = 256 * 1 * (576 + 64 + 40) * 8 + 256 * 2 * 4   # (+ the dispatch order of the parts: one int per workgroup)
-    assert lib.sdp_state_bytes(256, 512, 512) == 256 * 8 * 576 * 64 * 6 + 1024 + bridge
-    assert lib.sdp_state_bytes(1, 1, 1) == 1 * 1 * 64 * 64 * 6 + 256
-    assert lib.sdp_state_bytes(3, 65, 2) == 3 * 2 * 128 * 64 * 6 + 256
-    assert lib.sdp_state_bytes(2, 1024, 100) == 2 * 16 * 192 * 64 * 6 + 256 + 2 * 3 * (192 + 64 + 16) * 8 + 256
+    assert lib.sdp_state_bytes(256, 512, 512) == 256 * 8 * 576 * 64 * 5 + 1024 + bridge
+    assert lib.sdp_state_bytes(1, 1, 1) == 1 * 1 * 64 * 64 * 5 + 256
+    assert lib.sdp_state_bytes(3, 65, 2) == 3 * 2 * 128 * 64 * 5 + 256
+    assert lib.sdp_state_bytes(2, 1024, 100) == 2 * 16 * 192 * 64 * 5 + 256 + 2 * 3 * (192 + 64 + 16) * 8 + 256
     assert lib.sdp_state_d_bytes(256, 512, 512) == 256 * 8 * 576 * 64 * 8 + 1024 + bridge
     assert lib.sdp_state_d_bytes(0, 5, 5) == 0
     assert lib.sdp_state_bytes(0, 5, 5) == 0
