@@ -117,6 +117,9 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #ifndef SDP_WF
 #define SDP_WF 1  // forward sweep: try the windowed form on interior chunks
 #endif
+#ifndef SDP_BWD_HALF
+#define SDP_BWD_HALF 0  // fp32 backward sweep: boundary hand-off in halves of a chunk (see HALF) -- measured slower, off
+#endif
 #ifndef SDP_FWD_SUB
 #define SDP_FWD_SUB 1  // forward sweep: compute in WB-step blocks inside a K-step chunk (see fwd_blocks)
 #endif
@@ -1593,19 +1596,28 @@ __device__ __forceinline__ void sweep(const Params &p)
                 continue;
             }
 
-            // ---- boundary values for the edge lane: K broadcast LDS reads, off the dependency chain ----
+            // ---- boundary values for the edge lane: broadcast LDS reads, off the dependency chain ----
+            // HALF (fp32 backward sweep, one workgroup per pair; -DSDP_BWD_HALF=1): the chunk's 32 steps take their boundary
+            // values in two halves of 16 and hand their own down in two halves, each with its progress word -- the strip below
+            // then trails by 63 + 16 steps instead of 63 + 32 (three lags per pair at the headline shape: 1387 instead of 1435
+            // steps).  Built, bit-identical, measured in round 4 and NOT adopted: backward 164 -> 179 us at 256 x 512^2,
+            // 491 -> 532 at 256 x 1024^2 (same box, interleaved) -- the second wait in the middle of a chunk exposes an LDS
+            // round trip and a poll on a sweep that is waiting for memory most of the time, and that costs more than 48
+            // steps of lag return.
+            constexpr bool HALF = REV && PASS == PASS_BWD && KIND == CK_F32 && !PARTS && K == 32 && SDP_BWD_HALF;
             u64 bcv[K];
-            {
-                // fwd: lane 0 at step t0+k needs column t0+k; rev: lane 63 needs column t0+k-63
-                const int c_lo = REV ? t0 - 63 : t0;
+            // fwd: lane 0 at step t0+k needs column t0+k; rev: lane 63 needs column t0+k-63
+            const int c_lo = REV ? t0 - 63 : t0;
+            auto acquire = [&](auto k0_tag, auto k1_tag) {   // boundary values of steps t0 + k, k in [K0, K1)
+                constexpr int K0 = decltype(k0_tag)::value, K1 = decltype(k1_tag)::value;
                 int need = 0;  // progress value that guarantees those columns are published
                 if (has_pred) {
-                    if (REV) {
-                        const int lo = c_lo < 0 ? 0 : c_lo;
-                        need = (c_lo + K > 0 && c_lo < m) ? m - lo : 0;
+                    if (REV) {   // (published from the right: the lowest column decides)
+                        const int lo = c_lo + K0 < 0 ? 0 : c_lo + K0;
+                        need = (c_lo + K1 > 0 && c_lo + K0 < m) ? m - lo : 0;
                     } else {
-                        const int hi = c_lo + K < m ? c_lo + K : m;
-                        need = (c_lo < m) ? hi : 0;
+                        const int hi = c_lo + K1 < m ? c_lo + K1 : m;
+                        need = (c_lo + K0 < m) ? hi : 0;
                     }
                 }
                 if constexpr (REV && KIND == CK_F32) {
@@ -1642,21 +1654,26 @@ __device__ __forceinline__ void sweep(const Params &p)
                             p.status[1] = b, p.status[2] = s, p.status[3] = c | (PASS << 24);
                         }
                     }
-                    if (c_lo >= 0 && c_lo + K <= m) {
+                    if (c_lo + K0 >= 0 && c_lo + K1 <= m) {
 #pragma unroll
-                        for (int k = 0; k < K; ++k) bcv[k] = bnd_in[c_lo + k];
+                        for (int k = K0; k < K1; ++k) bcv[k] = bnd_in[c_lo + k];
                     } else {
 #pragma unroll
-                        for (int k = 0; k < K; ++k) {
+                        for (int k = K0; k < K1; ++k) {
                             const int col = c_lo + k;
                             bcv[k] = (col >= 0 && col < m) ? bnd_in[col] : edge_zero<KIND>();
                         }
                     }
                 } else {
 #pragma unroll
-                    for (int k = 0; k < K; ++k) bcv[k] = edge_zero<KIND>();
+                    for (int k = K0; k < K1; ++k) bcv[k] = edge_zero<KIND>();
                 }
-            }
+            };
+            using kc0 = std::integral_constant<int, 0>;
+            using kch = std::integral_constant<int, K / 2>;
+            using kc1 = std::integral_constant<int, K>;
+            if constexpr (HALF) acquire(kch{}, kc1{});   // the reverse sweep starts with the chunk's upper steps
+            else acquire(kc0{}, kc1{});
 
             // ---- staged inputs of this chunk: one burst of LDS reads, off the dependency chain ----
             float in0[K], in1[K], in2[T::SIN > 2 ? K : 1];
@@ -1722,10 +1739,11 @@ __device__ __forceinline__ void sweep(const Params &p)
             float *lo = lds_out + lane * PO + par * K;  // this lane's row, this chunk's half of the ring
 
             // ---- K steps; EDGE=false is the mask-free body for chunks fully inside the matrix ----
-            auto steps = [&](auto edge_tag) {
+            auto steps = [&](auto edge_tag, auto kk0_tag, auto kk1_tag) {   // steps kk in [KK0, KK1) of the chunk, in processing order
                 constexpr bool EDGE = decltype(edge_tag)::value;
+                constexpr int KK0 = decltype(kk0_tag)::value, KK1 = decltype(kk1_tag)::value;
 #pragma unroll
-                for (int kk = 0; kk < K; ++kk) {
+                for (int kk = KK0; kk < KK1; ++kk) {
                     const int k = REV ? K - 1 - kk : kk;
                     const int t = t0 + k;
                     const int col = t - lane;
@@ -2056,12 +2074,12 @@ __device__ __forceinline__ void sweep(const Params &p)
                     --wf_skip;
                 }
             }
-            if (!wf_done) {
+            if (!wf_done && !HALF) {
 #pragma unroll
                 for (int sb = 0; sb < K / WB; ++sb) wf_frames[sb] = FRAME_NONE;
                 prepass();
-                if (interior) steps(std::false_type{});
-                else steps(std::true_type{});
+                if (interior) steps(std::false_type{}, kc0{}, kc1{});
+                else steps(std::true_type{}, kc0{}, kc1{});
             }
 
             // The normalised form publishes its values in one frame per block as well whenever they fit (exact
@@ -2091,27 +2109,29 @@ __device__ __forceinline__ void sweep(const Params &p)
                 }
             }
 
-            // ---- publish K boundary values for the next strip (one lane, K LDS writes) ----
-            if (has_succ) {
+            // ---- publish boundary values for the next strip (one lane), then the progress word ----
+            auto publish_range = [&](auto k0_tag, auto k1_tag, int *wf_frames_) {   // values of steps t0 + k, k in [K0, K1)
+                constexpr int K0 = decltype(k0_tag)::value, K1 = decltype(k1_tag)::value;
+                if (!has_succ) return;
                 // fwd: lane 63 produced column t0+k-63 at step k; rev: lane 0 produced column t0+k
-                const int c_lo = REV ? t0 : t0 - 63;
+                const int p_lo = REV ? t0 : t0 - 63;
                 if (lane == PUB_LANE) {
-                    if (c_lo >= 0 && c_lo + K <= m) {
+                    if (p_lo + K0 >= 0 && p_lo + K1 <= m) {
 #pragma unroll
-                        for (int k = 0; k < K; ++k) bnd_out[c_lo + k] = (slot_t)hist[k];
+                        for (int k = K0; k < K1; ++k) bnd_out[p_lo + k] = (slot_t)hist[k];
                     } else {
 #pragma unroll
-                        for (int k = 0; k < K; ++k) {
-                            const int col = c_lo + k;
+                        for (int k = K0; k < K1; ++k) {
+                            const int col = p_lo + k;
                             if (col >= 0 && col < m) bnd_out[col] = (slot_t)hist[k];
                         }
                     }
                 }
                 int done;  // columns published so far (fwd: from the left; rev: from the right)
                 if (REV) {
-                    done = t0 < m ? m - t0 : 0;
+                    done = t0 + K0 < m ? m - (t0 + K0) : 0;
                 } else {
-                    const int hi = t0 + K - 63;
+                    const int hi = t0 + K1 - 63;
                     done = hi < 0 ? 0 : (hi > m ? m : hi);
                 }
                 // LDS executes a wave's DS instructions in order, so the data written above is visible to
@@ -2119,7 +2139,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                 if constexpr (PASS == PASS_FWD && KIND == CK_EXP) {
                     if (lane == PUB_LANE) {
 #pragma unroll
-                        for (int sb = 0; sb < K / WB; ++sb) frm_out[c * (K / WB) + sb] = wf_frames[sb];
+                        for (int sb = 0; sb < K / WB; ++sb) frm_out[c * (K / WB) + sb] = wf_frames_[sb];
                     }
                 }
                 if (lane == PUB_LANE && !(SDP_EXP_BUILD && (p.dbg & 8))) lds_store_i32(prog + 4 * oword, obase + done);
@@ -2133,6 +2153,18 @@ __device__ __forceinline__ void sweep(const Params &p)
                             __builtin_amdgcn_raw_buffer_store_b64((u32x2){gv, 0u}, rs_xo, lane < K ? (unsigned)(col * 8) : OOB, 0, XB_AUX);
                     }
                 }
+            };
+            if constexpr (HALF) {
+                // upper half of the chunk (steps t0 + 31 .. t0 + 16), hand it down, lower half, hand it down
+                if (interior) steps(std::false_type{}, kc0{}, kch{});
+                else steps(std::true_type{}, kc0{}, kch{});
+                publish_range(kch{}, kc1{}, nullptr);
+                acquire(kc0{}, kch{});
+                if (interior) steps(std::false_type{}, kch{}, kc1{});
+                else steps(std::true_type{}, kch{}, kc1{});
+                publish_range(kc0{}, kch{}, nullptr);
+            } else {
+                publish_range(kc0{}, kc1{}, wf_frames);
             }
 
             // ---- flush: one memory-aligned K-element block per row (see fo_* above) ----

@@ -212,7 +212,10 @@ int sdp_loss_backward_f32(const float *ref, const float *pred, const float *G, c
                           const float *scale, float *grad, int B, int N, int M, int kind, int device,
                           void *stream);
 
-/* The adjoint forward sweep with the loss's gradient as its seed, formed inside the kernel: Ztheta[b,i,j] =
+/* EXPERIMENTAL -- parity-equal to the unfused sequence, but SLOWER than it (B=256, 512 x 512: 2.02 vs 1.62 ms per training
+ * step; the seed's divisions sit on the sweep's dependency chain and cost more than the 268 MB tensor they save).  Kept
+ * for callers who are short of memory, not of time; deepblast_amd.losses uses the unfused kernels by default.
+ * The adjoint forward sweep with the loss's gradient as its seed, formed inside the kernel: Ztheta[b,i,j] =
  * scale[b] * d(term)/d(pred) where G != 0 (and inside the pair's block), 0 elsewhere -- exactly what
  * sdp_loss_backward_f32 would write and sdp_adjoint_forward_f32 would read back, without the (B,N,M) tensor in
  * between (training: decode -> masked loss on the alignment matrix -> backward; reference: losses.py:9-118 applied to

@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FILES = ["deepblast_amd/csrc/sdp_kernels.hip", "deepblast_amd/csrc/sdp_kernels.h", "deepblast_amd/csrc/sdp_api.hip", "deepblast_amd/csrc/sdp_comm.hip",
-         "include/sdp.h"]
+         "deepblast_amd/csrc/sdp_ref.hip", "include/sdp.h"]
 
 
 def source_sha():
