@@ -5,13 +5,13 @@
 # modes, FETCH_SIZE and WRITE_SIZE counter passes (separate runs, kernel-trace only -- gpurun refuses pmc + other
 # traces), and the source hash the numbers belong to.  Afterwards, in the build container:
 #   python tools/collect_profiles.py <tag>    -> profiles/<tag>_*.csv|json + profiles/traffic.json (stamped)
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/round_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 python tools/source_stamp.py > $OUT/stamp.json
 if [ "$2" != "quick" ]; then
-  timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $OUT/pytest_gpu.txt
+  timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $OUT/pytest_gpu.txt
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee $OUT/smoke.txt
   # the harsher fuzz (steep / flat scores, forbidden gaps, tiny and thin shapes, many pairs, per-pair lengths): the
   # suite did not catch the one kernel bug of round 2, this did
