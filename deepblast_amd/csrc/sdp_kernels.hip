@@ -117,6 +117,9 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #ifndef SDP_WF
 #define SDP_WF 1  // forward sweep: try the windowed form on interior chunks
 #endif
+#ifndef SDP_SKIP_DEAD
+#define SDP_SKIP_DEAD 0  // packed state: records of lanes outside the matrix neither written nor read (see q20_dead) -- measured slower, off
+#endif
 #ifndef SDP_BWD_HALF
 #define SDP_BWD_HALF 0  // fp32 backward sweep: boundary hand-off in halves of a chunk (see HALF) -- measured slower, off
 #endif
@@ -673,10 +676,20 @@ __device__ __forceinline__ void sweep(const Params &p)
         auto q20_soff_b = [&](int t_base, int g4) { return (unsigned)(t_base >> 5) * p.st_us + 8192u + (unsigned)((((t_base >> 2) & 7) + g4) * 256); };
         typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
         typedef unsigned u32x4q __attribute__((ext_vector_type(4)));
+        // Records of the ramps (-DSDP_SKIP_DEAD=1): a lane whose four steps of a record all lie left of the matrix (the
+        // strip's head ramp: lane > last step), right of it (tail ramp: first step - lane >= m) or below it (lane >= rows) has
+        // nothing to say in it; with the switch on such records are neither written nor read (their offset is sent out of
+        // range), so that the whole 128-byte lines of the 12.5 % skew padding that hold nothing else never cross the fabric.
+        // Built and measured in round 4, as the per-lane variant was in round 1, and again SLOWER: forward 210 -> 215 us,
+        // backward 161 -> 168 us at 256 x 512^2, 784 -> 827 / 515 -> 517 at 256 x 1024^2 (same box, interleaved) -- the
+        // lines at the edge of the ramp become partial writes / reads, which cost the memory system more than the dead
+        // bytes saved.  Off.
+        auto q20_dead = [&](int t_first) { return SDP_SKIP_DEAD && (lane > t_first + 3 || t_first - lane >= m || lane >= rows); };
         auto load_q = [&](int t_base, int g, unsigned *dst) {  // 24-bit: steps t_base + 2g, + 1 (3 dwords); 20-bit: steps t_base + 4g .. + 3 (5 dwords)
             if constexpr (Q20) {
-                const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_q, q_lane + (g & 3) * 1024, q20_soff_a(t_base, g & ~3), AUX_ST_LOAD);
-                const unsigned v4 = __builtin_amdgcn_raw_buffer_load_b32(rs_q, lane * 4 + (g & 3) * 256, q20_soff_b(t_base, g & ~3), AUX_ST_LOAD);
+                const bool dead = q20_dead(t_base + 4 * g);
+                const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_q, dead ? OOB : q_lane + (g & 3) * 1024, q20_soff_a(t_base, g & ~3), AUX_ST_LOAD);
+                const unsigned v4 = __builtin_amdgcn_raw_buffer_load_b32(rs_q, dead ? OOB : lane * 4 + (g & 3) * 256, q20_soff_b(t_base, g & ~3), AUX_ST_LOAD);
                 const unsigned v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
                 dst[0] = v0, dst[1] = v1, dst[2] = v2, dst[3] = v3, dst[4] = v4;
             } else {
@@ -694,9 +707,10 @@ __device__ __forceinline__ void sweep(const Params &p)
             if constexpr (Q20) {
                 u32x4q v;
                 v[0] = src[0], v[1] = src[1], v[2] = src[2], v[3] = src[3];
-                __builtin_amdgcn_raw_buffer_store_b128(v, rs_q, q_lane + (g & 3) * 1024, q20_soff_a(t_base, g & ~3), AUX_ST_STORE);
+                const bool dead = q20_dead(t_base + 4 * g);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_q, dead ? OOB : q_lane + (g & 3) * 1024, q20_soff_a(t_base, g & ~3), AUX_ST_STORE);
                 asm volatile("s_nop 1" : : "v"(v) : "memory");
-                __builtin_amdgcn_raw_buffer_store_b32(src[4], rs_q, lane * 4 + (g & 3) * 256, q20_soff_b(t_base, g & ~3), AUX_ST_STORE);
+                __builtin_amdgcn_raw_buffer_store_b32(src[4], rs_q, dead ? OOB : lane * 4 + (g & 3) * 256, q20_soff_b(t_base, g & ~3), AUX_ST_STORE);
             } else {
                 u32x3 v;
                 v[0] = src[0], v[1] = src[1], v[2] = src[2];
