@@ -121,7 +121,7 @@ size_t lds_bytes(int pass, int K, int W, int mcap, size_t *stage_off, int nin = 
 {
     const int nslot = 2;  // boundary rows are shared by alternate strips (see the kernel)
     size_t off = (size_t)nslot * mcap * sdp::boundary_slot_bytes(pass) + 64 + (size_t)nslot * sdp::FRAME_CAP * 4;  // boundary rows, progress words, frame words
-    off = (off + 15) & ~(size_t)15;
+    off = ((off + 15) & ~(size_t)15) + 16;   // (+ 16: the staged-output ring of wave 0 writes one float in front of itself, see FLUSH2)
     if (stage_off) *stage_off = off;
     return off + (size_t)W * sdp::stage_floats(pass, K, nin) * sizeof(float);
 }

@@ -117,6 +117,18 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #ifndef SDP_WF
 #define SDP_WF 1  // forward sweep: try the windowed form on interior chunks
 #endif
+#ifndef SDP_TOPLOAD
+#define SDP_TOPLOAD 1  // packed reverse sweep: the next chunk's state records are loaded in one burst at the top of the iteration
+#endif
+#ifndef SDP_REFILL_BARRIER
+#define SDP_REFILL_BARRIER 1
+#endif
+#ifndef SDP_PROLOGUE_WAIT
+#define SDP_PROLOGUE_WAIT 1  // reverse sweeps: the prologue's loads are waited for before the chunk loop (see the chunk loop's prologue)
+#endif
+#ifndef SDP_FLUSH2
+#define SDP_FLUSH2 1  // reverse sweeps, aligned K = 32 builds: outputs leave two columns per lane (see FLUSH2)
+#endif
 #ifndef SDP_SKIP_DEAD
 #define SDP_SKIP_DEAD 0  // packed state: records of lanes outside the matrix neither written nor read (see q20_dead) -- measured slower, off
 #endif
@@ -284,6 +296,13 @@ __device__ __forceinline__ float q20_field(unsigned u)  // field in the low 20 b
     return __uint_as_float((u & 0xfffffu) | 0x41000000u) - 8.0f;
 }
 // (f - 8) of both weights of cell `sub` (0..3) of a five-dword record; the caller multiplies by Q20_UNSCALE
+typedef unsigned q20_vec __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float2 q20_unpack(const unsigned *w, int sub);
+__device__ __forceinline__ float2 q20_unpack(q20_vec a, unsigned b, int sub)   // dwords 0-3 as they were loaded, dword 4
+{
+    const unsigned w[5] = {a[0], a[1], a[2], a[3], b};
+    return q20_unpack(w, sub);
+}
 __device__ __forceinline__ float2 q20_unpack(const unsigned *w, int sub)
 {
     switch (sub) {
@@ -685,13 +704,32 @@ __device__ __forceinline__ void sweep(const Params &p)
         // lines at the edge of the ramp become partial writes / reads, which cost the memory system more than the dead
         // bytes saved.  Off.
         auto q20_dead = [&](int t_first) { return SDP_SKIP_DEAD && (lane > t_first + 3 || t_first - lane >= m || lane >= rows); };
-        auto load_q = [&](int t_base, int g, unsigned *dst) {  // 24-bit: steps t_base + 2g, + 1 (3 dwords); 20-bit: steps t_base + 4g .. + 3 (5 dwords)
+        // 20-bit fields: the ring of prefetched records keeps the dwordx4 of a record AS THE VECTOR it was loaded as.  Kept as
+        // five scalars (rounds 1-3 did that for the dwordx3 records too) each dword is a loop-carried value of its own, the
+        // load needs four consecutive registers for them, and the compiler resolved that by loading into other registers and
+        // COPYING all records of the next chunk into place at the end of every iteration -- behind an `s_waitcnt vmcnt(0)`:
+        // the prefetch distance was the rest of the iteration, not a chunk, and the sweep ran at memory latency.
+        u32x4q rq4[Q20 ? K / 4 : 1];
+        unsigned rq1[Q20 ? K / 4 : 1];
+        // ... and the records of the NEXT chunk are a second set, loaded in one burst at the top of the iteration (TOPLOAD) and
+        // moved over at its end: the wait for them then sits a whole iteration behind their issue.  (Refilling a slot of the
+        // first set right after its last use -- the scheme of rounds 1-3 -- reads as the same thing, but the compiler gave the
+        // refills registers of their own anyway and moved them over at the end of the iteration, behind a vmcnt(0) that the
+        // loads issued during the last steps had had a few hundred cycles to meet.)
+        constexpr bool TOPLOAD = Q20 && REV && T::QIN == Q_PACKED && SDP_TOPLOAD;
+        u32x4q rq4n[TOPLOAD ? K / 4 : 1];
+        unsigned rq1n[TOPLOAD ? K / 4 : 1];
+        auto load_q20 = [&](int t_base, int g) {   // steps t_base + 4g .. + 3 -> rq4[g], rq1[g] (TOPLOAD: the next chunk's set)
+            const bool dead = q20_dead(t_base + 4 * g);
+            const u32x4q va = __builtin_amdgcn_raw_buffer_load_b128(rs_q, dead ? OOB : q_lane + (g & 3) * 1024, q20_soff_a(t_base, g & ~3), AUX_ST_LOAD);
+            const unsigned vb = __builtin_amdgcn_raw_buffer_load_b32(rs_q, dead ? OOB : lane * 4 + (g & 3) * 256, q20_soff_b(t_base, g & ~3), AUX_ST_LOAD);
+            if constexpr (TOPLOAD) rq4n[g] = va, rq1n[g] = vb;
+            else rq4[g] = va, rq1[g] = vb;
+        };
+        auto load_q = [&](int t_base, int g, unsigned *dst) {  // 24-bit: steps t_base + 2g, + 1 (3 dwords)
             if constexpr (Q20) {
-                const bool dead = q20_dead(t_base + 4 * g);
-                const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_q, dead ? OOB : q_lane + (g & 3) * 1024, q20_soff_a(t_base, g & ~3), AUX_ST_LOAD);
-                const unsigned v4 = __builtin_amdgcn_raw_buffer_load_b32(rs_q, dead ? OOB : lane * 4 + (g & 3) * 256, q20_soff_b(t_base, g & ~3), AUX_ST_LOAD);
-                const unsigned v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
-                dst[0] = v0, dst[1] = v1, dst[2] = v2, dst[3] = v3, dst[4] = v4;
+                (void)dst;
+                load_q20(t_base, g);
             } else {
                 const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs_q, q_lane + (g & 3) * 768, q_soff(t_base, g & ~3), AUX_ST_LOAD);
                 const unsigned v0 = v[0], v1 = v[1], v2 = v[2];
@@ -800,10 +838,15 @@ __device__ __forceinline__ void sweep(const Params &p)
 
         float rs[NS][K];   // staged inputs of the NEXT chunk (registers)
         constexpr int QREC_STEPS = Q20 ? 4 : 2, QREC_DW = Q20 ? 5 : 3;   // steps and dwords of one packed record
-        unsigned rq[QREC_DW * K / QREC_STEPS];  // packed Q of the current chunk, one record per 2 (4) steps; a record is refilled
+        unsigned rq[Q20 ? 1 : QREC_DW * K / QREC_STEPS];  // 24-bit fields: packed Q of the current chunk, one record per 2 steps; a record is refilled
                                  // with the same steps of the next chunk as soon as both have been consumed
-        float2 rqx[K];     // exact Q rows / Qd rows: slot k holds step t0+k and is refilled right after it is consumed
+        float2 rqx[K];     // exact Q rows / Qd rows of the current chunk: slot k holds step t0+k
         float2 rdd[K];
+        // TOPLOAD_X: the rows of the next chunk are a second set, loaded in one burst at the top of the iteration and moved over
+        // at its end (see TOPLOAD); otherwise a slot is refilled right after it has been consumed
+        constexpr bool TOPLOAD_X = SDP_TOPLOAD != 0 && (T::QIN == Q_EXACT || T::DIN);
+        float2 rqxn[(TOPLOAD_X && T::QIN == Q_EXACT) ? K : 1];
+        float2 rddn[(TOPLOAD_X && T::DIN) ? K : 1];
 
         // Staged INPUT geometry.  Row-major tensors enter as K-column blocks, four columns (one dwordx4) per
         // lane; row r's blocks start at columns K*j - (r mod 4).  During chunk c (steps cK .. cK+K-1) row r needs
@@ -876,10 +919,11 @@ __device__ __forceinline__ void sweep(const Params &p)
         // only, a row pitch that is not a multiple of 32 floats made every 128-byte store straddle two lines: the
         // backward sweep ran 2.1-2.4x slower at M = 516 than at M = 512.)  fo_off0 is the LDS index when the current
         // chunk has parity 0, fo_dk the change when it has parity 1, fo_voff the global byte offset (row i0, t0 = 0).
-        int fo_off0[K], fo_dk[K];
-        unsigned fo_voff[K];
+        constexpr bool FLUSH2 = T::SOUT > 0 && !GEN && K == 32 && SDP_FLUSH2;   // (see below)
+        int fo_off0[FLUSH2 ? 1 : K], fo_dk[FLUSH2 ? 1 : K];
+        unsigned fo_voff[FLUSH2 ? 1 : K];
         bool fo_need_tail = false;
-        if constexpr (T::SOUT > 0) {
+        if constexpr (T::SOUT > 0 && !FLUSH2) {
             const int beta = GEN ? (int)(((uintptr_t)(p.sout + b_out * plane_elems) >> 2) & (uintptr_t)(K - 1)) : 0;
             fo_need_tail = GEN && (beta != 0 || (ld & (K - 1)) != 0);
 #pragma unroll
@@ -893,6 +937,28 @@ __device__ __forceinline__ void sweep(const Params &p)
                 fo_voff[k] = (unsigned)((r * ld - (r - rho) + s_l) * 4);   // column s_l - D_r of row r
             }
         }
+
+        // Plain flushes of the aligned K = 32 builds move TWO columns per lane (FLUSH2): 16 ds_read_b64 + 16
+        // buffer_store_dwordx2 per chunk instead of 32 + 32 dword operations.  A wave can have 63 memory instructions in flight
+        // (vmcnt is 6 bits); with 32 dword stores of 256 bytes next to the 16 state loads a chunk is 48 of them, little more
+        // than one chunk's worth of bytes ahead of the sweep, and cycle stamps (tools/bwd_trace.py) showed the wave stalling at
+        // its next memory instruction once real memory latency applied (everything cache-served: 124 us, real: 160).
+        // Row r's block is elements rho_r + e of the ring, e = 0..31; with PO = 65 the pair (e, e + 1), e even, is 8-byte aligned
+        // in LDS (r PO + rho_r = 66 r - 32 floor(r / 32)).  A pair never straddles the two halves of the ring when the current
+        // chunk has parity 0; with parity 1 the pair rho_r + e = 31 would be ring positions 63 and 0, so every chunk also
+        // writes its step 31 to position -1 of the row (the unused pad of the row above), and that pair is read from there.
+        // Lanes 16 a .. 16 a + 15 of an instruction take rows x + 8 (a >> 1) + 16 (a & 1): the two rows of a 32-lane LDS group
+        // are 16 apart, i.e. 32 banks apart.
+        // Nothing of this geometry is kept in per-instruction registers (rounds 1-3 held three 32-entry index arrays across
+        // the chunk loop): a lane's LDS index and global offset are one per-lane base each plus a constant of the instruction.
+        // A wave's VALU sees 256 registers; whatever lives beyond that sits in AGPRs, and the prefetched state records of the
+        // next chunk were what the compiler put there -- to be copied back at the end of every iteration behind a vmcnt(0).
+        //   instruction k2 (0..15), lane -> row r = c + rl, c = (k2 & 7) + 32 (k2 >> 3), rl = 8 (a >> 1) + 16 (a & 1), a = lane >> 4;
+        //   columns e_l, e_l + 1 of the row's block, e_l = 2 (lane & 15);  rho_r = r & 31 = (k2 & 7) + rl;  D_r = r - rho_r = 32 (k2 >> 3)
+        //   LDS index (parity 0) = r PO + rho_r + e_l = [c PO + (k2 & 7)] + f2_l,   f2_l = rl PO + rl + e_l
+        //   global float offset  = r ld - D_r + e_l   = [c ld - 32 (k2 >> 3)] + f2_g, f2_g = rl ld + e_l
+        const int f2_rl = 8 * ((lane >> 4) >> 1) + 16 * ((lane >> 4) & 1), f2_el = 2 * (lane & 15);
+        const int f2_l = f2_rl * PO + f2_rl + f2_el, f2_g = f2_rl * ld + f2_el;
 
         // Chunk c of this strip touches only real cells of a full, unmasked strip: no masking needed.
         auto chunk_interior = [&](int c) { return plain_strip && c * K >= 63 && c * K + K < m; };
@@ -989,9 +1055,11 @@ __device__ __forceinline__ void sweep(const Params &p)
 #pragma unroll
             for (int g = 0; g < K / QREC_STEPS; ++g) {
                 if constexpr (ABL_NOLOAD) {
-                    for (int j = 0; j < QREC_DW; ++j) rq[QREC_DW * g + j] = 0x20003000u + 64 * g + lane;
+                    if constexpr (Q20) rq4[g] = (u32x4q){0x20003000u + 64 * g + lane, 0x20003000u, 0x20003000u, 0x20003000u}, rq1[g] = 0x20003000u;
+                    else for (int j = 0; j < QREC_DW; ++j) rq[QREC_DW * g + j] = 0x20003000u + 64 * g + lane;
                 } else {
-                    load_q(c_first * K, g, rq + QREC_DW * g);
+                    load_q(c_first * K, g, Q20 ? rq : rq + QREC_DW * g);
+                    if constexpr (TOPLOAD) rq4[g] = rq4n[g], rq1[g] = rq1n[g];
                 }
             }
         }
@@ -1006,6 +1074,14 @@ __device__ __forceinline__ void sweep(const Params &p)
         write_block(c_first);
         load_block(c_first + 1);
         write_block(c_first + 1);
+        // Every load of the prologue has returned before the chunk loop is entered (vmcnt(0), expcnt / lgkmcnt untouched) -- said
+        // with the builtin, which the compiler's own wait-count bookkeeping understands.  Without it the state records of the
+        // FIRST chunk are "pending loads into v[0:31]" on the loop-entry path only; the compiler merges that with the back
+        // edge, and every iteration then waited (`s_waitcnt vmcnt(1)` in front of the first reuse of v0 as a temporary) until
+        // all but one of the loads it had just issued for the NEXT chunk were back: the prefetch distance was not a chunk but
+        // the few hundred cycles up to that point, and the reverse sweeps ran at memory latency (round 4, cycle stamps:
+        // 900-2200 cycles per chunk in a phase that issues eight LDS writes).  The price: one exposed latency per strip.
+        if constexpr ((REV || T::QIN == Q_EXACT) && SDP_PROLOGUE_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);
 
         // ---- forward sweep, exp domain: the K steps of a chunk are computed in blocks of WB = 16 ----
         // The chunk (K steps) stays the unit of the memory pipeline -- staged input blocks, state prefetch distance --
@@ -1160,7 +1236,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                     // experiments build, sdp_set_trace: shader-cycle stamps of this block -- [pair / 64][wave][strip round][block][4]
                     auto stamp = [&](int k) {
                         if constexpr (SDP_EXP_BUILD != 0) {
-                            if (p.trace && (b & 63) == 0 && b < 256 && lane == 0 && (parts ? part < 4 : sidx / W < 2) && tb / WB < 40)
+                            if (p.trace && !(p.dbg & 1024) && (b & 63) == 0 && b < 256 && lane == 0 && (parts ? part < 4 : sidx / W < 2) && tb / WB < 40)
                                 p.trace[((((b >> 6) * 4 + wave) * 4 + (parts ? part : sidx / W)) * 40 + tb / WB) * 8 + k] = __builtin_readcyclecounter();   // (k < 4 used)
                         }
                     };
@@ -1532,20 +1608,48 @@ __device__ __forceinline__ void sweep(const Params &p)
         };
 
         // ---- output flush after a chunk (reverse sweeps) ----
-        auto flush_out = [&](int t0, int par) {
+        // `active` = false: nothing to flush yet (first iteration) -- the same instructions run with every offset out of range.
+        // The flush is branch-free on purpose, and so is its place in the loop: the compiler computes the vmcnt of a wait for
+        // a state record (loaded one iteration earlier) from the memory instructions it is SURE were issued since, and a
+        // conditional flush counted as zero stores -- every chunk then waited until its own, just issued, output stores had
+        // been acknowledged by memory before it touched the first record (`s_waitcnt vmcnt(14)` where 30 were in flight:
+        // a write round trip per chunk, the 35 us between the backward sweep on cache-served tensors and on real ones).
+        auto flush_out = [&](int t0, int par, bool active) {
             if constexpr (T::SOUT > 0) {
                 const int ubase = (i0 * ld + t0) * 4;
-                // all K*64 elements are real cells: rows of a full strip, columns within t0-63 .. t0+2K-2 (D_r in (r-K, r])
-                // (aligned pitch: D_r = K floor(r/K), columns t0-K*(64/K-1) .. t0+K-1)
-                const bool flush_plain = rows == 64 && (fo_need_tail ? (t0 >= 64 && t0 + 2 * K <= m) : (t0 >= K * (64 / K - 1) && t0 + K <= m));
-                if (flush_plain) {
-                    float vals[K];
+                if constexpr (FLUSH2) {
+                    if ((m & 1) == 0) {   // (uniform)
+                        float2 vals[K / 2];
 #pragma unroll
-                    for (int k = 0; k < K; ++k) vals[k] = lds_out[fo_off0[k] + par * fo_dk[k]];
+                        for (int k2 = 0; k2 < K / 2; ++k2) {
+                            const int sfull = (k2 & 7) + f2_rl + f2_el;
+                            const int d1 = sfull < K - 1 ? K : -K;   // parity 1: the other half of the ring (sfull = K - 1: position -1)
+                            const int idx = ((k2 & 7) + 32 * (k2 >> 3)) * PO + (k2 & 7) + f2_l + (par ? d1 : 0);
+                            vals[k2] = *reinterpret_cast<const float2 *>(__builtin_assume_aligned(lds_out + idx, 8));
+                        }
 #pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        if constexpr (ABL_NOSTORE) keep(vals[k]);
-                        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vals[k]), rs_out, fo_voff[k], ubase, AUX_OUT_STORE);
+                        for (int k2 = 0; k2 < K / 2; ++k2) {
+                            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                            const int c_r = (k2 & 7) + 32 * (k2 >> 3);
+                            const int row = c_r + f2_rl;
+                            const int col = t0 - 32 * (k2 >> 3) + f2_el;   // even: the pair (col, col + 1) is inside or outside together (m even)
+                            const bool ok = active && (unsigned)col < (unsigned)m && (i0 + row) < n;
+                            const unsigned off = ok ? (unsigned)((f2_g + c_r * ld - 32 * (k2 >> 3)) * 4 + ubase) : OOB;
+                            if constexpr (ABL_NOSTORE) { keep(vals[k2].x); keep(vals[k2].y); }
+                            else __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(vals[k2].x), __float_as_uint(vals[k2].y)}, rs_out, off, 0, AUX_OUT_STORE);
+                        }
+                    } else {   // an odd number of columns (per-pair lengths): a column at a time, indices formed on the spot
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            const int row = k * RPI + r_l, rho = row & (K - 1), sfull = rho + s_l;
+                            const int idx = row * PO + sfull + (par ? (sfull >= K ? -K : K) : 0);
+                            const float v = lds_out[idx];
+                            const int col = t0 - (row - rho) + s_l;
+                            const bool ok = active && (unsigned)col < (unsigned)m && (i0 + row) < n;
+                            const unsigned off = ok ? (unsigned)((row * ld - (row - rho) + s_l) * 4 + ubase) : OOB;
+                            if constexpr (ABL_NOSTORE) { unsigned vv = __float_as_uint(v) ^ off; keep(vv); }
+                            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, off, 0, AUX_OUT_STORE);
+                        }
                     }
                 } else {
                     float vals[K];
@@ -1555,13 +1659,13 @@ __device__ __forceinline__ void sweep(const Params &p)
                     for (int k = 0; k < K; ++k) {
                         const int row = k * RPI + r_l;
                         const int col = t0 + (int)(fo_voff[k] >> 2) - row * ld;   // t0 - D_row + s_l (fo_voff >= 0: D_r <= r)
-                        const bool ok = (unsigned)col < (unsigned)m && (i0 + row) < n;
+                        const bool ok = active && (unsigned)col < (unsigned)m && (i0 + row) < n;
                         const unsigned off = ok ? fo_voff[k] + (unsigned)ubase : OOB;
                         if constexpr (ABL_NOSTORE) {
                             unsigned vv = __float_as_uint(vals[k]) ^ off;
                             keep(vv);
                         } else {
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vals[k]), rs_out, off, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vals[k]), rs_out, off, 0, AUX_OUT_STORE);
                         }
                     }
                 }
@@ -1576,8 +1680,37 @@ __device__ __forceinline__ void sweep(const Params &p)
         const int nflush = T::SOUT > 0 ? (fo_need_tail ? 2 : 1) : 0;
         int pf_t0 = 0, pf_par = 0;
         for (int ci = 0; ci < nchunks + nflush; ++ci) {
+            // experiments build, sdp_set_trace, backward sweep: per chunk (slot = position in processing order) cycle stamps
+            // 0 top, 1 previous chunk's outputs flushed, 2 boundary values there, 3 steps done, 4 published
+            auto stamp_rev = [&](int k) {
+                if constexpr (SDP_EXP_BUILD != 0 && PASS == PASS_BWD) {
+                    if (p.trace && (p.dbg & 1024) && (b & 63) == 0 && b < 256 && lane == 0 && (parts ? part < 4 : sidx / W < 2) && ci < 40)
+                        p.trace[((((b >> 6) * 4 + wave) * 4 + (parts ? part : sidx / W)) * 40 + ci) * 8 + k] = __builtin_readcyclecounter();
+                }
+            };
+            stamp_rev(0);
+            if constexpr (TOPLOAD_X && !ABL_NOLOAD) {
+                if (ci < nchunks) {   // (uniform; the extra flush iterations load nothing)
+                    const int c_ = REV ? nchunks - 1 - ci : ci;
+                    const int tn = (ci + 1 < nchunks) ? (c_ + dir) * K : c_ * K;   // the last chunk re-reads its own rows: harmless
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        if constexpr (T::QIN == Q_EXACT) rqxn[k] = load_f2(rs_qx, tn, k);
+                        if constexpr (T::DIN) rddn[k] = load_d(tn, k);
+                    }
+                }
+            }
+            if constexpr (TOPLOAD) {
+                if (ci < nchunks) {   // (uniform; the extra flush iterations load nothing)
+                    const int c_ = nchunks - 1 - ci;
+                    const int tn = (ci + 1 < nchunks) ? (c_ - 1) * K : c_ * K;   // the last chunk re-reads its own records: harmless
+#pragma unroll
+                    for (int g = 0; g < K / 4; ++g) load_q20(tn, g);
+                }
+            }
             if constexpr (T::SOUT > 0) {
-                if (ci > 0) flush_out(pf_t0, pf_par);
+                flush_out(pf_t0, pf_par, ci > 0);
+                stamp_rev(1);
                 if (ci >= nchunks) {
                     pf_t0 = -K, pf_par = 1;
                     continue;
@@ -1594,7 +1727,7 @@ __device__ __forceinline__ void sweep(const Params &p)
             // experiments build, sdp_set_trace: stamps 4..7 of a chunk's two block slots bracket the chunk's memory pipeline
             auto stamp_chunk = [&](int blk, int k) {
                 if constexpr (SDP_EXP_BUILD != 0 && PASS == PASS_FWD) {
-                    if (p.trace && (b & 63) == 0 && b < 256 && lane == 0 && (parts ? part < 4 : sidx / W < 2) && blk < 40)
+                    if (p.trace && !(p.dbg & 1024) && (b & 63) == 0 && b < 256 && lane == 0 && (parts ? part < 4 : sidx / W < 2) && blk < 40)
                         p.trace[((((b >> 6) * 4 + wave) * 4 + (parts ? part : sidx / W)) * 40 + blk) * 8 + k] = __builtin_readcyclecounter();
                 }
             };
@@ -1688,6 +1821,7 @@ __device__ __forceinline__ void sweep(const Params &p)
             using kc1 = std::integral_constant<int, K>;
             if constexpr (HALF) acquire(kch{}, kc1{});   // the reverse sweep starts with the chunk's upper steps
             else acquire(kc0{}, kc1{});
+            stamp_rev(2);
 
             // ---- staged inputs of this chunk: one burst of LDS reads, off the dependency chain ----
             float in0[K], in1[K], in2[T::SIN > 2 ? K : 1];
@@ -1768,19 +1902,26 @@ __device__ __forceinline__ void sweep(const Params &p)
                     float2 q0, q1;
                     if constexpr (T::QIN == Q_EXACT) {
                         q0 = rqx[k];
-                        if constexpr (!ABL_NOLOAD) rqx[k] = load_f2(rs_qx, t0_next, k);
+                        if constexpr (!ABL_NOLOAD && !TOPLOAD_X) rqx[k] = load_f2(rs_qx, t0_next, k);
                     }
                     if constexpr (T::QIN == Q_PACKED) {
-                        if constexpr (Q20) q0 = q20_unpack(rq + 5 * (k >> 2), k & 3);
+                        if constexpr (Q20) q0 = q20_unpack(rq4[k >> 2], rq1[k >> 2], k & 3);
                         else q0 = q_unpack(rq + 3 * (k >> 1), k & 1);
                         q0.x *= QF_UNSCALE, q0.y *= QF_UNSCALE;
                         if constexpr (!ABL_NOLOAD) {   // the record's last step in processing order has been consumed: refill it
-                            if ((k & (QREC_STEPS - 1)) == (REV ? 0 : QREC_STEPS - 1)) load_q(t0_next, k / QREC_STEPS, rq + QREC_DW * (k / QREC_STEPS));
+                            if (!TOPLOAD && (k & (QREC_STEPS - 1)) == (REV ? 0 : QREC_STEPS - 1)) {
+                                // (the refill must stay BEHIND the last use of what it overwrites: hoisted above it by the
+                                //  scheduler, old and new record are alive together, get different registers, and the new
+                                //  ones are copied into place at the end of the iteration behind a vmcnt(0))
+                                if constexpr (SDP_REFILL_BARRIER) __builtin_amdgcn_sched_barrier(0);
+                                load_q(t0_next, k / QREC_STEPS, Q20 ? rq : rq + QREC_DW * (k / QREC_STEPS));
+                                if constexpr (SDP_REFILL_BARRIER) __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
                     }
                     if constexpr (T::DIN) {
                         q1 = rdd[k];
-                        if constexpr (!ABL_NOLOAD) rdd[k] = load_d(t0_next, k);
+                        if constexpr (!ABL_NOLOAD && !TOPLOAD_X) rdd[k] = load_d(t0_next, k);
                     }
 
                     if constexpr (ABL_NOMATH) {
@@ -2178,8 +2319,22 @@ __device__ __forceinline__ void sweep(const Params &p)
                 else steps(std::true_type{}, kch{}, kc1{});
                 publish_range(kc0{}, kch{}, nullptr);
             } else {
+                stamp_rev(3);
                 publish_range(kc0{}, kc1{}, wf_frames);
             }
+            if constexpr (FLUSH2) lo[-1 - par * K] = lo[K - 1];   // step 31's value once more, at position -1 of the row (see FLUSH2)
+            if constexpr (TOPLOAD) {
+#pragma unroll
+                for (int g = 0; g < K / 4; ++g) rq4[g] = rq4n[g], rq1[g] = rq1n[g];
+            }
+            if constexpr (TOPLOAD_X && !ABL_NOLOAD) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    if constexpr (T::QIN == Q_EXACT) rqx[k] = rqxn[k];
+                    if constexpr (T::DIN) rdd[k] = rddn[k];
+                }
+            }
+            stamp_rev(4);
 
             // ---- flush: one memory-aligned K-element block per row (see fo_* above) ----
             pf_t0 = t0, pf_par = par;
