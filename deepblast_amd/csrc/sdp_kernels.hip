@@ -117,6 +117,9 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #ifndef SDP_WF
 #define SDP_WF 1  // forward sweep: try the windowed form on interior chunks
 #endif
+#ifndef SDP_STAGE_EARLY
+#define SDP_STAGE_EARLY 0  // forward sweep: the next block set into the LDS ring as soon as the chunk's last block has read its inputs -- measured, no gain, off
+#endif
 #ifndef SDP_TOPLOAD
 #define SDP_TOPLOAD 1  // packed reverse sweep: the next chunk's state records are loaded in one burst at the top of the iteration
 #endif
@@ -1225,7 +1228,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                 for (int j = 0; j < WB; ++j) bcv[j] = edge_zero<KIND>();
             }
         };
-        auto fwd_blocks = [&](int c, int t0) {
+        auto fwd_blocks = [&](int c, int t0, auto &&stage_next) {
             if constexpr (FWD_SUB) {
                 int thr = lane + (sw ? 1 : 0);  // EDGE: the lane's cell is live at step t iff t >= thr
                 if (sw && i0 + lane == 0) thr = 0x7fffffff;  // padded row 1 of Smith-Waterman never is
@@ -1308,6 +1311,12 @@ __device__ __forceinline__ void sweep(const Params &p)
                             read_boundary(tb, bcf0, fa0, fb0);
                         }
                     }
+                    // (-DSDP_STAGE_EARLY=1) The chunk's LAST block has read its inputs: the ring half of the oldest block set is dead,
+                    // and the block set loaded at the top of this chunk could go into it NOW rather than after the block, where
+                    // its loads are waited for behind the block's own state stores (`s_waitcnt vmcnt(0)`: the compiler counts only
+                    // what every path is sure to have issued).  Built and measured in round 4: forward 214 -> 217 us at 256 x 512^2,
+                    // 791 -> 801 at 256 x 1024^2 -- the store acknowledgements are not what the forward sweep waits for.  Off.
+                    if constexpr (SDP_STAGE_EARLY && sb == K / WB - 1) stage_next();
                     u64 hist[WB];
                     int frame_pub = FRAME_NONE;
                     stamp(1);
@@ -1736,9 +1745,9 @@ __device__ __forceinline__ void sweep(const Params &p)
             stamp_chunk(t0 / WB, 5);
 
             if constexpr (FWD_SUB) {
-                fwd_blocks(c, t0);
+                fwd_blocks(c, t0, [&]() { if (more) write_block(bb_new); });
                 stamp_chunk(t0 / WB + 1, 4);
-                if (more) write_block(bb_new);
+                if constexpr (!SDP_STAGE_EARLY) { if (more) write_block(bb_new); }
                 stamp_chunk(t0 / WB + 1, 5);
                 continue;
             }
