@@ -136,15 +136,15 @@ __host__ __device__ inline size_t state_order_bytes(int B) { return ((size_t)B *
 
 // State layout: the state of a (pair, strip) is a sequence of units of 32 steps (packed Q: 12288 B, float2: 16384 B);
 // unit u of (pair b, strip s) starts at (b * nstrips + s) * ps + u * us.  See "Skewed state addressing" in sdp_kernels.hip.
-// Packed Q, round 4 (SDP_Q20 = 1): two 20-bit fields per cell, 5 bytes; four steps of a lane are 20 bytes, kept as two
-// planes per unit -- 8 rows of 1024 B (dwordx4 per lane) followed by 8 rows of 256 B (one dword per lane) -- so that every
-// wave access still covers whole contiguous lines.  SDP_Q20 = 0: the 24-bit fields of rounds 1-3 (6 bytes per cell, 16
-// rows of 768 B).
+// Packed Q, round 4 (SDP_Q20 = 1): two 20-bit fields per cell, 5 bytes; a 16-step block of a lane is 20 dwords, kept as
+// five rows of 1024 B (row j: dwords 4j .. 4j+3 of every lane) -- every wave access is one dwordx4 over contiguous lines;
+// a unit of 32 steps is two blocks, ten rows.  SDP_Q20 = 0: the 24-bit fields of rounds 1-3 (6 bytes per cell, 16 rows of
+// 768 B).
 #ifndef SDP_Q20
 #define SDP_Q20 1
 #endif
 constexpr int STATE_UNIT_STEPS = 32;
-constexpr unsigned STATEQ_UNIT_BYTES = SDP_Q20 ? (8 * 1024 + 8 * 256) : 16 * 768, STATE2_UNIT_BYTES = 32 * 512;
+constexpr unsigned STATEQ_UNIT_BYTES = SDP_Q20 ? 10 * 1024 : 16 * 768, STATE2_UNIT_BYTES = 32 * 512;
 // (Sharing the ramp rows of neighbouring strips -- no skew padding -- was implemented in round 2 for both formats, measured
 // slower (partial-line writes) and removed in round 3; see DESIGN.md.)
 __host__ __device__ inline size_t state_rows2(int N, int M) { return (size_t)((N + 63) / 64) * ((M + 63 + 63) / 64 * 64); }

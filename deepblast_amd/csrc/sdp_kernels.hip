@@ -121,7 +121,7 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #define SDP_STAGE_EARLY 0  // forward sweep: the next block set into the LDS ring as soon as the chunk's last block has read its inputs -- measured, no gain, off
 #endif
 #ifndef SDP_TOPLOAD
-#define SDP_TOPLOAD 1  // packed reverse sweep: the next chunk's state records are loaded in one burst at the top of the iteration
+#define SDP_TOPLOAD 1  // exact-state sweeps: the next chunk's state rows are loaded in one burst at the top of the iteration (the packed reverse sweep always does)
 #endif
 #ifndef SDP_REFILL_BARRIER
 #define SDP_REFILL_BARRIER 1
@@ -131,9 +131,6 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #endif
 #ifndef SDP_FLUSH2
 #define SDP_FLUSH2 1  // reverse sweeps, aligned K = 32 builds: outputs leave two columns per lane (see FLUSH2)
-#endif
-#ifndef SDP_SKIP_DEAD
-#define SDP_SKIP_DEAD 0  // packed state: records of lanes outside the matrix neither written nor read (see q20_dead) -- measured slower, off
 #endif
 #ifndef SDP_BWD_HALF
 #define SDP_BWD_HALF 0  // fp32 backward sweep: boundary hand-off in halves of a chunk (see HALF) -- measured slower, off
@@ -278,7 +275,7 @@ __device__ __forceinline__ float2 q_unpack(const unsigned *w, int second)
 // as before).  The factor keeps the field below 2^20 for q <= 1 + 9e-7; a saturated weight (anything within 2^-21 of 1)
 // decodes to exactly 1, a weight below 2^-21 to exactly 0, so a saturated path loses nothing -- the 24-bit format kept 1 -
 // 2^-23 as it was and lost 1.7e-8 of E per step.  Four cells -- eight fields, x0 y0 x1 y1 x2 y2 x3 y3 from bit 0 up -- fill
-// five dwords; dwords 0-3 go to plane A of the unit, dword 4 to plane B (sdp_kernels.h).
+// five dwords; the 20 dwords of a 16-step block are stored as five rows of one dwordx4 per lane (sdp_kernels.h).
 constexpr bool Q20 = SDP_Q20 != 0;
 constexpr float Q20_SCALE = 0.99999809265136718750f;    // 1 - 2^-19
 constexpr float Q20_UNSCALE = 1.0000019073486328125f;   // 1 + 2^-19 = 1 / (1 - 2^-19) to fp32
@@ -299,13 +296,6 @@ __device__ __forceinline__ float q20_field(unsigned u)  // field in the low 20 b
     return __uint_as_float((u & 0xfffffu) | 0x41000000u) - 8.0f;
 }
 // (f - 8) of both weights of cell `sub` (0..3) of a five-dword record; the caller multiplies by Q20_UNSCALE
-typedef unsigned q20_vec __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float2 q20_unpack(const unsigned *w, int sub);
-__device__ __forceinline__ float2 q20_unpack(q20_vec a, unsigned b, int sub)   // dwords 0-3 as they were loaded, dword 4
-{
-    const unsigned w[5] = {a[0], a[1], a[2], a[3], b};
-    return q20_unpack(w, sub);
-}
 __device__ __forceinline__ float2 q20_unpack(const unsigned *w, int sub)
 {
     switch (sub) {
@@ -692,48 +682,44 @@ __device__ __forceinline__ void sweep(const Params &p)
                                                 (T::QIN == Q_PACKED || T::QOUT == Q_PACKED) ? ST_RECORDS : 0u);
         // 24-bit fields: scalar offset of record row t_base/2 + g4 (g4 = 0, 4, 8, 12; t_base a multiple of the chunk length)
         auto q_soff = [&](int t_base, int g4) { return (unsigned)(t_base >> 5) * p.st_us + (unsigned)((((t_base >> 1) & 15) + g4) * 768); };
-        // 20-bit fields: scalar offsets of row t_base/4 + g4 (g4 = 0, 4) of plane A (1024-byte rows) and of plane B (256-byte rows,
-        // behind the eight rows of plane A)
-        auto q20_soff_a = [&](int t_base, int g4) { return (unsigned)(t_base >> 5) * p.st_us + (unsigned)((((t_base >> 2) & 7) + g4) * 1024); };
-        auto q20_soff_b = [&](int t_base, int g4) { return (unsigned)(t_base >> 5) * p.st_us + 8192u + (unsigned)((((t_base >> 2) & 7) + g4) * 256); };
+        // 20-bit fields: a 16-step BLOCK of a lane is 20 dwords (four records of five), kept as five rows of 1024 B -- row j holds
+        // dwords 4j .. 4j+3 of every lane -- so that every access is a whole dwordx4 of contiguous 1 KB per wave: five memory
+        // instructions per 16 steps (the first layout of round 4, dwordx4 + dword per record, took eight; rounds 1-3 eight
+        // dwordx3).  A 32-step unit is two blocks, ten rows.  Scalar offset of row jr (0..4) of the block that holds step t:
+        auto q20_soff = [&](int t, int jr) { return (unsigned)(t >> 5) * p.st_us + (unsigned)((((t >> 4) & 1) * 5 + jr) * 1024); };
         typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
         typedef unsigned u32x4q __attribute__((ext_vector_type(4)));
-        // Records of the ramps (-DSDP_SKIP_DEAD=1): a lane whose four steps of a record all lie left of the matrix (the
-        // strip's head ramp: lane > last step), right of it (tail ramp: first step - lane >= m) or below it (lane >= rows) has
-        // nothing to say in it; with the switch on such records are neither written nor read (their offset is sent out of
-        // range), so that the whole 128-byte lines of the 12.5 % skew padding that hold nothing else never cross the fabric.
-        // Built and measured in round 4, as the per-lane variant was in round 1, and again SLOWER: forward 210 -> 215 us,
-        // backward 161 -> 168 us at 256 x 512^2, 784 -> 827 / 515 -> 517 at 256 x 1024^2 (same box, interleaved) -- the
-        // lines at the edge of the ramp become partial writes / reads, which cost the memory system more than the dead
-        // bytes saved.  Off.
-        auto q20_dead = [&](int t_first) { return SDP_SKIP_DEAD && (lane > t_first + 3 || t_first - lane >= m || lane >= rows); };
-        // 20-bit fields: the ring of prefetched records keeps the dwordx4 of a record AS THE VECTOR it was loaded as.  Kept as
-        // five scalars (rounds 1-3 did that for the dwordx3 records too) each dword is a loop-carried value of its own, the
-        // load needs four consecutive registers for them, and the compiler resolved that by loading into other registers and
-        // COPYING all records of the next chunk into place at the end of every iteration -- behind an `s_waitcnt vmcnt(0)`:
-        // the prefetch distance was the rest of the iteration, not a chunk, and the sweep ran at memory latency.
-        u32x4q rq4[Q20 ? K / 4 : 1];
-        unsigned rq1[Q20 ? K / 4 : 1];
-        // ... and the records of the NEXT chunk are a second set, loaded in one burst at the top of the iteration (TOPLOAD) and
+        // (an earlier variant sent the records of lanes that lie outside the matrix for all their steps out of range -- neither
+        //  written nor read, -DSDP_SKIP_DEAD of round 4 -- so that whole lines of the skew padding never crossed the fabric:
+        //  forward 210 -> 215 us, backward 161 -> 168 us; the lines at the edge of a ramp become partial accesses.  Removed.)
+        // The ring of prefetched rows keeps every dwordx4 AS THE VECTOR it was loaded as.  Kept as scalars (rounds 1-3 did
+        // that for the dwordx3 records) each dword is a loop-carried value of its own, the load needs consecutive registers
+        // for them, and the compiler resolved that by loading elsewhere and COPYING all rows of the next chunk into place at
+        // the end of every iteration -- behind an `s_waitcnt vmcnt(0)`.
+        constexpr int QROWS = 5 * K / 16;   // rows (dwordx4 per lane) of a chunk
+        u32x4q rqv[Q20 ? QROWS : 1];
+        // ... and the rows of the NEXT chunk are a second set, loaded in one burst at the top of the iteration (TOPLOAD) and
         // moved over at its end: the wait for them then sits a whole iteration behind their issue.  (Refilling a slot of the
         // first set right after its last use -- the scheme of rounds 1-3 -- reads as the same thing, but the compiler gave the
         // refills registers of their own anyway and moved them over at the end of the iteration, behind a vmcnt(0) that the
-        // loads issued during the last steps had had a few hundred cycles to meet.)
-        constexpr bool TOPLOAD = Q20 && REV && T::QIN == Q_PACKED && SDP_TOPLOAD;
-        u32x4q rq4n[TOPLOAD ? K / 4 : 1];
-        unsigned rq1n[TOPLOAD ? K / 4 : 1];
-        auto load_q20 = [&](int t_base, int g) {   // steps t_base + 4g .. + 3 -> rq4[g], rq1[g] (TOPLOAD: the next chunk's set)
-            const bool dead = q20_dead(t_base + 4 * g);
-            const u32x4q va = __builtin_amdgcn_raw_buffer_load_b128(rs_q, dead ? OOB : q_lane + (g & 3) * 1024, q20_soff_a(t_base, g & ~3), AUX_ST_LOAD);
-            const unsigned vb = __builtin_amdgcn_raw_buffer_load_b32(rs_q, dead ? OOB : lane * 4 + (g & 3) * 256, q20_soff_b(t_base, g & ~3), AUX_ST_LOAD);
-            if constexpr (TOPLOAD) rq4n[g] = va, rq1n[g] = vb;
-            else rq4[g] = va, rq1[g] = vb;
+        // loads issued during the last steps had had a few hundred cycles to meet: the reverse sweeps ran at memory latency.)
+        constexpr bool TOPLOAD = Q20 && REV && T::QIN == Q_PACKED;
+        u32x4q rqvn[TOPLOAD ? QROWS : 1];
+        auto load_q20 = [&](int t_base, int jj) {   // row jj (0 .. QROWS-1) of the chunk that starts at step t_base
+            const u32x4q va = __builtin_amdgcn_raw_buffer_load_b128(rs_q, q_lane, q20_soff(t_base + 16 * (jj / 5), jj % 5), AUX_ST_LOAD);
+            if constexpr (TOPLOAD) rqvn[jj] = va;
+            else rqv[jj] = va;
+        };
+        // the five dwords of the record of steps 4g .. 4g+3 of the chunk, out of the rows
+        auto q20_record = [&](int g, unsigned *w) {
+#pragma unroll
+            for (int e = 0; e < 5; ++e) {
+                const int d = 5 * (g & 3) + e;           // dword of the block
+                w[e] = rqv[5 * (g >> 2) + (d >> 2)][d & 3];
+            }
         };
         auto load_q = [&](int t_base, int g, unsigned *dst) {  // 24-bit: steps t_base + 2g, + 1 (3 dwords)
-            if constexpr (Q20) {
-                (void)dst;
-                load_q20(t_base, g);
-            } else {
+            if constexpr (!Q20) {
                 const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs_q, q_lane + (g & 3) * 768, q_soff(t_base, g & ~3), AUX_ST_LOAD);
                 const unsigned v0 = v[0], v1 = v[1], v2 = v[2];
                 dst[0] = v0, dst[1] = v1, dst[2] = v2;
@@ -745,13 +731,11 @@ __device__ __forceinline__ void sweep(const Params &p)
             // 16).  The compiler only inserts the wait state for stores without a scalar offset register, so it
             // is forced here: the no-op "reads" the data registers (nothing that overwrites them can move above
             // it) and is ordered after the store as a memory operation.
-            if constexpr (Q20) {
+            if constexpr (Q20) {   // g: row of the block that holds step t_base (src: its four dwords)
                 u32x4q v;
                 v[0] = src[0], v[1] = src[1], v[2] = src[2], v[3] = src[3];
-                const bool dead = q20_dead(t_base + 4 * g);
-                __builtin_amdgcn_raw_buffer_store_b128(v, rs_q, dead ? OOB : q_lane + (g & 3) * 1024, q20_soff_a(t_base, g & ~3), AUX_ST_STORE);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_q, q_lane, q20_soff(t_base, g), AUX_ST_STORE);
                 asm volatile("s_nop 1" : : "v"(v) : "memory");
-                __builtin_amdgcn_raw_buffer_store_b32(src[4], rs_q, dead ? OOB : lane * 4 + (g & 3) * 256, q20_soff_b(t_base, g & ~3), AUX_ST_STORE);
             } else {
                 u32x3 v;
                 v[0] = src[0], v[1] = src[1], v[2] = src[2];
@@ -791,6 +775,7 @@ __device__ __forceinline__ void sweep(const Params &p)
         // stored as dwordx4 + dword.
         unsigned qbits_x = 0, qbits_y = 0;
         unsigned qb_x[3] = {0, 0, 0}, qb_y[3] = {0, 0, 0};
+        unsigned qblk[20];   // 20-bit fields: the dwords of the current 16-step block; a row leaves as soon as it is complete
         auto store_state_bits = [&](int t_base, int k, unsigned fx, unsigned fy) {
             if constexpr (Q20) {
                 if ((k & 3) == 0) qb_x[0] = fx, qb_y[0] = fy;
@@ -798,9 +783,13 @@ __device__ __forceinline__ void sweep(const Params &p)
                 else if ((k & 3) == 2) qb_x[2] = fx, qb_y[2] = fy;
                 else {
                     const unsigned ax[4] = {qb_x[0], qb_x[1], qb_x[2], fx}, ay[4] = {qb_y[0], qb_y[1], qb_y[2], fy};
-                    unsigned w[5];
-                    q20_pack4(ax, ay, w);
-                    store_q(t_base, k >> 2, w);
+                    const int g = (k >> 2) & 3;   // record of the block
+                    q20_pack4(ax, ay, qblk + 5 * g);
+                    const int tb16 = t_base + (k & ~15);
+                    if (g == 0) store_q(tb16, 0, qblk);
+                    else if (g == 1) store_q(tb16, 1, qblk + 4);
+                    else if (g == 2) store_q(tb16, 2, qblk + 8);
+                    else store_q(tb16, 3, qblk + 12), store_q(tb16, 4, qblk + 16);
                 }
             } else if ((k & 1) == 0) {
                 qbits_x = fx, qbits_y = fy;
@@ -1058,11 +1047,19 @@ __device__ __forceinline__ void sweep(const Params &p)
 #pragma unroll
             for (int g = 0; g < K / QREC_STEPS; ++g) {
                 if constexpr (ABL_NOLOAD) {
-                    if constexpr (Q20) rq4[g] = (u32x4q){0x20003000u + 64 * g + lane, 0x20003000u, 0x20003000u, 0x20003000u}, rq1[g] = 0x20003000u;
-                    else for (int j = 0; j < QREC_DW; ++j) rq[QREC_DW * g + j] = 0x20003000u + 64 * g + lane;
+                    if constexpr (!Q20) for (int j = 0; j < QREC_DW; ++j) rq[QREC_DW * g + j] = 0x20003000u + 64 * g + lane;
                 } else {
-                    load_q(c_first * K, g, Q20 ? rq : rq + QREC_DW * g);
-                    if constexpr (TOPLOAD) rq4[g] = rq4n[g], rq1[g] = rq1n[g];
+                    if constexpr (!Q20) load_q(c_first * K, g, rq + QREC_DW * g);
+                }
+            }
+            if constexpr (Q20) {
+#pragma unroll
+                for (int jj = 0; jj < QROWS; ++jj) {
+                    if constexpr (ABL_NOLOAD) rqv[jj] = (u32x4q){0x20003000u + 64 * jj + lane, 0x20003000u, 0x20003000u, 0x20003000u};
+                    else {
+                        load_q20(c_first * K, jj);
+                        if constexpr (TOPLOAD) rqv[jj] = rqvn[jj];
+                    }
                 }
             }
         }
@@ -1714,7 +1711,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                     const int c_ = nchunks - 1 - ci;
                     const int tn = (ci + 1 < nchunks) ? (c_ - 1) * K : c_ * K;   // the last chunk re-reads its own records: harmless
 #pragma unroll
-                    for (int g = 0; g < K / 4; ++g) load_q20(tn, g);
+                    for (int jj = 0; jj < QROWS; ++jj) load_q20(tn, jj);
                 }
             }
             if constexpr (T::SOUT > 0) {
@@ -1914,16 +1911,21 @@ __device__ __forceinline__ void sweep(const Params &p)
                         if constexpr (!ABL_NOLOAD && !TOPLOAD_X) rqx[k] = load_f2(rs_qx, t0_next, k);
                     }
                     if constexpr (T::QIN == Q_PACKED) {
-                        if constexpr (Q20) q0 = q20_unpack(rq4[k >> 2], rq1[k >> 2], k & 3);
-                        else q0 = q_unpack(rq + 3 * (k >> 1), k & 1);
+                        if constexpr (Q20) {
+                            unsigned w5[5];
+                            q20_record(k >> 2, w5);
+                            q0 = q20_unpack(w5, k & 3);
+                        } else {
+                            q0 = q_unpack(rq + 3 * (k >> 1), k & 1);
+                        }
                         q0.x *= QF_UNSCALE, q0.y *= QF_UNSCALE;
                         if constexpr (!ABL_NOLOAD) {   // the record's last step in processing order has been consumed: refill it
-                            if (!TOPLOAD && (k & (QREC_STEPS - 1)) == (REV ? 0 : QREC_STEPS - 1)) {
+                            if (!Q20 && (k & (QREC_STEPS - 1)) == (REV ? 0 : QREC_STEPS - 1)) {
                                 // (the refill must stay BEHIND the last use of what it overwrites: hoisted above it by the
                                 //  scheduler, old and new record are alive together, get different registers, and the new
                                 //  ones are copied into place at the end of the iteration behind a vmcnt(0))
                                 if constexpr (SDP_REFILL_BARRIER) __builtin_amdgcn_sched_barrier(0);
-                                load_q(t0_next, k / QREC_STEPS, Q20 ? rq : rq + QREC_DW * (k / QREC_STEPS));
+                                load_q(t0_next, k / QREC_STEPS, rq + QREC_DW * (k / QREC_STEPS));
                                 if constexpr (SDP_REFILL_BARRIER) __builtin_amdgcn_sched_barrier(0);
                             }
                         }
@@ -2334,7 +2336,7 @@ __device__ __forceinline__ void sweep(const Params &p)
             if constexpr (FLUSH2) lo[-1 - par * K] = lo[K - 1];   // step 31's value once more, at position -1 of the row (see FLUSH2)
             if constexpr (TOPLOAD) {
 #pragma unroll
-                for (int g = 0; g < K / 4; ++g) rq4[g] = rq4n[g], rq1[g] = rq1n[g];
+                for (int jj = 0; jj < QROWS; ++jj) rqv[jj] = rqvn[jj];
             }
             if constexpr (TOPLOAD_X && !ABL_NOLOAD) {
 #pragma unroll
