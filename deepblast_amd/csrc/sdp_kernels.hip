@@ -117,6 +117,9 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #ifndef SDP_WF
 #define SDP_WF 1  // forward sweep: try the windowed form on interior chunks
 #endif
+#ifndef SDP_FLUSH_FAST
+#define SDP_FLUSH_FAST 1  // reverse sweeps: chunks whose outputs are all real cells flush without per-lane tests
+#endif
 #ifndef SDP_STAGE_EARLY
 #define SDP_STAGE_EARLY 0  // forward sweep: the next block set into the LDS ring as soon as the chunk's last block has read its inputs -- measured, no gain, off
 #endif
@@ -1624,7 +1627,33 @@ __device__ __forceinline__ void sweep(const Params &p)
             if constexpr (T::SOUT > 0) {
                 const int ubase = (i0 * ld + t0) * 4;
                 if constexpr (FLUSH2) {
-                    if ((m & 1) == 0) {   // (uniform)
+                    // all 64 x 32 elements are real cells (rows of a full strip, columns t0 - 32 .. t0 + 31 inside the matrix): no
+                    // per-lane tests, the global offset is one per-lane base plus a scalar, the LDS index one per-lane base plus a
+                    // constant -- no vector arithmetic at all when the chunk has parity 0, a compare-and-select per row class when 1
+                    const bool flush_plain = active && rows == 64 && t0 >= K && t0 + K <= m;
+                    if (flush_plain && SDP_FLUSH_FAST) {
+                        float2 vals[K / 2];
+                        const int thr_l = K - 1 - f2_rl - f2_el;   // (k2 & 7) < thr_l  <=>  sfull < K - 1
+                        if (par) {
+#pragma unroll
+                            for (int k2 = 0; k2 < K / 2; ++k2) {
+                                const int idx = ((k2 & 7) + 32 * (k2 >> 3)) * PO + (k2 & 7) + f2_l + ((k2 & 7) < thr_l ? K : -K);
+                                vals[k2] = *reinterpret_cast<const float2 *>(__builtin_assume_aligned(lds_out + idx, 8));
+                            }
+                        } else {
+#pragma unroll
+                            for (int k2 = 0; k2 < K / 2; ++k2)
+                                vals[k2] = *reinterpret_cast<const float2 *>(__builtin_assume_aligned(lds_out + f2_l + ((k2 & 7) + 32 * (k2 >> 3)) * PO + (k2 & 7), 8));
+                        }
+#pragma unroll
+                        for (int k2 = 0; k2 < K / 2; ++k2) {
+                            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                            const int c_r = (k2 & 7) + 32 * (k2 >> 3);
+                            if constexpr (ABL_NOSTORE) { keep(vals[k2].x); keep(vals[k2].y); }
+                            else __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(vals[k2].x), __float_as_uint(vals[k2].y)}, rs_out, (unsigned)(f2_g * 4),
+                                                                       ubase + (c_r * ld - 32 * (k2 >> 3)) * 4, AUX_OUT_STORE);
+                        }
+                    } else if ((m & 1) == 0) {   // (uniform)
                         float2 vals[K / 2];
 #pragma unroll
                         for (int k2 = 0; k2 < K / 2; ++k2) {
