@@ -700,25 +700,22 @@ __device__ __forceinline__ void sweep(const Params &p)
         // for them, and the compiler resolved that by loading elsewhere and COPYING all rows of the next chunk into place at
         // the end of every iteration -- behind an `s_waitcnt vmcnt(0)`.
         constexpr int QROWS = 5 * K / 16;   // rows (dwordx4 per lane) of a chunk
-        u32x4q rqv[Q20 ? QROWS : 1];
+        u32x4q rq2[2][Q20 ? QROWS : 1];   // two sets: the current chunk's rows and the next chunk's (roles swap every chunk, see ROT)
         // ... and the rows of the NEXT chunk are a second set, loaded in one burst at the top of the iteration (TOPLOAD) and
         // moved over at its end: the wait for them then sits a whole iteration behind their issue.  (Refilling a slot of the
         // first set right after its last use -- the scheme of rounds 1-3 -- reads as the same thing, but the compiler gave the
         // refills registers of their own anyway and moved them over at the end of the iteration, behind a vmcnt(0) that the
         // loads issued during the last steps had had a few hundred cycles to meet: the reverse sweeps ran at memory latency.)
         constexpr bool TOPLOAD = Q20 && REV && T::QIN == Q_PACKED;
-        u32x4q rqvn[TOPLOAD ? QROWS : 1];
-        auto load_q20 = [&](int t_base, int jj) {   // row jj (0 .. QROWS-1) of the chunk that starts at step t_base
-            const u32x4q va = __builtin_amdgcn_raw_buffer_load_b128(rs_q, q_lane, q20_soff(t_base + 16 * (jj / 5), jj % 5), AUX_ST_LOAD);
-            if constexpr (TOPLOAD) rqvn[jj] = va;
-            else rqv[jj] = va;
+        auto load_q20 = [&](int t_base, int jj, auto set_tag) {   // row jj (0 .. QROWS-1) of the chunk that starts at step t_base -> set S
+            rq2[decltype(set_tag)::value][jj] = __builtin_amdgcn_raw_buffer_load_b128(rs_q, q_lane, q20_soff(t_base + 16 * (jj / 5), jj % 5), AUX_ST_LOAD);
         };
-        // the five dwords of the record of steps 4g .. 4g+3 of the chunk, out of the rows
-        auto q20_record = [&](int g, unsigned *w) {
+        // the five dwords of the record of steps 4g .. 4g+3 of the chunk, out of the rows of set S
+        auto q20_record = [&](int g, unsigned *w, auto set_tag) {
 #pragma unroll
             for (int e = 0; e < 5; ++e) {
                 const int d = 5 * (g & 3) + e;           // dword of the block
-                w[e] = rqv[5 * (g >> 2) + (d >> 2)][d & 3];
+                w[e] = rq2[decltype(set_tag)::value][5 * (g >> 2) + (d >> 2)][d & 3];
             }
         };
         auto load_q = [&](int t_base, int g, unsigned *dst) {  // 24-bit: steps t_base + 2g, + 1 (3 dwords)
@@ -835,13 +832,14 @@ __device__ __forceinline__ void sweep(const Params &p)
         constexpr int QREC_STEPS = Q20 ? 4 : 2, QREC_DW = Q20 ? 5 : 3;   // steps and dwords of one packed record
         unsigned rq[Q20 ? 1 : QREC_DW * K / QREC_STEPS];  // 24-bit fields: packed Q of the current chunk, one record per 2 steps; a record is refilled
                                  // with the same steps of the next chunk as soon as both have been consumed
-        float2 rqx[K];     // exact Q rows / Qd rows of the current chunk: slot k holds step t0+k
-        float2 rdd[K];
+        // exact Q rows / Qd rows: slot k of a set holds step t0+k of a chunk; two sets whose roles (current chunk / next chunk)
+        // swap every chunk (ROT) -- or one set whose slots are refilled right after use (-DSDP_TOPLOAD=0)
+        float2 rqx2[2][K];
+        float2 rdd2[2][K];
         // TOPLOAD_X: the rows of the next chunk are a second set, loaded in one burst at the top of the iteration and moved over
         // at its end (see TOPLOAD); otherwise a slot is refilled right after it has been consumed
         constexpr bool TOPLOAD_X = SDP_TOPLOAD != 0 && (T::QIN == Q_EXACT || T::DIN);
-        float2 rqxn[(TOPLOAD_X && T::QIN == Q_EXACT) ? K : 1];
-        float2 rddn[(TOPLOAD_X && T::DIN) ? K : 1];
+
 
         // Staged INPUT geometry.  Row-major tensors enter as K-column blocks, four columns (one dwordx4) per
         // lane; row r's blocks start at columns K*j - (r mod 4).  During chunk c (steps cK .. cK+K-1) row r needs
@@ -1042,8 +1040,8 @@ __device__ __forceinline__ void sweep(const Params &p)
         if constexpr (T::QIN == Q_EXACT) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                if constexpr (ABL_NOLOAD) rqx[k] = make_float2(0.25f + 1e-3f * k, 0.5f - 1e-3f * lane);
-                else rqx[k] = load_f2(rs_qx, c_first * K, k);
+                if constexpr (ABL_NOLOAD) rqx2[0][k] = rqx2[1][k] = make_float2(0.25f + 1e-3f * k, 0.5f - 1e-3f * lane);
+                else rqx2[0][k] = load_f2(rs_qx, c_first * K, k);
             }
         }
         if constexpr (T::QIN == Q_PACKED) {
@@ -1058,19 +1056,16 @@ __device__ __forceinline__ void sweep(const Params &p)
             if constexpr (Q20) {
 #pragma unroll
                 for (int jj = 0; jj < QROWS; ++jj) {
-                    if constexpr (ABL_NOLOAD) rqv[jj] = (u32x4q){0x20003000u + 64 * jj + lane, 0x20003000u, 0x20003000u, 0x20003000u};
-                    else {
-                        load_q20(c_first * K, jj);
-                        if constexpr (TOPLOAD) rqv[jj] = rqvn[jj];
-                    }
+                    if constexpr (ABL_NOLOAD) rq2[0][jj] = rq2[1][jj] = (u32x4q){0x20003000u + 64 * jj + lane, 0x20003000u, 0x20003000u, 0x20003000u};
+                    else load_q20(c_first * K, jj, std::integral_constant<int, 0>{});
                 }
             }
         }
         if constexpr (T::DIN) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                if constexpr (ABL_NOLOAD) rdd[k] = make_float2(0.25f + 1e-3f * k, 0.5f - 1e-3f * lane);
-                else rdd[k] = load_d(c_first * K, k);
+                if constexpr (ABL_NOLOAD) rdd2[0][k] = rdd2[1][k] = make_float2(0.25f + 1e-3f * k, 0.5f - 1e-3f * lane);
+                else rdd2[0][k] = load_d(c_first * K, k);
             }
         }
         load_block(c_first);
@@ -1714,7 +1709,15 @@ __device__ __forceinline__ void sweep(const Params &p)
         // columns in the ring; every element of that flush that exists was produced in chunk 0).
         const int nflush = T::SOUT > 0 ? (fo_need_tail ? 2 : 1) : 0;
         int pf_t0 = 0, pf_par = 0;
-        for (int ci = 0; ci < nchunks + nflush; ++ci) {
+        // ROT: sweeps that prefetch state rows run the chunk loop unrolled by two, and the two instances use the two register
+        // sets in opposite roles (P = set of the current chunk's rows, 1 - P = set the next chunk's rows are loaded into): no
+        // row is ever moved, and a row is waited for where it is first used, a whole iteration and more behind its load.
+        // (With one body and a move "next -> current" at its end the wait sat at the move.)
+        constexpr bool ROT = TOPLOAD || TOPLOAD_X;
+        auto chunk_body = [&](auto p_tag, const int ci) {
+            constexpr int P = decltype(p_tag)::value;
+            using cur_t = std::integral_constant<int, P>;
+            using nxt_t = std::integral_constant<int, ROT ? 1 - P : P>;
             // experiments build, sdp_set_trace, backward sweep: per chunk (slot = position in processing order) cycle stamps
             // 0 top, 1 previous chunk's outputs flushed, 2 boundary values there, 3 steps done, 4 published
             auto stamp_rev = [&](int k) {
@@ -1724,14 +1727,22 @@ __device__ __forceinline__ void sweep(const Params &p)
                 }
             };
             stamp_rev(0);
+            // Everything this wave has in flight is a whole iteration old: the rows loaded at the top of the previous iteration (the
+            // ones this chunk consumes) and that iteration's output stores.  Waiting for all of it HERE, with the builtin the
+            // compiler's bookkeeping understands, is free -- and leaves the compiler nothing to wait for at the rows' first use.
+            // Left to itself it waits there with vmcnt(10): "the ten loads issued since may stay out" -- but it does not count
+            // the 16 output stores issued behind those loads, the counter retires in order, and so the ten youngest operations
+            // are stores and the wait takes the rows just requested for the NEXT chunk along: the prefetch distance shrinks to
+            // the few hundred cycles of the flush.
+            if constexpr (ROT && SDP_PROLOGUE_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);
             if constexpr (TOPLOAD_X && !ABL_NOLOAD) {
                 if (ci < nchunks) {   // (uniform; the extra flush iterations load nothing)
                     const int c_ = REV ? nchunks - 1 - ci : ci;
                     const int tn = (ci + 1 < nchunks) ? (c_ + dir) * K : c_ * K;   // the last chunk re-reads its own rows: harmless
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        if constexpr (T::QIN == Q_EXACT) rqxn[k] = load_f2(rs_qx, tn, k);
-                        if constexpr (T::DIN) rddn[k] = load_d(tn, k);
+                        if constexpr (T::QIN == Q_EXACT) rqx2[nxt_t::value][k] = load_f2(rs_qx, tn, k);
+                        if constexpr (T::DIN) rdd2[nxt_t::value][k] = load_d(tn, k);
                     }
                 }
             }
@@ -1740,7 +1751,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                     const int c_ = nchunks - 1 - ci;
                     const int tn = (ci + 1 < nchunks) ? (c_ - 1) * K : c_ * K;   // the last chunk re-reads its own records: harmless
 #pragma unroll
-                    for (int jj = 0; jj < QROWS; ++jj) load_q20(tn, jj);
+                    for (int jj = 0; jj < QROWS; ++jj) load_q20(tn, jj, nxt_t{});
                 }
             }
             if constexpr (T::SOUT > 0) {
@@ -1748,7 +1759,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                 stamp_rev(1);
                 if (ci >= nchunks) {
                     pf_t0 = -K, pf_par = 1;
-                    continue;
+                    return;
                 }
             }
             const int c = REV ? nchunks - 1 - ci : ci;
@@ -1775,7 +1786,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                 stamp_chunk(t0 / WB + 1, 4);
                 if constexpr (!SDP_STAGE_EARLY) { if (more) write_block(bb_new); }
                 stamp_chunk(t0 / WB + 1, 5);
-                continue;
+                return;
             }
 
             // ---- boundary values for the edge lane: broadcast LDS reads, off the dependency chain ----
@@ -1936,13 +1947,13 @@ __device__ __forceinline__ void sweep(const Params &p)
 
                     float2 q0, q1;
                     if constexpr (T::QIN == Q_EXACT) {
-                        q0 = rqx[k];
-                        if constexpr (!ABL_NOLOAD && !TOPLOAD_X) rqx[k] = load_f2(rs_qx, t0_next, k);
+                        q0 = rqx2[P][k];
+                        if constexpr (!ABL_NOLOAD && !TOPLOAD_X) rqx2[P][k] = load_f2(rs_qx, t0_next, k);
                     }
                     if constexpr (T::QIN == Q_PACKED) {
                         if constexpr (Q20) {
                             unsigned w5[5];
-                            q20_record(k >> 2, w5);
+                            q20_record(k >> 2, w5, cur_t{});
                             q0 = q20_unpack(w5, k & 3);
                         } else {
                             q0 = q_unpack(rq + 3 * (k >> 1), k & 1);
@@ -1960,8 +1971,8 @@ __device__ __forceinline__ void sweep(const Params &p)
                         }
                     }
                     if constexpr (T::DIN) {
-                        q1 = rdd[k];
-                        if constexpr (!ABL_NOLOAD && !TOPLOAD_X) rdd[k] = load_d(t0_next, k);
+                        q1 = rdd2[P][k];
+                        if constexpr (!ABL_NOLOAD && !TOPLOAD_X) rdd2[P][k] = load_d(t0_next, k);
                     }
 
                     if constexpr (ABL_NOMATH) {
@@ -2363,23 +2374,20 @@ __device__ __forceinline__ void sweep(const Params &p)
                 publish_range(kc0{}, kc1{}, wf_frames);
             }
             if constexpr (FLUSH2) lo[-1 - par * K] = lo[K - 1];   // step 31's value once more, at position -1 of the row (see FLUSH2)
-            if constexpr (TOPLOAD) {
-#pragma unroll
-                for (int jj = 0; jj < QROWS; ++jj) rqv[jj] = rqvn[jj];
-            }
-            if constexpr (TOPLOAD_X && !ABL_NOLOAD) {
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    if constexpr (T::QIN == Q_EXACT) rqx[k] = rqxn[k];
-                    if constexpr (T::DIN) rdd[k] = rddn[k];
-                }
-            }
             stamp_rev(4);
 
             // ---- flush: one memory-aligned K-element block per row (see fo_* above) ----
             pf_t0 = t0, pf_par = par;
 
             if (more) write_block(bb_new);
+        };
+        if constexpr (ROT) {
+            for (int ci = 0; ci < nchunks + nflush; ci += 2) {
+                chunk_body(std::integral_constant<int, 0>{}, ci);
+                if (ci + 1 < nchunks + nflush) chunk_body(std::integral_constant<int, 1>{}, ci + 1);
+            }
+        } else {
+            for (int ci = 0; ci < nchunks + nflush; ++ci) chunk_body(std::integral_constant<int, 0>{}, ci);
         }
         if constexpr (!REV) {
             if (t_final >= 0) {
