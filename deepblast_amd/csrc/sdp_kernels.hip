@@ -120,6 +120,12 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #ifndef SDP_FLUSH_FAST
 #define SDP_FLUSH_FAST 1  // reverse sweeps: chunks whose outputs are all real cells flush without per-lane tests
 #endif
+#ifndef SDP_VEC_BND
+#define SDP_VEC_BND 1
+#endif
+#ifndef SDP_ZERO_SKIP
+#define SDP_ZERO_SKIP 2  // fp32 backward sweep: a chunk whose carries, boundary values and cotangent are all +0 produces +0 everywhere: 1 = its steps are skipped, 2 = and its state rows not loaded (bit-identical)
+#endif
 #ifndef SDP_STAGE_EARLY
 #define SDP_STAGE_EARLY 0  // forward sweep: the next block set into the LDS ring as soon as the chunk's last block has read its inputs -- measured, no gain, off
 #endif
@@ -839,6 +845,79 @@ __device__ __forceinline__ void sweep(const Params &p)
         // TOPLOAD_X: the rows of the next chunk are a second set, loaded in one burst at the top of the iteration and moved over
         // at its end (see TOPLOAD); otherwise a slot is refilled right after it has been consumed
         constexpr bool TOPLOAD_X = SDP_TOPLOAD != 0 && (T::QIN == Q_EXACT || T::DIN);
+        // fp32 reverse sweep: the K boundary values of a chunk travel through LDS as 16-byte accesses (K / 4 instead of K instructions each way)
+        constexpr bool VEC_BND = REV && PASS == PASS_BWD && KIND == CK_F32 && sizeof(slot_t) == 4 && K % 4 == 0 && SDP_VEC_BND;
+        // Exact zeros (see the chunk loop): the fp32 backward sweep skips the steps of chunks that can only produce +0, and (LAZY)
+        // does not fetch the state rows of a chunk it already knows to be one.  There is ONE place per iteration where the next
+        // chunk's rows are requested, and the request is always issued: a fetch that is not wanted goes through a buffer
+        // descriptor of zero records, which returns zeros without touching memory.  (Loads under a branch, or at a second site
+        // for the rare case, make the loaded registers phi nodes: copies behind waits, and a conservative wait in front of the
+        // rows' first use -- measured, both.)
+        constexpr bool ZSKIP = REV && PASS == PASS_BWD && KIND == CK_F32 && !SDP_BWD_HALF && !ABL_NOMATH && SDP_ZERO_SKIP;
+        constexpr bool LAZY = ZSKIP && !ABL_NOLOAD && (TOPLOAD || TOPLOAD_X) && SDP_ZERO_SKIP > 1;
+        bool known_zero = false;   // the chunk about to be processed is a zero chunk (found out an iteration ahead): its rows were not fetched
+        int zring = 0;             // bit h: half h of the output ring is known to hold +0 everywhere (written by a zero chunk)
+        auto load_rows = [&](int tn, auto set_tag, bool wanted) {   // state rows of the chunk that starts at step tn -> set S
+            if constexpr (TOPLOAD) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const char *>(p.qin) + ps_idx * p.st_ps, wanted ? ST_RECORDS : 0u);
+#pragma unroll
+                for (int jj = 0; jj < QROWS; ++jj)
+                    rq2[decltype(set_tag)::value][jj] = __builtin_amdgcn_raw_buffer_load_b128(rs, q_lane, q20_soff(tn + 16 * (jj / 5), jj % 5), AUX_ST_LOAD);
+            } else if constexpr (T::QIN == Q_EXACT) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const char *>(p.qin) + ps_idx * p.st2_ps, wanted ? ST_RECORDS : 0u);
+#pragma unroll
+                for (int k = 0; k < K; ++k) rqx2[decltype(set_tag)::value][k] = load_f2(rs, tn, k);
+            }
+        };
+        // LAZY: will the chunk that starts at step tn meet nothing but +0 from outside -- the K boundary values of the strip
+        // below and, where it holds the terminal cell, the cotangent?  (With +0 carries that makes it a zero chunk.)  Asked an
+        // iteration ahead, so only if the strip below has published those columns already (`block`: wait for it -- the strip's
+        // first chunk, which has to wait for them anyway); false = not known.  Chunks that reach over the matrix's edges and
+        // strips whose boundary comes through the bridge from another workgroup are left to find out when their turn comes.
+        auto boundary_zero = [&](int tn, bool block) -> bool {
+            if constexpr (LAZY) {
+                if (SDP_EXP_BUILD && (p.dbg & 4096)) return false;
+                unsigned any = (t_final >= tn && t_final < tn + K) ? __float_as_uint(et) : 0u;
+                if (has_pred) {
+                    const int c_lo_n = tn - 63;
+                    if (imported) return false;
+                    const bool inner = c_lo_n >= 0 && c_lo_n + K <= m;
+                    const int need = (c_lo_n + K > 0 && c_lo_n < m) ? m - (c_lo_n < 0 ? 0 : c_lo_n) : 0;   // (as in the chunk's own acquire)
+                    bool ready = need == 0;
+                    for (int spin = 0; !ready && spin < (block ? (1 << 21) : 1); ++spin) {
+                        if (__builtin_amdgcn_readfirstlane(lds_load_i32(prog + 4 * pword)) >= pbase + need) {
+                            ready = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (!ready) return false;   // (a hand-off that never comes is reported by the chunk's own acquire)
+                    if (!inner) {   // over an edge of the matrix (the first and the last chunks of a strip): columns that exist, one by one
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            const int col = c_lo_n + k;
+                            if (col >= 0 && col < m) any |= (unsigned)bnd_in[col];
+                        }
+                    } else if constexpr (VEC_BND) {
+                        const uint4 *src = reinterpret_cast<const uint4 *>(bnd_in + (c_lo_n - 1));   // columns tn - 64 .. tn - 33: one more than needed
+                        const uint4 v0 = src[0];
+                        any |= v0.y | v0.z | v0.w;
+#pragma unroll
+                        for (int g = 1; g < K / 4; ++g) {
+                            const uint4 v = src[g];
+                            any |= v.x | v.y | v.z | v.w;
+                        }
+                        any |= (unsigned)bnd_in[c_lo_n + K - 1];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) any |= (unsigned)bnd_in[c_lo_n + k];
+                    }
+                }
+                return __builtin_amdgcn_ballot_w64(any != 0) == 0;
+            } else {
+                return false;
+            }
+        };
 
 
         // Staged INPUT geometry.  Row-major tensors enter as K-column blocks, four columns (one dwordx4) per
@@ -1041,7 +1120,7 @@ __device__ __forceinline__ void sweep(const Params &p)
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 if constexpr (ABL_NOLOAD) rqx2[0][k] = rqx2[1][k] = make_float2(0.25f + 1e-3f * k, 0.5f - 1e-3f * lane);
-                else rqx2[0][k] = load_f2(rs_qx, c_first * K, k);
+                else if constexpr (!LAZY) rqx2[0][k] = load_f2(rs_qx, c_first * K, k);   // (LAZY: below)
             }
         }
         if constexpr (T::QIN == Q_PACKED) {
@@ -1057,7 +1136,7 @@ __device__ __forceinline__ void sweep(const Params &p)
 #pragma unroll
                 for (int jj = 0; jj < QROWS; ++jj) {
                     if constexpr (ABL_NOLOAD) rq2[0][jj] = rq2[1][jj] = (u32x4q){0x20003000u + 64 * jj + lane, 0x20003000u, 0x20003000u, 0x20003000u};
-                    else load_q20(c_first * K, jj, std::integral_constant<int, 0>{});
+                    else if constexpr (!LAZY) load_q20(c_first * K, jj, std::integral_constant<int, 0>{});
                 }
             }
         }
@@ -1067,6 +1146,16 @@ __device__ __forceinline__ void sweep(const Params &p)
                 if constexpr (ABL_NOLOAD) rdd2[0][k] = rdd2[1][k] = make_float2(0.25f + 1e-3f * k, 0.5f - 1e-3f * lane);
                 else rdd2[0][k] = load_d(c_first * K, k);
             }
+        }
+        zring = 0;
+        if constexpr (LAZY) {
+            // the strip's first chunk: its carries are the initial ones; if they and everything that reaches it from outside are
+            // known to be +0 it is a zero chunk and its rows are not fetched.  Not waited for: the strip below is usually a lag
+            // behind at this point, the fetch overlaps that wait, and a fetch held back until the boundary values are there
+            // would put its latency on every hand-off of the ramp (measured: +7 us at 256 x 512^2).
+            const unsigned cbits = __float_as_uint(cy.fa) | __float_as_uint(cy.fb) | __float_as_uint(cy.fc);
+            known_zero = __builtin_amdgcn_ballot_w64(cbits != 0) == 0 && boundary_zero(c_first * K, false);
+            load_rows(c_first * K, std::integral_constant<int, 0>{}, !known_zero);
         }
         load_block(c_first);
         write_block(c_first);
@@ -1618,7 +1707,7 @@ __device__ __forceinline__ void sweep(const Params &p)
         // conditional flush counted as zero stores -- every chunk then waited until its own, just issued, output stores had
         // been acknowledged by memory before it touched the first record (`s_waitcnt vmcnt(14)` where 30 were in flight:
         // a write round trip per chunk, the 35 us between the backward sweep on cache-served tensors and on real ones).
-        auto flush_out = [&](int t0, int par, bool active) {
+        auto flush_out = [&](int t0, int par, bool active, bool zero = false) {   // zero: both halves of the ring are known to hold +0
             if constexpr (T::SOUT > 0) {
                 const int ubase = (i0 * ld + t0) * 4;
                 if constexpr (FLUSH2) {
@@ -1629,7 +1718,10 @@ __device__ __forceinline__ void sweep(const Params &p)
                     if (flush_plain && SDP_FLUSH_FAST) {
                         float2 vals[K / 2];
                         const int thr_l = K - 1 - f2_rl - f2_el;   // (k2 & 7) < thr_l  <=>  sfull < K - 1
-                        if (par) {
+                        if (zero) {
+#pragma unroll
+                            for (int k2 = 0; k2 < K / 2; ++k2) vals[k2] = make_float2(0.f, 0.f);
+                        } else if (par) {
 #pragma unroll
                             for (int k2 = 0; k2 < K / 2; ++k2) {
                                 const int idx = ((k2 & 7) + 32 * (k2 >> 3)) * PO + (k2 & 7) + f2_l + ((k2 & 7) < thr_l ? K : -K);
@@ -1648,6 +1740,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                             else __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(vals[k2].x), __float_as_uint(vals[k2].y)}, rs_out, (unsigned)(f2_g * 4),
                                                                        ubase + (c_r * ld - 32 * (k2 >> 3)) * 4, AUX_OUT_STORE);
                         }
+                        if constexpr (LAZY) __builtin_amdgcn_s_waitcnt(0x4F70);   // vmcnt(16): everything older than these K / 2 stores
                     } else if ((m & 1) == 0) {   // (uniform)
                         float2 vals[K / 2];
 #pragma unroll
@@ -1668,6 +1761,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                             if constexpr (ABL_NOSTORE) { keep(vals[k2].x); keep(vals[k2].y); }
                             else __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(vals[k2].x), __float_as_uint(vals[k2].y)}, rs_out, off, 0, AUX_OUT_STORE);
                         }
+                        if constexpr (LAZY) __builtin_amdgcn_s_waitcnt(0x4F70);   // vmcnt(16)
                     } else {   // an odd number of columns (per-pair lengths): a column at a time, indices formed on the spot
 #pragma unroll
                         for (int k = 0; k < K; ++k) {
@@ -1680,6 +1774,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                             if constexpr (ABL_NOSTORE) { unsigned vv = __float_as_uint(v) ^ off; keep(vv); }
                             else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, off, 0, AUX_OUT_STORE);
                         }
+                        if constexpr (LAZY) __builtin_amdgcn_s_waitcnt(0x8F70);   // vmcnt(32)
                     }
                 } else {
                     float vals[K];
@@ -1698,6 +1793,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vals[k]), rs_out, off, 0, AUX_OUT_STORE);
                         }
                     }
+                    if constexpr (LAZY) __builtin_amdgcn_s_waitcnt(0x0F70 | (K & 15) | ((K >> 4) << 14));   // vmcnt(K)
                 }
             }
         };
@@ -1726,42 +1822,6 @@ __device__ __forceinline__ void sweep(const Params &p)
                         p.trace[((((b >> 6) * 4 + wave) * 4 + (parts ? part : sidx / W)) * 40 + ci) * 8 + k] = __builtin_readcyclecounter();
                 }
             };
-            stamp_rev(0);
-            // Everything this wave has in flight is a whole iteration old: the rows loaded at the top of the previous iteration (the
-            // ones this chunk consumes) and that iteration's output stores.  Waiting for all of it HERE, with the builtin the
-            // compiler's bookkeeping understands, is free -- and leaves the compiler nothing to wait for at the rows' first use.
-            // Left to itself it waits there with vmcnt(10): "the ten loads issued since may stay out" -- but it does not count
-            // the 16 output stores issued behind those loads, the counter retires in order, and so the ten youngest operations
-            // are stores and the wait takes the rows just requested for the NEXT chunk along: the prefetch distance shrinks to
-            // the few hundred cycles of the flush.
-            if constexpr (ROT && SDP_PROLOGUE_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);
-            if constexpr (TOPLOAD_X && !ABL_NOLOAD) {
-                if (ci < nchunks) {   // (uniform; the extra flush iterations load nothing)
-                    const int c_ = REV ? nchunks - 1 - ci : ci;
-                    const int tn = (ci + 1 < nchunks) ? (c_ + dir) * K : c_ * K;   // the last chunk re-reads its own rows: harmless
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        if constexpr (T::QIN == Q_EXACT) rqx2[nxt_t::value][k] = load_f2(rs_qx, tn, k);
-                        if constexpr (T::DIN) rdd2[nxt_t::value][k] = load_d(tn, k);
-                    }
-                }
-            }
-            if constexpr (TOPLOAD) {
-                if (ci < nchunks) {   // (uniform; the extra flush iterations load nothing)
-                    const int c_ = nchunks - 1 - ci;
-                    const int tn = (ci + 1 < nchunks) ? (c_ - 1) * K : c_ * K;   // the last chunk re-reads its own records: harmless
-#pragma unroll
-                    for (int jj = 0; jj < QROWS; ++jj) load_q20(tn, jj, nxt_t{});
-                }
-            }
-            if constexpr (T::SOUT > 0) {
-                flush_out(pf_t0, pf_par, ci > 0);
-                stamp_rev(1);
-                if (ci >= nchunks) {
-                    pf_t0 = -K, pf_par = 1;
-                    return;
-                }
-            }
             const int c = REV ? nchunks - 1 - ci : ci;
             const int t0 = c * K;
             const bool more = ci + 1 < nchunks;
@@ -1770,25 +1830,6 @@ __device__ __forceinline__ void sweep(const Params &p)
             // block set that chunk c+dir needs in addition; its loads are issued one per step below
             // (the last chunk re-reads its own set: harmless, keeps the step body branch-free)
             const int bb_new = more ? (REV ? c - 1 : c + 2) : c;
-            // experiments build, sdp_set_trace: stamps 4..7 of a chunk's two block slots bracket the chunk's memory pipeline
-            auto stamp_chunk = [&](int blk, int k) {
-                if constexpr (SDP_EXP_BUILD != 0 && PASS == PASS_FWD) {
-                    if (p.trace && !(p.dbg & 1024) && (b & 63) == 0 && b < 256 && lane == 0 && (parts ? part < 4 : sidx / W < 2) && blk < 40)
-                        p.trace[((((b >> 6) * 4 + wave) * 4 + (parts ? part : sidx / W)) * 40 + blk) * 8 + k] = __builtin_readcyclecounter();
-                }
-            };
-            stamp_chunk(t0 / WB, 4);
-            load_block(bb_new);
-            stamp_chunk(t0 / WB, 5);
-
-            if constexpr (FWD_SUB) {
-                fwd_blocks(c, t0, [&]() { if (more) write_block(bb_new); });
-                stamp_chunk(t0 / WB + 1, 4);
-                if constexpr (!SDP_STAGE_EARLY) { if (more) write_block(bb_new); }
-                stamp_chunk(t0 / WB + 1, 5);
-                return;
-            }
-
             // ---- boundary values for the edge lane: broadcast LDS reads, off the dependency chain ----
             // HALF (fp32 backward sweep, one workgroup per pair; -DSDP_BWD_HALF=1): the chunk's 32 steps take their boundary
             // values in two halves of 16 and hand their own down in two halves, each with its progress word -- the strip below
@@ -1847,6 +1888,22 @@ __device__ __forceinline__ void sweep(const Params &p)
                             p.status[1] = b, p.status[2] = s, p.status[3] = c | (PASS << 24);
                         }
                     }
+                    if constexpr (VEC_BND && K0 == 0 && K1 == K) {
+                        if (c_lo >= 0 && c_lo + K <= m) {
+                            // columns t0 - 63 .. t0 - 32: the K four-byte slots from the aligned t0 - 64 on as K / 4 16-byte reads, plus one
+                            const uint4 *src = reinterpret_cast<const uint4 *>(bnd_in + (c_lo - 1));
+                            unsigned w[K + 1];
+#pragma unroll
+                            for (int g = 0; g < K / 4; ++g) {
+                                const uint4 v = src[g];
+                                w[4 * g] = v.x, w[4 * g + 1] = v.y, w[4 * g + 2] = v.z, w[4 * g + 3] = v.w;
+                            }
+                            w[K] = bnd_in[c_lo + K - 1];
+#pragma unroll
+                            for (int k = 0; k < K; ++k) bcv[k] = w[k + 1];
+                            return;
+                        }
+                    }
                     if (c_lo + K0 >= 0 && c_lo + K1 <= m) {
 #pragma unroll
                         for (int k = K0; k < K1; ++k) bcv[k] = bnd_in[c_lo + k];
@@ -1865,9 +1922,177 @@ __device__ __forceinline__ void sweep(const Params &p)
             using kc0 = std::integral_constant<int, 0>;
             using kch = std::integral_constant<int, K / 2>;
             using kc1 = std::integral_constant<int, K>;
+            u64 hist[K];  // the edge-facing carry after each step (published below by one lane)
+            const int par = c & 1;
+            float *lo = lds_out + lane * PO + par * K;  // this lane's row, this chunk's half of the ring
+            // ---- publish boundary values for the next strip (one lane), then the progress word ----
+            auto publish_range = [&](auto k0_tag, auto k1_tag, int *wf_frames_) {   // values of steps t0 + k, k in [K0, K1)
+                constexpr int K0 = decltype(k0_tag)::value, K1 = decltype(k1_tag)::value;
+                if (!has_succ) return;
+                // fwd: lane 63 produced column t0+k-63 at step k; rev: lane 0 produced column t0+k
+                const int p_lo = REV ? t0 : t0 - 63;
+                if (lane == PUB_LANE) {
+                    if constexpr (VEC_BND && K0 == 0 && K1 == K) {
+                        if (p_lo + K <= m) {   // (p_lo = t0: a multiple of K slots of four bytes)
+                            uint4 *dst = reinterpret_cast<uint4 *>(bnd_out + p_lo);
+#pragma unroll
+                            for (int g = 0; g < K / 4; ++g)
+                                dst[g] = make_uint4((unsigned)hist[4 * g], (unsigned)hist[4 * g + 1], (unsigned)hist[4 * g + 2], (unsigned)hist[4 * g + 3]);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) {
+                                const int col = p_lo + k;
+                                if (col < m) bnd_out[col] = (slot_t)hist[k];
+                            }
+                        }
+                    } else if (p_lo + K0 >= 0 && p_lo + K1 <= m) {
+#pragma unroll
+                        for (int k = K0; k < K1; ++k) bnd_out[p_lo + k] = (slot_t)hist[k];
+                    } else {
+#pragma unroll
+                        for (int k = K0; k < K1; ++k) {
+                            const int col = p_lo + k;
+                            if (col >= 0 && col < m) bnd_out[col] = (slot_t)hist[k];
+                        }
+                    }
+                }
+                int done;  // columns published so far (fwd: from the left; rev: from the right)
+                if (REV) {
+                    done = t0 + K0 < m ? m - (t0 + K0) : 0;
+                } else {
+                    const int hi = t0 + K1 - 63;
+                    done = hi < 0 ? 0 : (hi > m ? m : hi);
+                }
+                // LDS executes a wave's DS instructions in order, so the data written above is visible to
+                // any wave that observes this word (the asm statements also stop compiler reordering)
+                if constexpr (PASS == PASS_FWD && KIND == CK_EXP) {
+                    if (lane == PUB_LANE) {
+#pragma unroll
+                        for (int sb = 0; sb < K / WB; ++sb) frm_out[c * (K / WB) + sb] = wf_frames_[sb];
+                    }
+                }
+                if (lane == PUB_LANE && !(SDP_EXP_BUILD && (p.dbg & 8))) lds_store_i32(prog + 4 * oword, obase + done);
+                if constexpr (REV && KIND == CK_F32) {
+                    if (exported && t0 < m) {
+                        // the chunk's columns to the bridge row, one granule per lane (tag 0; columns past the matrix: dummies)
+                        const int col = t0 + lane;
+                        const unsigned gv = (lane < K && col < m) ? (unsigned)bnd_out[col] : 0u;
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        if (!(SDP_EXP_BUILD && (p.dbg & 8)))
+                            __builtin_amdgcn_raw_buffer_store_b64((u32x2){gv, 0u}, rs_xo, lane < K ? (unsigned)(col * 8) : OOB, 0, XB_AUX);
+                    }
+                }
+            };
+            stamp_rev(0);
+            bool zero_chunk = false;   // (ZSKIP) this chunk can only produce +0: see "exact zeros" below
+            // +0 bit for bit in every lane's three carries, in the K boundary values and -- where the chunk holds the terminal
+            // cell -- in the cotangent
+            auto zero_test = [&]() {
+                unsigned any = __float_as_uint(cy.fa) | __float_as_uint(cy.fb) | __float_as_uint(cy.fc);
+#pragma unroll
+                for (int k = 0; k < K; ++k) any |= lo32(bcv[k]);
+                if (t_final >= t0 && t_final < t0 + K) any |= __float_as_uint(et);
+                return __builtin_amdgcn_ballot_w64(any != 0) == 0 && !(SDP_EXP_BUILD && (p.dbg & 4096));
+            };
+            auto zero_fill_ring = [&]() {   // a zero chunk's outputs: +0 to its half of the ring, its boundary values, the row's copy of step K - 1
+#pragma unroll
+                for (int k = 0; k < K; ++k) hist[k] = 0;
+                if (!((zring >> par) & 1)) {   // (from the third chunk of a run on both halves are zero already)
+#pragma unroll
+                    for (int k = 0; k < K; ++k) lo[k] = 0.f;
+                    zring |= 1 << par;
+                }
+                if constexpr (FLUSH2) lo[-1 - par * K] = 0.f;   // (shared by both halves)
+            };
+            if constexpr (LAZY) {
+                // (the fp32 backward sweep waits inside its flush and requests rows further down: see there)
+            } else {
+            // Everything this wave has in flight is a whole iteration old: the rows loaded at the top of the previous iteration (the
+            // ones this chunk consumes) and that iteration's output stores.  Waiting for all of it HERE, with the builtin the
+            // compiler's bookkeeping understands, is free -- and leaves the compiler nothing to wait for at the rows' first use.
+            // Left to itself it waits there with vmcnt(10): "the ten loads issued since may stay out" -- but it does not count
+            // the 16 output stores issued behind those loads, the counter retires in order, and so the ten youngest operations
+            // are stores and the wait takes the rows just requested for the NEXT chunk along: the prefetch distance shrinks to
+            // the few hundred cycles of the flush.
+            if constexpr (ROT && SDP_PROLOGUE_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);
+            if constexpr (TOPLOAD_X && !ABL_NOLOAD) {
+                if (ci < nchunks) {   // (uniform; the extra flush iterations load nothing)
+                    const int c_ = REV ? nchunks - 1 - ci : ci;
+                    const int tn = (ci + 1 < nchunks) ? (c_ + dir) * K : c_ * K;   // the last chunk re-reads its own rows: harmless
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        if constexpr (T::QIN == Q_EXACT) rqx2[nxt_t::value][k] = load_f2(rs_qx, tn, k);
+                        if constexpr (T::DIN) rdd2[nxt_t::value][k] = load_d(tn, k);
+                    }
+                }
+            }
+            if constexpr (TOPLOAD) {
+                if (ci < nchunks) {   // (uniform; the extra flush iterations load nothing)
+                    const int c_ = nchunks - 1 - ci;
+                    const int tn = (ci + 1 < nchunks) ? (c_ - 1) * K : c_ * K;   // the last chunk re-reads its own records: harmless
+#pragma unroll
+                    for (int jj = 0; jj < QROWS; ++jj) load_q20(tn, jj, nxt_t{});
+                }
+            }
+            }
+            if constexpr (T::SOUT > 0) {
+                flush_out(pf_t0, pf_par, ci > 0, ZSKIP && zring == 3);
+                stamp_rev(1);
+                if (ci >= nchunks) {
+                    pf_t0 = -K, pf_par = 1;
+                    return;
+                }
+            }
+            if constexpr (LAZY) {
+                // The flush above ended with a wait for everything older than its own stores (flush_out, LAZY): this chunk's rows,
+                // requested an iteration ago, and that iteration's outputs -- free, and said with the builtin the compiler's
+                // bookkeeping understands, so that it has nothing to add at the rows' first use (a wait it places there takes the
+                // rows just requested for the NEXT chunk along).  Then: what kind of chunk is this one (known from the iteration
+                // before, or found out now from its boundary values), and -- if it is a zero chunk, whose carries stay +0 --
+                // will the next one be too?  Its rows are requested accordingly, at this one place, and a zero chunk leaves the
+                // iteration: no path from it reaches the steps.
+                static_assert(!LAZY || (T::SIN == 0 && T::SOUT > 0), "the zero-chunk path below stages no inputs");
+                if (known_zero) {
+                    zero_chunk = true;
+                } else {
+                    acquire(kc0{}, kc1{});
+                    zero_chunk = zero_test();
+                }
+                stamp_rev(2);
+                const bool next_zero = zero_chunk && more && boundary_zero(t0_next, false);
+                load_rows(t0_next, nxt_t{}, more && !next_zero);
+                known_zero = next_zero;
+                if (zero_chunk) {
+                    zero_fill_ring();
+                    stamp_rev(3);
+                    publish_range(kc0{}, kc1{}, nullptr);
+                    stamp_rev(4);
+                    pf_t0 = t0, pf_par = par;
+                    return;
+                }
+            }
+            // experiments build, sdp_set_trace: stamps 4..7 of a chunk's two block slots bracket the chunk's memory pipeline
+            auto stamp_chunk = [&](int blk, int k) {
+                if constexpr (SDP_EXP_BUILD != 0 && PASS == PASS_FWD) {
+                    if (p.trace && !(p.dbg & 1024) && (b & 63) == 0 && b < 256 && lane == 0 && (parts ? part < 4 : sidx / W < 2) && blk < 40)
+                        p.trace[((((b >> 6) * 4 + wave) * 4 + (parts ? part : sidx / W)) * 40 + blk) * 8 + k] = __builtin_readcyclecounter();
+                }
+            };
+            stamp_chunk(t0 / WB, 4);
+            load_block(bb_new);
+            stamp_chunk(t0 / WB, 5);
+
+            if constexpr (FWD_SUB) {
+                fwd_blocks(c, t0, [&]() { if (more) write_block(bb_new); });
+                stamp_chunk(t0 / WB + 1, 4);
+                if constexpr (!SDP_STAGE_EARLY) { if (more) write_block(bb_new); }
+                stamp_chunk(t0 / WB + 1, 5);
+                return;
+            }
+
             if constexpr (HALF) acquire(kch{}, kc1{});   // the reverse sweep starts with the chunk's upper steps
-            else acquire(kc0{}, kc1{});
-            stamp_rev(2);
+            else if constexpr (!LAZY) acquire(kc0{}, kc1{});   // (LAZY: further up, in front of the decision what kind of chunk this is)
+            if constexpr (!LAZY) stamp_rev(2);
 
             // ---- staged inputs of this chunk: one burst of LDS reads, off the dependency chain ----
             float in0[K], in1[K], in2[T::SIN > 2 ? K : 1];
@@ -1928,9 +2153,6 @@ __device__ __forceinline__ void sweep(const Params &p)
                 }
             };
 
-            u64 hist[K];  // the edge-facing carry after each step (published below by one lane)
-            const int par = c & 1;
-            float *lo = lds_out + lane * PO + par * K;  // this lane's row, this chunk's half of the ring
 
             // ---- K steps; EDGE=false is the mask-free body for chunks fully inside the matrix ----
             auto steps = [&](auto edge_tag, auto kk0_tag, auto kk1_tag) {   // steps kk in [KK0, KK1) of the chunk, in processing order
@@ -2280,7 +2502,19 @@ __device__ __forceinline__ void sweep(const Params &p)
                     --wf_skip;
                 }
             }
-            if (!wf_done && !HALF) {
+            // ---- exact zeros (fp32 backward sweep) ----
+            // E is a sum of products of weights along paths: away from the alignment it underflows to exactly +0 (47 % of the
+            // cells of the benchmark's soft scores, nearly all of a peaked alignment).  If every lane's three carries, the K
+            // boundary values from the strip below and (where the chunk holds the terminal cell) the cotangent are +0 bit for
+            // bit, every step of the chunk computes e = 0 + 0, q * 0 and fma(q, 0, 0) with finite q >= 0: +0 outputs, +0
+            // carries, +0 values for the strip above -- so those are written without running the steps.  (-0, which a
+            // negative cotangent leaves behind, is not taken: sums of mixed zeros depend on the order.)
+            if constexpr (ZSKIP) {
+                if constexpr (!LAZY) zero_chunk = zero_test();   // (LAZY: a zero chunk never gets here)
+                if (zero_chunk) zero_fill_ring();
+                else zring &= ~(1 << par);
+            }
+            if (!wf_done && !HALF && !zero_chunk) {
 #pragma unroll
                 for (int sb = 0; sb < K / WB; ++sb) wf_frames[sb] = FRAME_NONE;
                 prepass();
@@ -2315,51 +2549,6 @@ __device__ __forceinline__ void sweep(const Params &p)
                 }
             }
 
-            // ---- publish boundary values for the next strip (one lane), then the progress word ----
-            auto publish_range = [&](auto k0_tag, auto k1_tag, int *wf_frames_) {   // values of steps t0 + k, k in [K0, K1)
-                constexpr int K0 = decltype(k0_tag)::value, K1 = decltype(k1_tag)::value;
-                if (!has_succ) return;
-                // fwd: lane 63 produced column t0+k-63 at step k; rev: lane 0 produced column t0+k
-                const int p_lo = REV ? t0 : t0 - 63;
-                if (lane == PUB_LANE) {
-                    if (p_lo + K0 >= 0 && p_lo + K1 <= m) {
-#pragma unroll
-                        for (int k = K0; k < K1; ++k) bnd_out[p_lo + k] = (slot_t)hist[k];
-                    } else {
-#pragma unroll
-                        for (int k = K0; k < K1; ++k) {
-                            const int col = p_lo + k;
-                            if (col >= 0 && col < m) bnd_out[col] = (slot_t)hist[k];
-                        }
-                    }
-                }
-                int done;  // columns published so far (fwd: from the left; rev: from the right)
-                if (REV) {
-                    done = t0 + K0 < m ? m - (t0 + K0) : 0;
-                } else {
-                    const int hi = t0 + K1 - 63;
-                    done = hi < 0 ? 0 : (hi > m ? m : hi);
-                }
-                // LDS executes a wave's DS instructions in order, so the data written above is visible to
-                // any wave that observes this word (the asm statements also stop compiler reordering)
-                if constexpr (PASS == PASS_FWD && KIND == CK_EXP) {
-                    if (lane == PUB_LANE) {
-#pragma unroll
-                        for (int sb = 0; sb < K / WB; ++sb) frm_out[c * (K / WB) + sb] = wf_frames_[sb];
-                    }
-                }
-                if (lane == PUB_LANE && !(SDP_EXP_BUILD && (p.dbg & 8))) lds_store_i32(prog + 4 * oword, obase + done);
-                if constexpr (REV && KIND == CK_F32) {
-                    if (exported && t0 < m) {
-                        // the chunk's columns to the bridge row, one granule per lane (tag 0; columns past the matrix: dummies)
-                        const int col = t0 + lane;
-                        const unsigned gv = (lane < K && col < m) ? (unsigned)bnd_out[col] : 0u;
-                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                        if (!(SDP_EXP_BUILD && (p.dbg & 8)))
-                            __builtin_amdgcn_raw_buffer_store_b64((u32x2){gv, 0u}, rs_xo, lane < K ? (unsigned)(col * 8) : OOB, 0, XB_AUX);
-                    }
-                }
-            };
             if constexpr (HALF) {
                 // upper half of the chunk (steps t0 + 31 .. t0 + 16), hand it down, lower half, hand it down
                 if (interior) steps(std::false_type{}, kc0{}, kch{});
@@ -2373,7 +2562,9 @@ __device__ __forceinline__ void sweep(const Params &p)
                 stamp_rev(3);
                 publish_range(kc0{}, kc1{}, wf_frames);
             }
-            if constexpr (FLUSH2) lo[-1 - par * K] = lo[K - 1];   // step 31's value once more, at position -1 of the row (see FLUSH2)
+            if constexpr (FLUSH2) {
+                if (!zero_chunk) lo[-1 - par * K] = lo[K - 1];   // step 31's value once more, at position -1 of the row (see FLUSH2)
+            }
             stamp_rev(4);
 
             // ---- flush: one memory-aligned K-element block per row (see fo_* above) ----

@@ -276,7 +276,8 @@ int sdp_plan_parts(int pass, int B, int N, int M, int has_lens, int exact_state,
  * results.  bit0/1/2: inputs / outputs / state of every pair alias pair 0 (all traffic cache-served); bit3: strips
  * never publish their progress, so every hand-off times out (tests the SDP_E_HANDOFF path); 16 / 32: scores kernel choice;
  * 64: never spread a pair over several workgroups (128 / 256: not in the backward / forward sweep); 512: wherever possible;
- * 1024: sdp_set_trace stamps the backward sweep instead of the forward; 2048: backward of the scores with dS in a pass of its own.
+ * 1024: sdp_set_trace stamps the backward sweep instead of the forward; 2048: backward of the scores with dS in a pass of its own;
+ * 4096: the backward sweep runs the steps of all-zero chunks too (A/B of the exact-zero skip; same results).
  * Returns the old mask. */
 int sdp_set_debug(int mask);
 /* Cycle stamps of the forward sweep (tools/fwd_trace.py): a device buffer of >= 40 KiB, or NULL to switch it off. */

@@ -239,3 +239,48 @@ print("captured-first-launch ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "captured-first-launch ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_exact_zero_chunks_are_skipped_without_changing_a_bit():
+    """The fp32 backward sweep does not run the steps of a chunk whose carries, boundary values and cotangent are all
+    +0 (sdp_kernels.hip, "exact zeros").  Experiments build, debug bit 4096 runs them all the same: E must be equal
+    bit for bit -- signs of zeros included -- on soft scores, on peaked ones (almost everything is zero), with zero and
+    negative cotangents (-0 is never skipped), Smith-Waterman, per-pair lengths, both state forms and pairs spread
+    over several workgroups."""
+    lib = _exp_lib()
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(0).cuda_stream
+    cases = [(6, 512, 512, 0, 1.0, False), (3, 700, 330, 1, 8.0, False), (5, 300, 900, 0, 30.0, True), (2, 1100, 1030, 0, 4.0, True),
+             (20, 1024, 1024, 0, 8.0, False)]
+    nzero = 0
+    for ci, (B, N, M, variant, steep, use_lens) in enumerate(cases):
+        theta, A = datagen.theta_A(4400 + ci, B, N, M)
+        theta *= steep
+        et_np = np.ones(B, np.float32)
+        et_np[0] = -2.5
+        if B > 2:
+            et_np[1] = 0.0
+            et_np[2] = -0.0
+        lens = None
+        if use_lens:
+            lens = torch.from_numpy(np.minimum(datagen.lengths(4500 + ci, B, 1, N), np.array([N, M])).astype(np.int32)).to(dev)
+        t, a, et = torch.from_numpy(theta).to(dev), torch.from_numpy(A).to(dev), torch.from_numpy(et_np).to(dev)
+        lp = None if lens is None else lens.data_ptr()
+        for exact in (0, 0x100):
+            nbytes = lib.sdp_state_bytes_v(B, N, M, variant | exact)
+            state = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=dev)
+            vt = torch.empty(B, dtype=torch.float32, device=dev)
+            assert lib.sdp_forward_f32(t.data_ptr(), a.data_ptr(), state.data_ptr(), vt.data_ptr(), B, N, M, lp, variant | exact, 0, stream) == 0, lib.sdp_last_error_string()
+            outs = []
+            for mask in (0, 4096):
+                lib.sdp_set_debug(mask)
+                try:
+                    E = torch.full((B, N, M), float("nan"), device=dev)
+                    assert lib.sdp_backward_f32(et.data_ptr(), state.data_ptr(), E.data_ptr(), B, N, M, lp, variant | exact, 0, stream) == 0, lib.sdp_last_error_string()
+                    torch.cuda.synchronize()
+                finally:
+                    lib.sdp_set_debug(0)
+                outs.append(E.view(torch.int32).cpu().numpy())
+            assert np.array_equal(outs[0], outs[1]), (B, N, M, variant, exact)
+            nzero += int((outs[0] == 0).sum())
+    assert nzero > 0
