@@ -322,7 +322,10 @@ def main():
                            "global_batch": B * world, "N": N, "M": M, "variant": args.variant,
                            "parallelism": f"batch-sharded x{world}", "gather": args.gather if world > 1 else "none",
                            "backend": ("rccl" if backend == "nccl" else backend + (" (ranks share one GPU: test mode)" if shared else "")) if world > 1 else "none",
-                           "arith": "fwd: scaled exp-domain f32 (exact power-of-two rescaling); bwd: f32; adjoint pair: f64 carries; f32 storage"},
+                           "arith": "fwd: scaled exp-domain f32 (exact power-of-two rescaling); bwd: f32; adjoint pair: f64 carries; f32 storage",
+                           "data_dependent": "the backward sweep does not run 32-step chunks whose outputs are exactly +0 nor read their state "
+                                             "(bit-identical E; 47 % of E's cells, 29 % of the chunks on this data: DESIGN.md 3.8); the forward sweep "
+                                             "-- the kernel the roofline is quoted on -- does all of its work"},
                 "kernel_ms": ms,
                 "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
