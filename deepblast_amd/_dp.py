@@ -27,8 +27,10 @@ def _validate(theta, A, operator, allow_none_operator):
     # error behaviour of the reference GPU variant (nw_cuda.py:171-175)
     if operator != 'softmax' and not (allow_none_operator and operator is None):
         raise NotImplementedError("HIP variant only supports 'softmax' operator")
-    if theta.dtype != torch.float32 or A.dtype != torch.float32:
-        raise TypeError("HIP variant only supports torch.float32 type")
+    # float32 (the reference's GPU classes take nothing else, nw_cuda.py:174-175) or float64 (its CPU classes take what they
+    # are given, and its own tests hand them float64: tests/test_nw.py:46-90) -- both tensors alike
+    if theta.dtype not in (torch.float32, torch.float64) or A.dtype != theta.dtype:
+        raise TypeError(f"HIP variant supports torch.float32 (and, unoptimised, torch.float64) tensors of one dtype; got {theta.dtype} and {A.dtype}")
     if theta.dim() != 3 or A.shape != theta.shape:
         raise ValueError(f"theta and A must both be (B, N, M); got {tuple(theta.shape)} and {tuple(A.shape)}")
     if A.device != theta.device:
@@ -43,8 +45,8 @@ def _same_device(ref, **others):
             continue
         if t.device != ref.device:
             raise ValueError(f"{name} is on {t.device}, expected {ref.device}")
-        if t.dtype != torch.float32:
-            raise TypeError(f"{name} must be torch.float32, got {t.dtype}")
+        if t.dtype != ref.dtype:
+            raise TypeError(f"{name} must be {ref.dtype}, got {t.dtype}")
 
 
 def make_functions(variant, prefix, allow_none_operator=False):
@@ -97,6 +99,8 @@ def make_functions(variant, prefix, allow_none_operator=False):
         @staticmethod
         def forward(ctx, theta, A, operator, lens=None, exact_state=False):
             _validate(theta, A, operator, allow_none_operator)
+            if theta.dtype == torch.float64:
+                exact_state = _engine.F64   # (truthy: the state serves all four sweeps, as with exact_state=True)
             eng = _engine.get_engine()
             Vt, Q = eng.forward(theta.detach(), A.detach(), variant, lens, exact_state=exact_state)
             ctx.save_for_backward(theta, A, Q)

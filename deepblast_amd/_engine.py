@@ -31,6 +31,7 @@ EXACT_STATE = 0x100  # include/sdp.h: SDP_EXACT_STATE
 ET_BROADCAST = 0x200  # include/sdp.h: SDP_ET_BROADCAST
 REF_ROUNDING = 0x400  # include/sdp.h: SDP_REF_ROUNDING
 REF = "ref"           # value of `exact_state` that selects it: the state is then the reference's own (B, N, M, 3) fp32
+F64 = "f64"           # value of `exact_state` that rides along with float64 tensors: the state is (B, N, M, 3) float64
 TRACEBACK_RULES = {"cpu": 0, "cuda": 1}  # include/sdp.h: SDP_TRACEBACK_CPU / SDP_TRACEBACK_CUDA
 
 
@@ -126,6 +127,8 @@ class HipEngine:
         adjoint sweeps need (include/sdp.h, SDP_EXACT_STATE); "ref": the reference's arithmetic and its own
         (B,N,M,3) fp32 Q (SDP_REF_ROUNDING) -- the other three sweeps must then be asked for the same."""
         dev = self._dev(theta)
+        if theta.dtype == torch.float64:
+            return self._forward_f64(theta, A, variant, lens, dev)
         self._check(theta, theta=theta, A=A)
         theta, A = theta.contiguous(), A.contiguous()
         B, N, M = theta.shape
@@ -155,6 +158,10 @@ class HipEngine:
         B, N, M = shape
         if Et.device != state.device:
             raise ValueError(f"Et is on {Et.device}, expected {state.device}")
+        if state.dtype == torch.float64:
+            if pair_range is not None or out is not None:
+                raise ValueError("the float64 path sweeps whole batches (no pair_range / out)")
+            return self._backward_f64(Et, state, (B, N, M), variant, lens, dev)
         Et, bcast = self._et(Et, B)
         lens = self._lens(lens, B, state.device)
         E = torch.empty((B, N, M), dtype=torch.float32, device=state.device) if out is None else out
@@ -193,6 +200,8 @@ class HipEngine:
         for name, t in (("Ztheta", Ztheta), ("ZA", ZA)):
             if t is not None and t.device != state.device:
                 raise ValueError(f"{name} is on {t.device}, expected {state.device}")
+        if state.dtype == torch.float64:
+            return self._adjoint_forward_f64(state, Ztheta, ZA, variant, lens, dev)
         Ztheta = Ztheta.to(torch.float32).contiguous()
         B, N, M = Ztheta.shape
         if ZA is not None:
@@ -226,6 +235,8 @@ class HipEngine:
     def adjoint_backward(self, E, state, state_d, variant, lens=None, ref=False):
         """-> Ed (B,N,M).  Replaces _adjoint_backward_pass_kernel (nw_cuda.py:160-165).  ref: as for adjoint_forward."""
         dev = self._dev(state)
+        if state.dtype == torch.float64:
+            return self._adjoint_backward_f64(E, state, state_d, variant, lens, dev)
         self._check(state, E=E, state_d=state_d)
         E = E.contiguous()
         B, N, M = E.shape
@@ -235,6 +246,73 @@ class HipEngine:
             rc = self.lib.sdp_adjoint_backward_f32(_ptr(E), _ptr(state), _ptr(state_d), _ptr(Ed), B, N, M,
                                                    _ptr(lens), self._v(3, variant) | (REF_ROUNDING if ref else 0), dev, self._stream(dev))
         _lib.check(rc, "sdp_adjoint_backward_f32")
+        return Ed
+
+    # ---- float64 tensors (include/sdp.h: sdp_*_f64) --------------------------------------
+    # The reference's CPU classes take float64 as it comes (its tests: decoding, gradcheck, gradgradcheck on .double()
+    # tensors, deepblast/tests/test_nw.py:46-90).  Here: the reference-arithmetic kernels with float64 storage, one
+    # workgroup per pair -- for tests and small problems, not a second fast path.  The state is the reference's own
+    # (B, N, M, 3) weights in float64, and the other three sweeps recognise it by its dtype.
+    @staticmethod
+    def _check64(ref, **tensors):
+        for name, t in tensors.items():
+            if t is None:
+                continue
+            if t.dtype != torch.float64:
+                raise TypeError(f"{name} must be torch.float64 like the other tensors of this call, got {t.dtype}")
+            if t.device != ref.device:
+                raise ValueError(f"{name} is on {t.device}, expected {ref.device}")
+
+    def _forward_f64(self, theta, A, variant, lens, dev):
+        self._check64(theta, theta=theta, A=A)
+        theta, A = theta.contiguous(), A.contiguous()
+        B, N, M = theta.shape
+        lens = self._lens(lens, B, theta.device)
+        state = torch.empty((B, N, M, 3), dtype=torch.float64, device=theta.device)
+        Vt = torch.empty(B, dtype=torch.float64, device=theta.device)
+        with torch.cuda.device(dev), self._bracket("sdp_f64_fwd_kernel"):
+            rc = self.lib.sdp_forward_f64(_ptr(theta), _ptr(A), _ptr(state), _ptr(Vt), B, N, M, _ptr(lens), variant, dev, self._stream(dev))
+        _lib.check(rc, "sdp_forward_f64")
+        return Vt, state
+
+    def _backward_f64(self, Et, state, shape, variant, lens, dev):
+        B, N, M = shape
+        Et = Et.to(torch.float64)
+        bcast = Et.numel() == 1
+        if not bcast:
+            Et = Et.expand(B).contiguous()
+        lens = self._lens(lens, B, state.device)
+        E = torch.empty((B, N, M), dtype=torch.float64, device=state.device)
+        with torch.cuda.device(dev), self._bracket("sdp_f64_bwd_kernel"):
+            rc = self.lib.sdp_backward_f64(_ptr(Et), _ptr(state), _ptr(E), B, N, M, _ptr(lens), variant | (ET_BROADCAST if bcast else 0),
+                                           dev, self._stream(dev))
+        _lib.check(rc, "sdp_backward_f64")
+        return E
+
+    def _adjoint_forward_f64(self, state, Ztheta, ZA, variant, lens, dev):
+        Ztheta = Ztheta.to(torch.float64).contiguous()
+        B, N, M = Ztheta.shape
+        if ZA is not None:
+            ZA = ZA.to(torch.float64).contiguous()
+        lens = self._lens(lens, B, state.device)
+        state_d = torch.empty((B, N, M, 3), dtype=torch.float64, device=state.device)
+        Vtd = torch.empty(B, dtype=torch.float64, device=state.device)
+        with torch.cuda.device(dev), self._bracket("sdp_f64_adj_fwd_kernel"):
+            rc = self.lib.sdp_adjoint_forward_f64(_ptr(state), _ptr(Ztheta), _ptr(ZA), _ptr(Vtd), _ptr(state_d), B, N, M, _ptr(lens),
+                                                  variant, dev, self._stream(dev))
+        _lib.check(rc, "sdp_adjoint_forward_f64")
+        return Vtd, state_d
+
+    def _adjoint_backward_f64(self, E, state, state_d, variant, lens, dev):
+        self._check64(state, E=E, state_d=state_d)
+        E = E.contiguous()
+        B, N, M = E.shape
+        lens = self._lens(lens, B, state.device)
+        Ed = torch.empty((B, N, M), dtype=torch.float64, device=state.device)
+        with torch.cuda.device(dev), self._bracket("sdp_f64_adj_bwd_kernel"):
+            rc = self.lib.sdp_adjoint_backward_f64(_ptr(E), _ptr(state), _ptr(state_d), _ptr(Ed), B, N, M, _ptr(lens), variant, dev,
+                                                   self._stream(dev))
+        _lib.check(rc, "sdp_adjoint_backward_f64")
         return Ed
 
     def traceback(self, grad, lens=None, rule="cpu"):

@@ -40,6 +40,17 @@ SIGNATURES = {
     "sdp_adjoint_backward_f32": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int, _c_i32p, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_void_p]),
+    "sdp_state_bytes_f64": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "sdp_forward_f64": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_int, _c_i32p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "sdp_backward_f64": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        _c_i32p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "sdp_adjoint_forward_f64": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_int, _c_i32p, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_void_p]),
+    "sdp_adjoint_backward_f64": (ctypes.c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int, _c_i32p, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_void_p]),
     "sdp_scores_f32": (ctypes.c_int, [_c_f32p] * 6 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "sdp_scores_backward_ws_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "sdp_scores_backward_f32": (ctypes.c_int, [_c_f32p] * 13 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),

@@ -748,6 +748,76 @@ int sdp_adjoint_backward_f32(const float *E, const float *state, const float *st
     return launch(sdp::PASS_ABWD, p, device, stream, false, vb.waves);
 }
 
+// ---- float64 tensors (sdp.h): the reference-arithmetic kernels of sdp_ref.hip with float64 storage ----
+size_t sdp_state_bytes_f64(int B, int N, int M)
+{
+    if (B <= 0 || N <= 0 || M <= 0) return 0;
+    return (size_t)B * N * M * 3 * sizeof(double);
+}
+
+static int f64_variant(int variant, const char *who, bool &et_bcast)
+{
+    et_bcast = (variant & SDP_ET_BROADCAST) != 0;
+    const int v = variant & ~SDP_ET_BROADCAST;
+    if (v != SDP_NW && v != SDP_SW) {
+        snprintf(g_err, sizeof(g_err), "%s: variant must be SDP_NW or SDP_SW (float64 tensors take no state / rounding / wave flags)", who);
+        return -1;
+    }
+    return v;
+}
+
+int sdp_forward_f64(const double *theta, const double *A, double *state, double *Vt, int B, int N, int M,
+                    const int32_t *lens, int variant, int device, void *stream)
+{
+    if (!theta || !A || !state || !Vt) return fail(SDP_E_NULLPTR, "sdp_forward_f64: null pointer");
+    bool bc;
+    const int v = f64_variant(variant, "sdp_forward_f64", bc);
+    if (v < 0 || bc) return v < 0 ? SDP_E_VARIANT : fail(SDP_E_VARIANT, "sdp_forward_f64: SDP_ET_BROADCAST belongs to the backward sweep");
+    if (int rc = check_shape(B, N, M, v)) return rc;
+    if (int rc = ref_prepare(device)) return rc;
+    hipLaunchKernelGGL(sdp_f64_fwd_kernel, dim3(B), dim3(256), ref_lds(M), (hipStream_t)stream, theta, A, state, Vt, lens, N, M, v == SDP_SW);
+    return ref_launched("sdp_f64_fwd_kernel");
+}
+
+int sdp_backward_f64(const double *Et, const double *state, double *E, int B, int N, int M,
+                     const int32_t *lens, int variant, int device, void *stream)
+{
+    if (!Et || !state || !E) return fail(SDP_E_NULLPTR, "sdp_backward_f64: null pointer");
+    bool bc;
+    const int v = f64_variant(variant, "sdp_backward_f64", bc);
+    if (v < 0) return SDP_E_VARIANT;
+    if (int rc = check_shape(B, N, M, v)) return rc;
+    if (int rc = ref_prepare(device)) return rc;
+    hipLaunchKernelGGL(sdp_f64_bwd_kernel, dim3(B), dim3(256), ref_lds(M), (hipStream_t)stream, Et, state, E, lens, N, M, v == SDP_SW, bc ? 1 : 0);
+    return ref_launched("sdp_f64_bwd_kernel");
+}
+
+int sdp_adjoint_forward_f64(const double *state, const double *Ztheta, const double *ZA, double *Vtd, double *state_d,
+                            int B, int N, int M, const int32_t *lens, int variant, int device, void *stream)
+{
+    if (!state || !Ztheta || !Vtd || !state_d) return fail(SDP_E_NULLPTR, "sdp_adjoint_forward_f64: null pointer");
+    bool bc;
+    const int v = f64_variant(variant, "sdp_adjoint_forward_f64", bc);
+    if (v < 0 || bc) return v < 0 ? SDP_E_VARIANT : fail(SDP_E_VARIANT, "sdp_adjoint_forward_f64: SDP_ET_BROADCAST belongs to the backward sweep");
+    if (int rc = check_shape(B, N, M, v)) return rc;
+    if (int rc = ref_prepare(device)) return rc;
+    hipLaunchKernelGGL(sdp_f64_adj_fwd_kernel, dim3(B), dim3(256), ref_lds(M), (hipStream_t)stream, state, Ztheta, ZA, Vtd, state_d, lens, N, M);
+    return ref_launched("sdp_f64_adj_fwd_kernel");
+}
+
+int sdp_adjoint_backward_f64(const double *E, const double *state, const double *state_d, double *Ed,
+                             int B, int N, int M, const int32_t *lens, int variant, int device, void *stream)
+{
+    if (!E || !state || !state_d || !Ed) return fail(SDP_E_NULLPTR, "sdp_adjoint_backward_f64: null pointer");
+    bool bc;
+    const int v = f64_variant(variant, "sdp_adjoint_backward_f64", bc);
+    if (v < 0 || bc) return v < 0 ? SDP_E_VARIANT : fail(SDP_E_VARIANT, "sdp_adjoint_backward_f64: SDP_ET_BROADCAST belongs to the backward sweep");
+    if (int rc = check_shape(B, N, M, v)) return rc;
+    if (int rc = ref_prepare(device)) return rc;
+    hipLaunchKernelGGL(sdp_f64_adj_bwd_kernel, dim3(B), dim3(256), ref_lds(M), (hipStream_t)stream, E, state, state_d, Ed, lens, N, M);
+    return ref_launched("sdp_f64_adj_bwd_kernel");
+}
+
 static bool scores_force_f32()
 {
 #ifdef SDP_EXPERIMENTS

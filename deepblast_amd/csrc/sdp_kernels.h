@@ -193,6 +193,11 @@ __global__ void sdp_ref_fwd_kernel(const float *theta, const float *A, float *Q,
 __global__ void sdp_ref_bwd_kernel(const float *Et, const float *Q, float *E, const int *lens, int N, int M, int sw, int et_bcast);
 __global__ void sdp_ref_adj_fwd_kernel(const float *Q, const float *Ztheta, const float *ZA, float *Vtd, float *Qd, const int *lens, int N, int M);
 __global__ void sdp_ref_adj_bwd_kernel(const float *E, const float *Q, const float *Qd, float *Ed, const int *lens, int N, int M);
+// ... and their float64-storage instantiations (sdp_*_f64)
+__global__ void sdp_f64_fwd_kernel(const double *theta, const double *A, double *Q, double *Vt, const int *lens, int N, int M, int sw);
+__global__ void sdp_f64_bwd_kernel(const double *Et, const double *Q, double *E, const int *lens, int N, int M, int sw, int et_bcast);
+__global__ void sdp_f64_adj_fwd_kernel(const double *Q, const double *Ztheta, const double *ZA, double *Vtd, double *Qd, const int *lens, int N, int M);
+__global__ void sdp_f64_adj_bwd_kernel(const double *E, const double *Q, const double *Qd, double *Ed, const int *lens, int N, int M);
 __global__ void sdp_selftest_kernel(int *out);
 __global__ void sdp_loss_fwd_kernel(const float *ref, const float *pred, const float *G, const int *lens, double *acc, int *cnt, int N, int M, int kind);
 __global__ void sdp_loss_bwd_kernel(const float *ref, const float *pred, const float *G, const int *lens, const float *scale, float *grad, int N, int M, int kind);

@@ -64,7 +64,7 @@
 extern "C" {
 #endif
 
-#define SDP_VERSION 103 /* 0.1.2: + sdp_backward_range_f32, sdp_state_pair_stride, SDP_ET_BROADCAST, SDP_REF_ROUNDING */
+#define SDP_VERSION 104 /* 0.1.3: + the float64 entry points (sdp_*_f64) */
 
 #define SDP_NW 0
 #define SDP_SW 1
@@ -152,6 +152,24 @@ int sdp_adjoint_forward_f32(const float *state, const float *Ztheta, const float
 int sdp_adjoint_backward_f32(const float *E, const float *state, const float *state_d, float *Ed,
                              int B, int N, int M, const int32_t *lens, int variant, int device,
                              void *stream);
+
+/* float64 tensors.  The reference's CPU classes take whatever dtype they are given -- its own tests run the decoding
+ * test, gradcheck and gradgradcheck on float64 tensors (deepblast/tests/test_nw.py:46-90, test_sw.py) -- so the drop-in
+ * does too: the four sweeps with float64 storage and float64 arithmetic throughout (the recurrences of nw.py / sw.py
+ * as numpy evaluates them on float64 arrays).  Same arguments as the _f32 entry points; theta, A, Vt, Et, E, Ztheta, ZA,
+ * Vtd, Ed are float64, `state` and `state_d` are the reference's (B, N, M, 3) weights in float64
+ * (sdp_state_bytes_f64 bytes each), `variant` is SDP_NW / SDP_SW (| SDP_ET_BROADCAST for the backward sweep).  One
+ * workgroup per pair and a barrier per anti-diagonal (csrc/sdp_ref.hip): a path for tests and small problems --
+ * milliseconds where the float32 path takes a fraction of one -- not a second fast path. */
+size_t sdp_state_bytes_f64(int B, int N, int M);
+int sdp_forward_f64(const double *theta, const double *A, double *state, double *Vt, int B, int N, int M,
+                    const int32_t *lens, int variant, int device, void *stream);
+int sdp_backward_f64(const double *Et, const double *state, double *E, int B, int N, int M,
+                     const int32_t *lens, int variant, int device, void *stream);
+int sdp_adjoint_forward_f64(const double *state, const double *Ztheta, const double *ZA, double *Vtd, double *state_d,
+                            int B, int N, int M, const int32_t *lens, int variant, int device, void *stream);
+int sdp_adjoint_backward_f64(const double *E, const double *state, const double *state_d, double *Ed,
+                             int B, int N, int M, const int32_t *lens, int variant, int device, void *stream);
 
 /* The score tensors the DP reads (reference: NeuralAligner.forward / .score, deepblast/alignment.py:122-123, 134-135:
  *   theta = F.softplus(torch.einsum('bid,bjd->bij', zx, zy));  A = F.logsigmoid(torch.einsum('bid,bjd->bij', gx, gy))).

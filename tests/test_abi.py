@@ -42,7 +42,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_limits(lib):
-    assert lib.sdp_version() == 103
+    assert lib.sdp_version() == 104
     assert lib.sdp_max_cols() == 2048  # reference GPU path: max_cols = 2048 (nw_cuda.py:11)
 
 

@@ -74,7 +74,8 @@ def test_known_answer_traceback(golden_dir, fake, kind):
 
 
 def test_error_behaviour_matches_gpu_variant(fake):
-    """nw_cuda.py:171-175: NotImplementedError for other operators, TypeError for non-fp32."""
+    """nw_cuda.py:171-175: NotImplementedError for other operators, TypeError for dtypes the sweeps do not have (float64 is
+    taken, like the reference's CPU classes take it: tests/test_float64_gpu.py) and for theta / A of two dtypes."""
     th = torch.rand(1, 4, 4)
     A = -torch.rand(1, 4, 4)
     with pytest.raises(NotImplementedError):
@@ -82,7 +83,9 @@ def test_error_behaviour_matches_gpu_variant(fake):
     with pytest.raises(NotImplementedError):
         NeedlemanWunschDecoder(None)(th, A)
     with pytest.raises(TypeError):
-        NeedlemanWunschDecoder("softmax")(th.double(), A.double())
+        NeedlemanWunschDecoder("softmax")(th.half(), A.half())
+    with pytest.raises(TypeError):
+        NeedlemanWunschDecoder("softmax")(th.double(), A)
     with pytest.raises(ValueError):
         NeedlemanWunschDecoder("softmax")(th, A[:, :3])
     SmithWatermanDecoder(None)(th, A)        # CPU reference is built with operator=None (test_sw.py:40)
