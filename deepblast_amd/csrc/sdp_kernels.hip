@@ -158,8 +158,13 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #ifndef SDP_NT
 #define SDP_NT 10
 #endif
+// State stores: sc1.  Once the forward sweep ran at the rate of the memory system (round 4) the store policy began to
+// matter: same box, interleaved, 256 x 512^2 forward 183 -> 176 us (191 -> 182, 212 -> 203 on slower boxes), forward;backward
+// 329 -> 321 (321 -> 315), 256 x 1024^2 1143 -> 1116; nt for the state stores: 177 / 333; sc0 sc1: 175 / 327; sc1 for the E
+// stores as well: forward;backward 341, nt sc1 for them: 314 (noise against 315) -- profiles/r04_store_policy.txt.  (In
+// rounds 2-3, with the sweep bound by its instruction stream, every one of these was inside the box-to-box spread.)
 #ifndef SDP_AUX_ST_STORE   // explicit policy bits of the state stores (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
-#define SDP_AUX_ST_STORE ((SDP_NT & 1) ? 2 : 0)
+#define SDP_AUX_ST_STORE ((SDP_NT & 1) ? 2 : 16)
 #endif
 #ifndef SDP_AUX_ST_LOAD
 #define SDP_AUX_ST_LOAD ((SDP_NT & 2) ? 2 : 0)
