@@ -166,6 +166,9 @@ def main():
                          f"different job than the one asked for")
     # test hook (tests/test_distributed_nccl_gpu.py): exercise the N > 1 flow of this script on a 1-GPU box -- all ranks
     # on device 0, collectives over gloo.  Never set for a measurement: the JSON line says so in config.backend.
+    # test hook: BENCH_FORCE_DIST=1 takes the N > 1 flow (process group, gather, fences, secondary measurements) with a world
+    # of ONE rank -- on the nccl backend that sends every collective of the flow through RCCL on a 1-GPU box
+    multi = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
     shared = os.environ.get("BENCH_SHARE_GPU") == "1"
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     if shared:
@@ -174,7 +177,7 @@ def main():
         raise SystemExit(f"[bench] rank {rank}: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} device(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
@@ -194,7 +197,7 @@ def main():
     dec = (NeedlemanWunschDecoder if args.variant == "nw" else SmithWatermanDecoder)("softmax")
     # the headline step is the metric's own idiom, literally: Vt = dec(theta, A); Vt.sum().backward(); the
     # same sweeps with the cotangent handed to torch.autograd.grad directly are reported next to it (`direct_cotangent`)
-    aligner = ShardedAligner(dec, gather=args.gather if world > 1 else "none", e_chunks=args.e_chunks,
+    aligner = ShardedAligner(dec, gather=args.gather if multi else "none", e_chunks=args.e_chunks,
                              idiom="sum_backward" if args.mode == "fwdbwd" else "grad")
     eng = get_engine()
     timer = KernelTimer()
@@ -244,7 +247,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -262,7 +265,7 @@ def main():
             marks[i + 1].record()
         fence()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -320,8 +323,8 @@ def main():
                                        + ("(BASELINE.json configs[1])" if world == 1 else
                                           f"(BASELINE.json configs[4] sharding: {B * world} pairs over {world} GPUs)"),
                            "global_batch": B * world, "N": N, "M": M, "variant": args.variant,
-                           "parallelism": f"batch-sharded x{world}", "gather": args.gather if world > 1 else "none",
-                           "backend": ("rccl" if backend == "nccl" else backend + (" (ranks share one GPU: test mode)" if shared else "")) if world > 1 else "none",
+                           "parallelism": f"batch-sharded x{world}", "gather": args.gather if multi else "none",
+                           "backend": ("rccl" if backend == "nccl" else backend + (" (ranks share one GPU: test mode)" if shared else "")) if multi else "none",
                            "arith": "fwd: scaled exp-domain f32 (exact power-of-two rescaling); bwd: f32; adjoint pair: f64 carries; f32 storage",
                            "data_dependent": "the backward sweep does not run 32-step chunks whose outputs are exactly +0 nor read their state "
                                              "(bit-identical E; 47 % of E's cells, 29 % of the chunks on this data: DESIGN.md 3.8); the forward sweep "
@@ -433,27 +436,27 @@ def main():
         os._exit(0)
 
     dog = None
-    if world > 1 and args.mode == "fwdbwd" and not os.environ.get("BENCH_NO_SECONDARY"):
+    if multi and args.mode == "fwdbwd" and not os.environ.get("BENCH_NO_SECONDARY"):
         # (BENCH_WATCHDOG_S: test hook, tests/test_multirank_one_gpu.py fires the watchdog on purpose)
         dog = threading.Timer(float(os.environ.get("BENCH_WATCHDOG_S") or max(60.0, 200.0 * elapsed)), watchdog)
         dog.daemon = True
         dog.start()
     direct = None
     if args.mode == "fwdbwd" and not os.environ.get("BENCH_NO_SECONDARY"):
-        direct = secondary(args.gather if world > 1 else "none", idiom="grad")
-    if world > 1 and args.mode == "fwdbwd" and args.gather != "e" and not os.environ.get("BENCH_NO_SECONDARY"):
+        direct = secondary(args.gather if multi else "none", idiom="grad")
+    if multi and args.mode == "fwdbwd" and args.gather != "e" and not os.environ.get("BENCH_NO_SECONDARY"):
         e_gather = secondary("e")                 # backward sweep + gather in --e-chunks pieces
         e_gather_one = secondary("e", e_chunks=1) if args.e_chunks > 1 else None   # one collective after the sweep
     # ... and with the tracebacks gathered instead (device walk + (N+M+4) int32 per pair over the wire)
     paths_gather = None
-    if world > 1 and args.mode == "fwdbwd" and args.gather != "paths" and not os.environ.get("BENCH_NO_SECONDARY"):
+    if multi and args.mode == "fwdbwd" and args.gather != "paths" and not os.environ.get("BENCH_NO_SECONDARY"):
         paths_gather = secondary("paths")
 
     if dog is not None:
         dog.cancel()
     if emitted.acquire(blocking=False):
         emit(e_gather, e_gather_one, paths_gather, direct)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -82,6 +82,24 @@ def test_sharded_align_two_ranks_rccl(tmp_path, mode):
         assert parity.abs_err(d["E"], ref["E"]) <= parity.TOL
 
 
+@pytest.mark.parametrize("mode", ["contiguous", "balanced", "chunked"])
+def test_sharded_align_one_rank_rccl(tmp_path, mode):
+    """What a 1-GPU box CAN run of the RCCL path: a process group of one rank on the nccl backend.  Every collective the
+    sharded path issues -- all_gather_into_tensor of Vt under the backward sweep, the E gather (one collective, the
+    asynchronous handle, the pieces under the sweep), the barrier -- goes through RCCL with the real argument types,
+    streams and async handles; what it cannot show is a second rank."""
+    import parity
+    mp.spawn(_worker, args=(1, _free_port(), mode, str(tmp_path)), nprocs=1, join=True)
+    theta, A = datagen.theta_A(45, 10, 150, 130)
+    if mode in ("contiguous", "chunked"):
+        ref = parity.oracle_all(theta, A, None, None, 0, omp=False)
+    else:
+        ref = parity.oracle_lens(theta, A, None, None, 0, datagen.lengths(46, 10, 5, 130))
+    d = np.load(tmp_path / "r0.npz")
+    assert parity.rel_err(d["Vt"], ref["Vt"]) <= parity.TOL
+    assert parity.abs_err(d["E"], ref["E"]) <= parity.TOL
+
+
 def _worker_paths(rank, world, port, backend, outdir):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "tests")):
@@ -136,6 +154,12 @@ def test_gathered_paths_two_ranks_share_one_gpu(tmp_path):
     every pair's traceback, in batch order, equal to the per-pair host walk over the oracle's E."""
     mp.spawn(_worker_paths, args=(2, _free_port(), "gloo", str(tmp_path)), nprocs=2, join=True)
     _check_paths(tmp_path, 2)
+
+
+def test_gathered_paths_one_rank_rccl(tmp_path):
+    """The walks gathered through RCCL by a group of one rank (see test_sharded_align_one_rank_rccl)."""
+    mp.spawn(_worker_paths, args=(1, _free_port(), "nccl", str(tmp_path)), nprocs=1, join=True)
+    _check_paths(tmp_path, 1)
 
 
 @needs2
@@ -229,3 +253,24 @@ def test_bench_two_ranks_flow_on_one_gpu():
     assert d["value"] > 0 and d["with_e_gather"]["value"] > 0 and "cpu_baseline" not in d
     assert d["with_paths_gather"]["value"] > 0 and d["with_paths_gather"]["bytes_into_each_gpu"] < d["with_e_gather"]["bytes_into_each_gpu"] / 50
     assert d["scaling"] == "weak" and "test mode" in d["config"]["backend"]
+
+
+def test_bench_multi_gpu_flow_one_rank_rccl():
+    """bench.py's N > 1 flow with a world of one rank on the nccl backend (BENCH_FORCE_DIST=1): the process group on RCCL, the
+    Vt gather under the backward sweep, the barrier fences, the all-reduce of the timing, the secondary E-gather and
+    path-gather measurements -- every collective of the flow the driver runs on 8 GPUs, through RCCL, on one GPU."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("BENCH_SHARE_GPU", "BENCH_BACKEND")}
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), BENCH_FORCE_DIST="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--B", "24", "--N", "200",
+           "--M", "180", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["backend"] == "rccl" and d["config"]["gather"] == "vt"
+    assert d["value"] > 0 and d["with_e_gather"]["value"] > 0 and d["with_paths_gather"]["value"] > 0
