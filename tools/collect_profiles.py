@@ -44,6 +44,9 @@ for name, pattern in (("kernel_stats.csv", "prof/**/*kernel_stats.csv"), ("train
                       ("bench_scores.json", "bench_scores.json"), ("bench_traceback.json", "bench_traceback.json"),
                       ("configs.txt", "configs.txt"), ("parts_configs2.txt", "parts_configs2.txt"),
                       ("ubench_mix.txt", "ubench_mix.txt"), ("ubench_mix2.txt", "ubench_mix2.txt"),
+                      ("bwd_trace.txt", "bwd_trace.txt"), ("bwd_trace_alias7.txt", "bwd_trace_alias7.txt"), ("fwd_trace.txt", "fwd_trace.txt"),
+                      ("fwd_trace_alias7.txt", "fwd_trace_alias7.txt"), ("zero_probe.txt", "zero_probe.txt"), ("bigB.txt", "bigB.txt"),
+                      ("shapes.txt", "shapes.txt"),
                       ("pytest_multigpu.txt", "pytest_multigpu.txt"), ("multigpu_skipped.txt", "multigpu_skipped.txt"),
                       ("pytest_gpu.txt", "pytest_gpu.txt"), ("smoke.txt", "smoke.txt"), ("fuzz2.txt", "fuzz2.txt"), ("parts_fuzz.txt", "parts_fuzz.txt")):
     f = first(pattern)

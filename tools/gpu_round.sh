@@ -51,6 +51,21 @@ timeout 300 python tools/gpu_configs.py 2> /dev/null | tee $OUT/configs.txt
 timeout 300 python tools/parts_probe.py 256 1022 1020 lens cfg3 2> /dev/null | grep "^parts" | tee $OUT/parts_configs2.txt
 # bare read / write / mixed streams of the forward sweep's size: what this box's memory system gives
 for u in mix mix2; do hipcc --offload-arch=gfx950 -O3 -o /tmp/$u tools/ubench/$u.hip 2> /dev/null && timeout 120 /tmp/$u 2>&1 | tee $OUT/ubench_$u.txt; done
+# cycle stamps inside the two sweeps (real memory and everything cache-served), the exact-zero skip switched off and on,
+# larger batches, other shapes
+timeout 300 python tools/bwd_trace.py > $OUT/bwd_trace.txt 2>&1
+timeout 300 python tools/bwd_trace.py 7 > $OUT/bwd_trace_alias7.txt 2>&1
+timeout 300 python tools/fwd_trace.py > $OUT/fwd_trace.txt 2>&1
+timeout 300 python tools/fwd_trace.py 7 > $OUT/fwd_trace_alias7.txt 2>&1
+timeout 300 python tools/zero_probe.py 2>&1 | grep -v amdgpu > $OUT/zero_probe.txt
+timeout 300 python tools/zero_probe.py 256 1024 1024 2>&1 | grep -v amdgpu >> $OUT/zero_probe.txt
+for B in 512 1024; do
+  timeout 300 python bench.py --steps 10 --warmup 2 --B $B --no-cpu-baseline 2> /dev/null | python -c "
+import json, sys
+d = json.loads([ln for ln in sys.stdin if ln.startswith('{')][-1])
+print(f\"B=$B: {d['ms_per_step']:.4f} ms/step  {d['value']:.4g} cell-updates/s  fwd {d['kernel_ms']['sdp_fwd_kernel'] * 1e3:.1f} us  bwd {d['kernel_ms']['sdp_bwd_kernel'] * 1e3:.1f} us  roofline frac {d['roofline']['frac']:.3f}\")"
+done > $OUT/bigB.txt
+timeout 300 python tools/ab.py 64x512x512 256x512x512 256x1024x1024 adj 2>&1 | grep "B=" > $OUT/shapes.txt
 # keep what is merged back small: the per-dispatch traces are large, the stats and counter CSVs are not
 find $OUT -name "*kernel_trace.csv" -size +4M -delete
 for f in $(find $OUT/prof $OUT/prof_train $OUT/prof_scores $OUT/prof_cfg $OUT/prof_scores_bwd -name "*kernel_stats.csv"); do echo "== $f"; head -8 $f; done
