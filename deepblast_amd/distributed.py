@@ -170,9 +170,16 @@ class ShardedAligner:
                 raise ValueError("a BalancedPlan needs the per-pair lengths of this rank's pairs")
             theta, A, lengths = pad_shard(theta, A, lengths, plan.per_rank)
         gathering = self.gather != "none" and dist.is_available() and dist.is_initialized()
-        if gathering and self.gather == "e" and self.e_chunks > 1 and lengths is None and theta.shape[0] >= self.e_chunks:
+        # (float64 tensors take the unchunked path: sdp_backward_range_f32 sweeps the float32 states only -- decided here,
+        #  before any collective has been issued)
+        if (gathering and self.gather == "e" and self.e_chunks > 1 and lengths is None and theta.shape[0] >= self.e_chunks
+                and theta.dtype == torch.float32):
             return self._align_chunked_e(theta.detach(), A.detach(), n_real)
         theta = theta.detach().requires_grad_(True)
+        # A takes no part in what is asked for here (E = dVt.sum()/dtheta): detached, so that neither idiom leaves anything
+        # in the caller's graph -- with A attached, `Vt.sum().backward()` would accumulate the reference's pass-through
+        # "gradient" (A itself, nw.py:355) into A.grad and run the backward of whatever produced A, on every align()
+        A = A.detach()
         Vt = self.decoder(theta, A, lengths) if lengths is not None else self.decoder(theta, A)
         # idiom "grad": dVt.sum()/dtheta with the cotangent handed over directly -- no reduction kernel, no fill
         if self.idiom == "grad" and (self._ones is None or self._ones.shape != Vt.shape or self._ones.device != Vt.device):
@@ -183,7 +190,7 @@ class ShardedAligner:
             # backward sweep computes E
             pending = _all_gather_cat(Vt.detach(), self.group, async_op=True)
         if self.idiom == "sum_backward":
-            Vt.sum().backward()
+            Vt.sum().backward(inputs=[theta])   # only the local theta leaf receives a gradient
             E = theta.grad
         else:
             (E,) = torch.autograd.grad(Vt, theta, grad_outputs=self._ones)
@@ -219,7 +226,10 @@ class ShardedAligner:
         variant = _engine.SW if isinstance(self.decoder, SmithWatermanDecoder) else _engine.NW
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         Bl, N, M = theta.shape
-        Vt, state = eng.forward(theta, A, variant)     # the same two sweeps decoder(theta, A) + autograd.grad launch
+        # the same two sweeps decoder(theta, A) + autograd.grad launch, in the decoder's arithmetic (sdp_backward_range_f32
+        # has a reference-rounding branch)
+        xs = _engine.REF if getattr(self.decoder, "arithmetic", "fast") == "reference" else False
+        Vt, state = eng.forward(theta, A, variant, exact_state=xs)
         vt_pending = _all_gather_cat(Vt, self.group, async_op=True)
         if self._ones is None or self._ones.shape != Vt.shape or self._ones.device != Vt.device:
             self._ones = torch.ones_like(Vt)
@@ -228,7 +238,7 @@ class ShardedAligner:
         bounds = [shard_bounds(Bl, self.e_chunks, k) for k in range(self.e_chunks)]
         works = []
         for lo, hi in bounds:
-            eng.backward(self._ones, state, (Bl, N, M), variant, pair_range=(lo, hi), out=mine)
+            eng.backward(self._ones, state, (Bl, N, M), variant, exact_state=xs, pair_range=(lo, hi), out=mine)
             outs = [full[r * Bl + lo:r * Bl + hi] for r in range(world)]
             works.append(dist.all_gather(outs, mine[lo:hi], group=self.group, async_op=True))
         e_pending = PendingGather(full, _Works(works))

@@ -104,6 +104,10 @@ class _DecodeLoss(torch.autograd.Function):
     def forward(ctx, theta, A, first, G, lens_loss, lens_dp, kind, variant):
         from ._dp import _validate
         _validate(theta, A, 'softmax', False)
+        if theta.dtype != torch.float32:
+            # the loss kernels read E through a raw float32 pointer: a float64 E (the engine's f64 path) must never get there
+            raise TypeError(f"decode_loss supports torch.float32 tensors only, got {theta.dtype}; with float64 use "
+                            "loss(first, decoder.decode(theta, A), x_len, y_len, G)")
         eng = get_engine()
         dev = eng._dev(theta)
         first = first.detach().to(torch.float32).contiguous()
@@ -162,6 +166,9 @@ def decode_loss(decoder, loss, theta, A, first, x_len, y_len, G, lengths=None):
     from ._engine import NW, SW
     from .sw import SmithWatermanDecoder
     variant = SW if isinstance(decoder, SmithWatermanDecoder) else NW
+    if getattr(decoder, "arithmetic", "fast") != "fast":
+        raise NotImplementedError("decode_loss runs the tuned sweeps only; with arithmetic='reference' use "
+                                  "loss(first, decoder.decode(theta, A), x_len, y_len, G)")
     B = theta.shape[0]
     lens_loss = _lens(x_len, y_len, B, theta.device)
     lens_dp = None
