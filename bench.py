@@ -51,7 +51,7 @@ def parse():
                          "train-mce-fused: the same as one op, the loss gradient seeding the adjoint sweep inside the kernel")
     ap.add_argument("--D", type=int, default=512, help="embedding width of --mode scores+dp (reference default n_embed)")
     ap.add_argument("--gather", choices=["vt", "e", "paths", "none"], default="vt")
-    ap.add_argument("--e-chunks", type=int, default=4, help="pieces of the backward sweep / E gather when E is gathered (1 = one collective after the sweep)")
+    ap.add_argument("--e-chunks", type=int, default=1, help="pieces of the backward sweep / E gather when E is gathered (1 = one collective after the sweep)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs in the CPU-baseline sample")
     return ap.parse_args()
@@ -91,6 +91,93 @@ class KernelTimer:
         for name, s, e in self.spans:
             acc.setdefault(name, []).append(s.elapsed_time(e))
         return {k: float(np.mean(v)) for k, v in acc.items()}
+
+
+class ClockSampler:
+    """Shader clock and socket power of the device WHILE the step loops (sysfs of the device's PCI function, polled from a
+    thread; `rocm-smi` as the fallback).  The same kernel ran 171-210 us on the boxes of round 4: a bench line without the
+    clock it was measured at cannot be compared with another round's."""
+
+    def __init__(self, dev_index):
+        self.dir = None
+        self.samples = []
+        self._stop = False
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            import glob
+            for d in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.basename(os.path.realpath(d)) == want and os.path.exists(os.path.join(d, "pp_dpm_sclk")):
+                    self.dir = d
+                    break
+        except Exception:   # noqa: BLE001
+            self.dir = None
+
+    def _read(self):
+        out = {}
+        try:
+            for name, key in (("pp_dpm_sclk", "sclk_mhz"), ("pp_dpm_mclk", "mclk_mhz"), ("pp_dpm_fclk", "fclk_mhz")):
+                with open(os.path.join(self.dir, name)) as f:
+                    cur = [ln for ln in f.read().splitlines() if ln.rstrip().endswith("*")]
+                if cur:
+                    out[key] = float(cur[0].split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+            import glob
+            for pw in glob.glob(os.path.join(self.dir, "hwmon", "hwmon*", "power1_*")):
+                if pw.endswith(("power1_input", "power1_average")):
+                    with open(pw) as f:
+                        out["power_w"] = float(f.read().strip()) / 1e6
+                    break
+        except (OSError, ValueError, IndexError):
+            pass
+        return out
+
+    def _smi(self):
+        import subprocess
+        try:
+            txt = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=20).stdout
+            j = json.loads(txt[txt.index("{"):])
+            card = next(iter(j.values()))
+            out = {}
+            for k, v in card.items():
+                kl = k.lower()
+                if "sclk" in kl and "clock speed" in kl:
+                    out["sclk_mhz"] = float(str(v).strip("()").lower().replace("mhz", ""))
+                elif "mclk" in kl and "clock speed" in kl:
+                    out["mclk_mhz"] = float(str(v).strip("()").lower().replace("mhz", ""))
+                elif "power" in kl and "(w)" in kl:
+                    out["power_w"] = float(v)
+            return out
+        except Exception:   # noqa: BLE001
+            return {}
+
+    def run(self, seconds, busy, rounds):
+        """busy(): enqueue some steps (returns quickly); called exactly `rounds` times (the same number on every rank: the
+        step may hold a collective).  Samples while the device works for about `seconds`."""
+        import threading
+
+        def poll():
+            while not self._stop:
+                smp = self._read() if self.dir else self._smi()
+                if smp:
+                    self.samples.append(smp)
+                time.sleep(0.02)
+        th = threading.Thread(target=poll, daemon=True)
+        t0 = time.perf_counter()
+        th.start()
+        for _ in range(rounds):
+            busy()
+            torch.cuda.synchronize()
+        seconds = time.perf_counter() - t0
+        self._stop = True
+        th.join(timeout=30)
+        smp = self.samples[len(self.samples) // 4:] or self.samples   # (the first quarter: clocks still ramping)
+        if not smp:
+            return {"sclk_mhz": None, "power_w": None, "samples": 0, "how": "no sysfs access and no rocm-smi on this box"}
+        out = {k: float(np.median([x[k] for x in smp if k in x])) for k in ("sclk_mhz", "mclk_mhz", "fclk_mhz", "power_w") if any(k in x for x in smp)}
+        out["samples"] = len(smp)
+        out["how"] = (("sysfs pp_dpm_* / hwmon of the device" if self.dir else "rocm-smi --showclocks --showpower") +
+                      f", median over ~{seconds:.1f} s of the same step looping right after the timed region")
+        return out
 
 
 def cpu_baseline(args):
@@ -279,6 +366,8 @@ def main():
     value = world * per_step_updates * args.steps / elapsed
     ms = timer.means_ms()
 
+    no_skip = clocks = None
+
     def emit(e_gather, e_gather_one, paths_gather, direct=None):
         """rank 0: the ONE JSON line (called once: after the secondary measurements, or by the watchdog below)."""
         if rank == 0:
@@ -293,7 +382,7 @@ def main():
             achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
             # HBM bytes per launch from the PMC passes (profiles/traffic.json, tools/gpu_round.sh): only if that file was
             # measured on exactly these kernel sources -- a stale figure is reported as null, not as a number
-            traffic, traffic_stamp = None, None
+            traffic, traffic_stamp, tj = None, None, {}
             tf = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tf) and (B, N, M, args.variant) == (256, 512, 512, "nw"):
                 try:
@@ -304,9 +393,23 @@ def main():
                     if traffic_stamp == source_stamp.source_sha():
                         traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
                     else:
+                        tj = {}
                         print("[bench] profiles/traffic.json was measured on other kernel sources: roofline.traffic = null", file=sys.stderr)
                 except (OSError, ValueError, ImportError):
-                    traffic = None
+                    traffic, tj = None, {}
+            # every sweep of the step, each with BOTH fractions: `frac` on the algorithmic bytes (what the
+            # roofline is graded on) and `real_frac` on the bytes the kernel actually moved (PMC traffic / launch time) -- a
+            # kernel that moves fewer bytes than the algorithmic figure (the backward sweep skips exact-zero chunks) must not
+            # show a flattering `frac` without the honest one next to it
+            per_kernel = {}
+            for k, v_ms in cand.items():
+                if k.startswith("sdp_scores"):
+                    continue
+                ab = cells * algo_bytes_per_cell(k)
+                tr = tj.get(k, {}).get("hbm_bytes_per_launch") if tj else None
+                per_kernel[k] = {"launch_ms": v_ms, "algorithmic_bytes_per_launch": ab, "frac": ab / (v_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "traffic": tr, "real_frac": (tr / (v_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None}
+            step_algo_bytes = cells * sum(algo_bytes_per_cell(k) for k in per_kernel) if per_kernel else per_step_updates * ALGO_BYTES_PER_CELL_UPDATE
             line = {
                 "metric": {"fwdbwd": "DP cell-updates/sec (fwd+bwd)", "align+traceback": "DP cell-updates/sec (fwd+bwd + batched traceback)", "train": "DP cell-updates/sec (train: fwd+bwd+adjoint pair)",
                            "scores+dp": "DP cell-updates/sec (scores from embeddings + fwd+bwd)",
@@ -332,10 +435,19 @@ def main():
                 "kernel_ms": ms,
                 "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                             "real_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                              "algorithmic_bytes_per_launch": dom_bytes,
                              "launch_ms": dom_ms,
-                             "whole_step_frac": (per_step_updates * ALGO_BYTES_PER_CELL_UPDATE * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9)},
+                             "kernels": per_kernel,
+                             # all sweeps of one step over the step's wall time: 12 + 12 B per cell for fwd + bwd, + 32 + 32 for the
+                             # adjoint pair of the training modes
+                             "whole_step_algorithmic_bytes": step_algo_bytes,
+                             "whole_step_frac": (step_algo_bytes * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9)},
             }
+            if no_skip is not None:
+                line["no_skip"] = no_skip
+            if clocks is not None:
+                line["clocks"] = clocks
             if dom.startswith("sdp_scores"):
                 # the GEMM dominates this mode: its bound is the matrix pipe (filled in below as scores_roofline); the
                 # HBM figures above then describe nothing and are replaced
@@ -444,6 +556,39 @@ def main():
     direct = None
     if args.mode == "fwdbwd" and not os.environ.get("BENCH_NO_SECONDARY"):
         direct = secondary(args.gather if multi else "none", idiom="grad")
+    # the control of the data-dependent saving: the same step with the backward sweep running EVERY chunk
+    # (variant | SDP_NO_ZERO_SKIP; E is bit-identical) -- a number that moves with the data travels with its control
+    if rank == 0 and not multi and args.mode in ("fwdbwd", "train") and not os.environ.get("BENCH_NO_SECONDARY"):
+        try:
+            eng.zero_skip = False
+            step()
+            ns_timer = KernelTimer(every=1)
+            eng.launch_hook = ns_timer
+            ns_timer.enabled = True
+            dt_ns, _ = timed(min(args.steps, 10))
+            ns_timer.enabled = False
+            nm = ns_timer.means_ms()
+            no_skip = {"ms_per_step": dt_ns / min(args.steps, 10) * 1e3, "value": per_step_updates * min(args.steps, 10) / dt_ns,
+                       "bwd_ms": nm.get("sdp_bwd_kernel"), "fwd_ms": nm.get("sdp_fwd_kernel"), "steps": min(args.steps, 10),
+                       "what": "the same step with variant | SDP_NO_ZERO_SKIP: the backward sweep runs every chunk and reads all of its state (bit-identical E)"}
+        except Exception as ex:   # noqa: BLE001
+            print(f"[bench] no_skip control failed: {ex}", file=sys.stderr, flush=True)
+        finally:
+            eng.zero_skip = True
+            eng.launch_hook = None if os.environ.get("BENCH_NO_KERNEL_EVENTS") else timer
+    if not os.environ.get("BENCH_NO_CLOCKS") and not os.environ.get("BENCH_NO_SECONDARY"):
+        # every rank loops the same number of steps (~1.5 s by the timed region's own figure, the max over ranks); rank 0 samples
+        rounds = max(1, min(400, int(1.5 / max(50 * elapsed / args.steps, 1e-4))))
+        busy = lambda: [step() for _ in range(50)]
+        try:
+            if rank == 0:
+                clocks = ClockSampler(local_rank).run(1.5, busy, rounds)
+            else:
+                for _ in range(rounds):
+                    busy()
+                    torch.cuda.synchronize()
+        except Exception as ex:   # noqa: BLE001
+            print(f"[bench] clock sampling failed: {ex}", file=sys.stderr, flush=True)
     if multi and args.mode == "fwdbwd" and args.gather != "e" and not os.environ.get("BENCH_NO_SECONDARY"):
         e_gather = secondary("e")                 # backward sweep + gather in --e-chunks pieces
         e_gather_one = secondary("e", e_chunks=1) if args.e_chunks > 1 else None   # one collective after the sweep

@@ -12,7 +12,7 @@ for A is A itself (nw.py:337-339,355); the second-order gradient w.r.t. A is Non
 (nw.py:386); Et may be non-uniform.
 
 Differences that are part of the design, not of the maths: `Q` is an opaque state tensor
-(library-private layout; 6 bytes per cell on the inference path, float2 when decode() announces
+(library-private layout; 5 bytes per cell -- two 20-bit weights -- on the inference path, float2 when decode() announces
 that the second-order sweeps will follow) instead of (B,N+2,M+2,3), and E is produced directly
 as (B,N,M) -- the reference's E[:,1:-1,1:-1] -- without materialising the zero border.
 """
@@ -55,11 +55,11 @@ def make_functions(variant, prefix, allow_none_operator=False):
     class FunctionBackward(torch.autograd.Function):
 
         @staticmethod
-        def forward(ctx, theta, A, Et, Q, operator, lens=None, exact_state=False):
+        def forward(ctx, theta, A, Et, Q, operator, lens=None, exact_state=False, no_fill=False):
             eng = _engine.get_engine()
             if Et.device != theta.device:
                 raise ValueError(f"Et is on {Et.device}, expected {theta.device}")
-            E = eng.backward(Et.detach(), Q, tuple(theta.shape), variant, lens, exact_state=exact_state)
+            E = eng.backward(Et.detach(), Q, tuple(theta.shape), variant, lens, exact_state=exact_state, **({"no_fill": True} if no_fill else {}))
             # exact state: the adjoint sweeps can use Q as it is; compact state: they need theta and A to get it
             if exact_state:
                 ctx.save_for_backward(Q, E)
@@ -79,7 +79,7 @@ def make_functions(variant, prefix, allow_none_operator=False):
             if exact_state:
                 Q, E = ctx.saved_tensors
             else:
-                # The saved state is the compact one (6 B/cell) the backward sweep reads fastest.  The adjoint
+                # The saved state is the compact one (5 B/cell) the backward sweep reads fastest.  The adjoint
                 # sweeps multiply the weights with directional derivatives of any magnitude and need them at
                 # full fp32 precision: re-run the forward sweep in its exact-state form.  Callers that know
                 # the second-order sweeps will follow (Decoder.decode, i.e. training) ask for the exact state
@@ -92,27 +92,27 @@ def make_functions(variant, prefix, allow_none_operator=False):
             ref = exact_state == _engine.REF
             Vtd, Qd = eng.adjoint_forward(Q, Ztheta, ZA, variant, lens, ref=ref)
             Ed = eng.adjoint_backward(E, Q, Qd, variant, lens, ref=ref)
-            return Ed, None, Vtd, None, None, None, None
+            return Ed, None, Vtd, None, None, None, None, None
 
     class Function(torch.autograd.Function):
 
         @staticmethod
-        def forward(ctx, theta, A, operator, lens=None, exact_state=False):
+        def forward(ctx, theta, A, operator, lens=None, exact_state=False, no_fill=False):
             _validate(theta, A, operator, allow_none_operator)
             if theta.dtype == torch.float64:
                 exact_state = _engine.F64   # (truthy: the state serves all four sweeps, as with exact_state=True)
             eng = _engine.get_engine()
             Vt, Q = eng.forward(theta.detach(), A.detach(), variant, lens, exact_state=exact_state)
             ctx.save_for_backward(theta, A, Q)
-            ctx.others = (operator, lens, exact_state)
+            ctx.others = (operator, lens, exact_state, no_fill)
             return Vt
 
         @staticmethod
         def backward(ctx, Et):
             theta, A, Q = ctx.saved_tensors
-            operator, lens, exact_state = ctx.others
-            E, A = FunctionBackward.apply(theta, A, Et, Q, operator, lens, exact_state)
-            return E, A, None, None, None
+            operator, lens, exact_state, no_fill = ctx.others
+            E, A = FunctionBackward.apply(theta, A, Et, Q, operator, lens, exact_state, no_fill)
+            return E, A, None, None, None, None
 
     Function.__name__ = Function.__qualname__ = prefix + "Function"
     FunctionBackward.__name__ = FunctionBackward.__qualname__ = prefix + "FunctionBackward"
@@ -191,21 +191,30 @@ class _Decoder(nn.Module):
         self.traceback_rule = traceback_rule
         self.arithmetic = arithmetic
 
-    def forward(self, theta, A, lengths=None):
+    def forward(self, theta, A, lengths=None, fill=True):
         """theta, A: (B, N, M) fp32 on a ROCm device -> Vt (B,) on the same device.
 
         `lengths` (optional, (B,2) int) is an extension: per-pair true sizes of a padded
-        batch; None reproduces the reference (DP over the full padded matrix)."""
+        batch; None reproduces the reference (DP over the full padded matrix).
+        `fill` (with lengths): True = the gradient E is zero outside each pair's n_b x m_b block (the contract);
+        False = those cells are NOT written and hold whatever the allocator handed out (include/sdp.h: SDP_NO_FILL) --
+        for callers that mask by the same lengths (a loss that slices [:x_len, :y_len], `traceback_batch(E, lengths)`):
+        the zero fill of a padded batch moves as many bytes as the sweep itself."""
         if self.arithmetic == "reference":
             return self._function.apply(theta, A, self.operator, lengths, _engine.REF)
         if lengths is None:
             return self._function.apply(theta, A, self.operator)
+        if not fill:
+            return self._function.apply(theta, A, self.operator, lengths, False, True)
         return self._function.apply(theta, A, self.operator, lengths)
 
-    def _forward_for_decode(self, theta, A, lengths):
+    def _forward_for_decode(self, theta, A, lengths, fill=True):
         # decode() is differentiated again by its callers (training: loss on the alignment matrix): save the
         # state in the exact form all four sweeps can share
-        return self._function.apply(theta, A, self.operator, lengths, _engine.REF if self.arithmetic == "reference" else True)
+        xs = _engine.REF if self.arithmetic == "reference" else True
+        if lengths is not None and not fill:
+            return self._function.apply(theta, A, self.operator, lengths, xs, True)
+        return self._function.apply(theta, A, self.operator, lengths, xs)
 
     def traceback(self, grad):
         return traceback(grad, self.traceback_rule)
@@ -220,10 +229,11 @@ class _Decoder(nn.Module):
             raise IndexError(f"traceback walked off the matrix for pairs {np.nonzero(counts < 0)[0].tolist()}")
         return [[tuple(int(v) for v in row) for row in states[b, :counts[b]]] for b in range(len(counts))]
 
-    def decode(self, theta, A, lengths=None):
-        """Expected alignment matrix dVt/dtheta, differentiable (nw_cuda.py:319-325)."""
+    def decode(self, theta, A, lengths=None, fill=True):
+        """Expected alignment matrix dVt/dtheta, differentiable (nw_cuda.py:319-325).  `lengths`, `fill`: see forward()
+        (the gradient that flows back through the result, Ed, is always zero outside the blocks)."""
         with torch.enable_grad():
-            nll = self._forward_for_decode(theta, A, lengths)
+            nll = self._forward_for_decode(theta, A, lengths, fill)
             v = torch.sum(nll)
             v_grad, _ = torch.autograd.grad(v, (theta, A), create_graph=True)
         return v_grad

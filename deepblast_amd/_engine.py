@@ -48,6 +48,9 @@ class HipEngine:
         # per-pass wave-count override for experiments and tests ({0 fwd, 1 bwd, 2 adj-fwd, 3 adj-bwd} -> waves);
         # travels with each call as SDP_WAVES(w), the library keeps no tuning state
         self.force_waves = {}
+        # measurement control (bench.py's `no_skip` figures): False = the backward sweep runs every chunk (SDP_NO_ZERO_SKIP);
+        # results are bit-identical either way
+        self.zero_skip = True
 
     def _v(self, pass_, variant):
         w = self.force_waves.get(pass_, 0)
@@ -93,7 +96,7 @@ class HipEngine:
         return self.lib.sdp_max_cols()
 
     def new_state(self, B, N, M, device, derivative=False, ref=False):
-        """Opaque buffer for Q (6 bytes per cell) or, with derivative=True, for Qd (float2 per cell); ref: the
+        """Opaque buffer for Q (packed: two 20-bit weights, 5 bytes per cell) or, with derivative=True, for Qd (float2 per cell); ref: the
         reference-rounding mode's (B, N, M, 3) fp32 for either."""
         if ref:
             nbytes = self.lib.sdp_state_bytes_v(B, N, M, REF_ROUNDING)
@@ -146,14 +149,16 @@ class HipEngine:
         """Bytes between the records of consecutive pairs in the state buffer (include/sdp.h: sdp_state_pair_stride)."""
         return self.lib.sdp_state_pair_stride(N, M, 1 if exact_state else 0)
 
-    def backward(self, Et, state, shape, variant, lens=None, exact_state=False, pair_range=None, out=None):
+    def backward(self, Et, state, shape, variant, lens=None, exact_state=False, pair_range=None, out=None, no_fill=False):
         """-> E (B,N,M).  Replaces _backward_pass_kernel (nw_cuda.py:98-102).
 
         exact_state: `state` came from forward(..., exact_state=True).
         pair_range=(lo, hi), out=(B,N,M) tensor: sweep only pairs lo..hi-1 of the batch, writing out[lo:hi] (the
         other rows of `out` are not touched) -- the backward sweep of a batch in pieces, so that a collective on
         piece k can run under the sweep of piece k+1 (distributed.py).  Needs lens=None.  The library finds the
-        pairs' records in `state` itself (sdp_backward_range_f32 takes the whole batch's buffers and the range)."""
+        pairs' records in `state` itself (sdp_backward_range_f32 takes the whole batch's buffers and the range).
+        no_fill (with lens): E outside each pair's block is NOT written (SDP_NO_FILL) -- for consumers that mask by the
+        same lengths and never read it; the default zero-fills, as the public contract says."""
         dev = self._dev(state)
         B, N, M = shape
         if Et.device != state.device:
@@ -168,6 +173,7 @@ class HipEngine:
         if tuple(E.shape) != (B, N, M) or E.dtype != torch.float32 or not E.is_contiguous() or E.device != state.device:
             raise ValueError("out must be a contiguous float32 (B, N, M) tensor on the state's device")
         v = self._v(1, variant) | self._state_flags(exact_state) | (ET_BROADCAST if bcast else 0)
+        v |= (0 if self.zero_skip else _lib.SDP_NO_ZERO_SKIP) | (_lib.SDP_NO_FILL if (no_fill and lens is not None) else 0)
         with torch.cuda.device(dev), self._bracket("sdp_bwd_kernel"):
             if pair_range is None:
                 rc = self.lib.sdp_backward_f32(_ptr(Et), _ptr(state), _ptr(E), B, N, M, _ptr(lens), v, dev, self._stream(dev))

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SDP_LIB_PATH") or os.path.join(_HERE, "libsdp_hip.so")
 
 SDP_NW, SDP_SW = 0, 1
+SDP_NO_ZERO_SKIP, SDP_NO_FILL = 0x800, 0x10000   # include/sdp.h: flags of the backward sweeps
 
 _c_f32p = ctypes.c_void_p
 _c_i32p = ctypes.c_void_p

@@ -312,12 +312,15 @@ unsigned long long *bridge_in_state(const void *state, int B, int N, int M, bool
 struct VariantBits {
     int variant, waves;
     bool exact, et_bcast, ref;
+    int flags;   // Params::flags: bit 0 SDP_NO_ZERO_SKIP, bit 1 SDP_NO_FILL
 };
-// The packed state keeps two 24-bit weights per cell; a saturated weight that the forward sweep leaves one step
-// below 1 costs 1.7e-8 of E on average, which stays inside the 1e-4 parity bound up to ~5000 steps of a fully
-// saturated path (measured: 7.5e-5 at N = M = 2048, 2.7e-4 at N = 20000).  Longer problems therefore always use
-// the exact (float2) state, whose largest weight is the complement of the other two (q_sharpen): <= 1e-5 at
-// N = 60000.  sdp_state_bytes covers either layout; forward and backward apply the same rule.
+// The packed state keeps two 20-bit weights per cell (absolute error <= 2^-21 per weight, sdp_kernels.hip "SDP_Q20").  Its
+// rounding error travels along an alignment path like a random walk (the 24-bit format of rounds 1-3 instead lost 1.7e-8 of
+// E per step of a SATURATED path, 7.5e-5 at N = M = 2048: the 20-bit fields decode a saturated weight to exactly 1 and do
+// not have that term); tests/test_parity_gpu.py::test_packed_state_at_the_longest_paths_it_serves holds max |dE| at
+// N = M = 2048 (N + M = 4096, the longest problem the packed state serves) on soft, steep and peaked scores to half the
+// 1e-4 bound.  Longer problems always use the exact (float2) state, whose largest weight is the complement of the other
+// two (q_sharpen): <= 1e-5 at N = 60000.  sdp_state_bytes covers either layout; forward and backward apply the same rule.
 constexpr int PACKED_MAX_PATH = 4096;
 inline bool exact_for(bool flag, int N, int M) { return flag || N + M > PACKED_MAX_PATH; }
 
@@ -328,7 +331,8 @@ VariantBits split_variant(int variant)
     v.et_bcast = (variant & SDP_ET_BROADCAST) != 0;
     v.waves = (variant >> 12) & 0xf;
     v.ref = (variant & SDP_REF_ROUNDING) != 0;
-    v.variant = variant & ~(SDP_EXACT_STATE | SDP_ET_BROADCAST | SDP_REF_ROUNDING | (0xf << 12));
+    v.flags = ((variant & SDP_NO_ZERO_SKIP) ? 1 : 0) | ((variant & SDP_NO_FILL) ? 2 : 0);
+    v.variant = variant & ~(SDP_EXACT_STATE | SDP_ET_BROADCAST | SDP_REF_ROUNDING | SDP_NO_ZERO_SKIP | SDP_NO_FILL | (0xf << 12));
     return v;
 }
 
@@ -600,7 +604,7 @@ int sdp_forward_f32(const float *theta, const float *A, float *state, float *Vt,
     p.dout = state;
     p.vout = Vt;
     p.lens = lens;
-    p.B = B, p.N = N, p.M = M, p.variant = variant;
+    p.B = B, p.N = N, p.M = M, p.variant = variant, p.flags = vb.flags;
     if (wants_order(B, N, lens, device)) {
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
@@ -632,7 +636,7 @@ int sdp_backward_f32(const float *Et, const float *state, float *E, int B, int N
     p.qin = reinterpret_cast<const uint32_t *>(state);
     p.sout = E;
     p.lens = lens;
-    p.B = B, p.N = N, p.M = M, p.variant = variant;
+    p.B = B, p.N = N, p.M = M, p.variant = variant, p.flags = vb.flags;
     if (lens != nullptr && B > num_cus(device)) p.order = order_in_state(state, B, N, M, exact);
     return launch(sdp::PASS_BWD, p, device, stream, exact, vb.waves, false, state);
 }
@@ -668,7 +672,7 @@ int sdp_backward_range_f32(const float *Et, const float *state, float *E, int B,
     p.vin_bcast = vb.et_bcast ? 1 : 0;
     p.qin = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(state) + (size_t)first * sdp_state_pair_stride(N, M, exact));
     p.sout = E + (size_t)first * N * M;
-    p.B = count, p.N = N, p.M = M, p.variant = variant;
+    p.B = count, p.N = N, p.M = M, p.variant = variant, p.flags = vb.flags;
     // state = nullptr: a launch over part of the batch never spreads pairs over several workgroups -- the bridge rows
     // live behind the record of the batch's LAST pair, and located from a sub-range they would fall into the records of
     // the pairs that follow it
@@ -694,7 +698,7 @@ int sdp_adjoint_forward_f32(const float *state, const float *Ztheta, const float
     p.dout = state_d;
     p.vout = Vtd;
     p.lens = lens;
-    p.B = B, p.N = N, p.M = M, p.variant = variant;
+    p.B = B, p.N = N, p.M = M, p.variant = variant, p.flags = vb.flags;
     if (lens != nullptr && B > num_cus(device)) p.order = order_in_state(state, B, N, M, true);
     return launch(sdp::PASS_AFWD, p, device, stream, false, vb.waves);
 }
@@ -720,7 +724,7 @@ int sdp_adjoint_forward_loss_f32(const float *state, const float *ref, const flo
     p.dout = state_d;
     p.vout = Vtd;
     p.lens = lens;
-    p.B = B, p.N = N, p.M = M, p.variant = variant;
+    p.B = B, p.N = N, p.M = M, p.variant = variant, p.flags = vb.flags;
     if (lens != nullptr && B > num_cus(device)) p.order = order_in_state(state, B, N, M, true);
     return launch(sdp::PASS_AFWD, p, device, stream, false, vb.waves, true);
 }
@@ -743,7 +747,7 @@ int sdp_adjoint_backward_f32(const float *E, const float *state, const float *st
     p.din = reinterpret_cast<const float2 *>(state_d);
     p.sout = Ed;
     p.lens = lens;
-    p.B = B, p.N = N, p.M = M, p.variant = variant;
+    p.B = B, p.N = N, p.M = M, p.variant = variant, p.flags = vb.flags;
     if (lens != nullptr && B > num_cus(device)) p.order = order_in_state(state, B, N, M, true);
     return launch(sdp::PASS_ABWD, p, device, stream, false, vb.waves);
 }

@@ -104,6 +104,7 @@ struct Params {
     int mcap;            // doubles per boundary row in LDS
     int stage_off;       // byte offset of the per-wave staging area in LDS
     int variant;
+    int flags;           // bit 0: run every chunk (SDP_NO_ZERO_SKIP), bit 1: no zero fill outside the pairs' blocks (SDP_NO_FILL)
     int dbg;             // experiments build only (sdp_set_debug): bit0 inputs, bit1 outputs, bit2 state: all pairs alias
                          // pair 0; bit3: strips never publish their progress (exercises the hand-off time-out)
     const int *order;    // launch order (pair per workgroup) or null = identity; lives in the tail of the Q state buffer

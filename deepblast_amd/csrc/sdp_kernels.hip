@@ -27,8 +27,8 @@
 //   * the forward sweep computes in blocks of 16 steps inside a K-step chunk: inputs,
 //     boundary values and published values live in 16-entry arrays (fwd_blocks);
 //   * the saved state (reference: Q, (B,N+2,M+2,3) fp32) is private to this library,
-//     so it is stored ALREADY SKEWED, [pair][strip][t][lane]: packed to 6 bytes per
-//     cell for the backward sweep (two steps per dwordx3), or float2 for the adjoint
+//     so it is stored ALREADY SKEWED, [pair][strip][t][lane]: packed to 5 bytes per
+//     cell for the backward sweep (two 20-bit fields; 16 steps of a lane = five dwordx4), or float2 for the adjoint
 //     sweeps (qm = 1 - qx - qy is never stored).  Forward writes and backward reads
 //     are then fully coalesced wave accesses with no transposition;
 //   * the forward recurrence runs in a scaled exp domain; normally in its windowed
@@ -251,6 +251,7 @@ struct Traits<PASS_ABWD, QX> {  // nw.py:251-267
     static constexpr bool REV = true;
 };
 
+// (The format of rounds 1-3, kept as the SDP_Q20 = 0 build for comparison; the shipped format is SDP_Q20 below: 20-bit fields, 5 bytes per cell.)
 // The saved softmax weights Q (qx, qy; qm = 1 - qx - qy) are kept as two 24-bit fields per cell: the low three
 // bytes of the float f = 1 + q*(1 - 2^-20), i.e. q on a grid of 2^-23 (absolute error <= 2^-24, the precision
 // fp32 itself has for weights in [0.5, 1)); the factor keeps f below 2 for any q <= 1 + 9e-7 -- a weight computed
@@ -580,6 +581,7 @@ __device__ __forceinline__ void sweep(const Params &p)
     auto zero_fill = [&]() {
         if constexpr (T::SOUT > 0) {
             if (p.lens == nullptr || (n == p.N && m == p.M)) return;
+            if (p.flags & 2) return;   // SDP_NO_FILL: the caller never reads E / Ed outside the pairs' blocks
 #ifdef SDP_NO_ZERO_FILL
             return;   // timing experiment only: E keeps whatever was in the buffer outside the pair's block
 #endif
@@ -881,7 +883,7 @@ __device__ __forceinline__ void sweep(const Params &p)
         // strips whose boundary comes through the bridge from another workgroup are left to find out when their turn comes.
         auto boundary_zero = [&](int tn, bool block) -> bool {
             if constexpr (LAZY) {
-                if (SDP_EXP_BUILD && (p.dbg & 4096)) return false;
+                if ((p.flags & 1) || (SDP_EXP_BUILD && (p.dbg & 4096))) return false;
                 unsigned any = (t_final >= tn && t_final < tn + K) ? __float_as_uint(et) : 0u;
                 if (has_pred) {
                     const int c_lo_n = tn - 63;
@@ -1997,7 +1999,7 @@ __device__ __forceinline__ void sweep(const Params &p)
 #pragma unroll
                 for (int k = 0; k < K; ++k) any |= lo32(bcv[k]);
                 if (t_final >= t0 && t_final < t0 + K) any |= __float_as_uint(et);
-                return __builtin_amdgcn_ballot_w64(any != 0) == 0 && !(SDP_EXP_BUILD && (p.dbg & 4096));
+                return __builtin_amdgcn_ballot_w64(any != 0) == 0 && !(p.flags & 1) && !(SDP_EXP_BUILD && (p.dbg & 4096));
             };
             auto zero_fill_ring = [&]() {   // a zero chunk's outputs: +0 to its half of the ring, its boundary values, the row's copy of step K - 1
 #pragma unroll

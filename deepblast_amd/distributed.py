@@ -180,7 +180,10 @@ class ShardedAligner:
         # in the caller's graph -- with A attached, `Vt.sum().backward()` would accumulate the reference's pass-through
         # "gradient" (A itself, nw.py:355) into A.grad and run the backward of whatever produced A, on every align()
         A = A.detach()
-        Vt = self.decoder(theta, A, lengths) if lengths is not None else self.decoder(theta, A)
+        # gather="paths": the walks are all that leaves this rank, and the device walk masks by the lengths -- E outside the
+        # pairs' blocks is then never read and not zero-filled (E_local in the result holds unspecified values there)
+        lean = lengths is not None and self.gather == "paths" and gathering
+        Vt = (self.decoder(theta, A, lengths, **({"fill": False} if lean else {})) if lengths is not None else self.decoder(theta, A))
         # idiom "grad": dVt.sum()/dtheta with the cotangent handed over directly -- no reduction kernel, no fill
         if self.idiom == "grad" and (self._ones is None or self._ones.shape != Vt.shape or self._ones.device != Vt.device):
             self._ones = torch.ones_like(Vt)

@@ -101,7 +101,7 @@ class _DecodeLoss(torch.autograd.Function):
     forms dLoss/dE from (first, E, G, scale) while it stages them.  Same values as the unfused path."""
 
     @staticmethod
-    def forward(ctx, theta, A, first, G, lens_loss, lens_dp, kind, variant):
+    def forward(ctx, theta, A, first, G, lens_loss, lens_dp, kind, variant, fill=False):
         from ._dp import _validate
         _validate(theta, A, 'softmax', False)
         if theta.dtype != torch.float32:
@@ -116,7 +116,9 @@ class _DecodeLoss(torch.autograd.Function):
         B, N, M = th.shape
         Vt, Q = eng.forward(th, a, variant, lens_dp, exact_state=True)
         ones = torch.ones(B, dtype=torch.float32, device=th.device)
-        E = eng.backward(ones, Q, (B, N, M), variant, lens_dp, exact_state=True)
+        # E outside the pairs' blocks is read by nobody in this op (the loss masks by its lengths, both adjoint sweeps by the
+        # DP's): not filled unless the caller wants the returned E whole
+        E = eng.backward(ones, Q, (B, N, M), variant, lens_dp, exact_state=True, **({} if (fill or lens_dp is None) else {"no_fill": True}))
         acc = torch.empty(B, dtype=torch.float64, device=th.device)
         cnt = torch.empty(B, dtype=torch.int32, device=th.device)
         with torch.cuda.device(dev), eng._bracket("sdp_loss_fwd_kernel"):
@@ -152,17 +154,21 @@ class _DecodeLoss(torch.autograd.Function):
             G = G * (ii & jj).to(G.dtype)
         _, Qd = eng.adjoint_forward_loss(Q, first, E, G, sc, kind, variant, lens_dp)
         Ed = eng.adjoint_backward(E, Q, Qd, variant, lens_dp)
-        return Ed, None, None, None, None, None, None, None
+        return Ed, None, None, None, None, None, None, None, None
 
 
-def decode_loss(decoder, loss, theta, A, first, x_len, y_len, G, lengths=None):
+def decode_loss(decoder, loss, theta, A, first, x_len, y_len, G, lengths=None, fill=False):
     """`loss(first, decoder.decode(theta, A[, lengths]), x_len, y_len, G)` as one op -> (loss scalar, E).
 
     decoder : NeedlemanWunschDecoder / SmithWatermanDecoder of this package
     loss    : MatrixCrossEntropy() / SoftPathLoss() / SoftAlignmentLoss() of this module (its `kind` is used)
     lengths : optional (B,2) per-pair sizes for the DP itself (None = the reference's full padded DP)
     The scalar is differentiable w.r.t. theta (the gradient w.r.t. A is None, as in the reference's second-order
-    path, nw.py:386); E is returned for inspection / traceback and is not differentiable through this op."""
+    path, nw.py:386); E is returned for inspection / traceback and is not differentiable through this op.
+    fill    : with `lengths`, False (default) leaves E OUTSIDE each pair's block unwritten -- nothing in this op reads it
+              (the loss slices by x_len / y_len as deepblast/losses.py:30-40 does, the sweeps mask by `lengths`), and
+              `decoder.traceback_batch(E, lengths)` does not either; True zero-fills it like decoder.decode() does.
+              The gradient w.r.t. theta is always zero outside the blocks."""
     from ._engine import NW, SW
     from .sw import SmithWatermanDecoder
     variant = SW if isinstance(decoder, SmithWatermanDecoder) else NW
@@ -179,4 +185,4 @@ def decode_loss(decoder, loss, theta, A, first, x_len, y_len, G, lengths=None):
             la = _np.asarray(lengths)
             same = la.shape == (B, 2) and _np.array_equal(la[:, 0], _np.asarray(x_len)) and _np.array_equal(la[:, 1], _np.asarray(y_len))
         lens_dp = lens_loss if (same and lens_loss is not None) else get_engine()._lens(lengths, B, theta.device)
-    return _DecodeLoss.apply(theta, A, first, G, lens_loss, lens_dp, loss.kind, variant)
+    return _DecodeLoss.apply(theta, A, first, G, lens_loss, lens_dp, loss.kind, variant, bool(fill))

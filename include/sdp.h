@@ -28,15 +28,18 @@
  *   - `state` / `state_d` are opaque buffers of sdp_state_bytes(B,N,M) /
  *     sdp_state_d_bytes(B,N,M) bytes that stand in for the reference's Q / Qd
  *     tensors.  Their layout is private (wavefront-skewed); only
- *     this library reads them.  For the backward sweep Q is kept as two 23-bit
- *     fixed-point weights per cell (absolute error <= 2^-24 per weight, 6 bytes
- *     per cell).  The adjoint sweeps (second order) multiply the weights with
+ *     this library reads them.  For the backward sweep Q is kept as two 20-bit
+ *     fixed-point weights per cell (absolute error <= 2^-21 = 4.8e-7 per weight,
+ *     SDP_PACKED_STATE_BYTES_PER_CELL = 5 bytes per cell, times 1.125 for the skew
+ *     padding at M = 512; a weight within 2^-21 of 1 / of 0 decodes to exactly 1 / 0).
+ *     The adjoint sweeps (second order) multiply the weights with
  *     directional derivatives of any size and need them at full fp32 precision:
  *     run sdp_forward_f32 with SDP_EXACT_STATE for them (float2 per cell, the
  *     size of Qd); sdp_backward_f32 reads that format too when given the flag.
- *     Problems with N + M > 4096 always use the float2 form (a saturated packed
- *     weight costs ~1.7e-8 of E per step; beyond ~5000 steps of a fully saturated
- *     path that would pass 1e-4): sdp_state_bytes accounts for it, and forward
+ *     Problems with N + M > 4096 always use the float2 form (the packed format's
+ *     rounding error is carried along an alignment path like a random walk: measured
+ *     <= 4e-5 of E at N = M = 2048 on soft and on steep scores, bound 1e-4):
+ *     sdp_state_bytes accounts for it, and forward
  *     and backward apply the same rule, so callers need not care.
  *   - `lens` is NULL (reference semantics: every pair uses the full padded N x M)
  *     or a DEVICE pointer to B x 2 int32 (n_b, m_b): pair b is aligned over its
@@ -90,6 +93,19 @@ extern "C" {
  * (sdp_state_bytes_v / sdp_state_d_bytes_v).  Unoptimised: milliseconds where the default path takes a fraction of one.
  * Not available for sdp_adjoint_forward_loss_f32. */
 #define SDP_REF_ROUNDING 0x400
+/* or-ed into `variant` of sdp_backward_f32 / sdp_backward_range_f32: run EVERY chunk of the sweep.  By default the fp32
+ * backward sweep neither runs 32-step chunks that can only produce +0 nor reads their state (E underflows to exactly +0
+ * away from the alignment) -- a data-dependent saving.  The results are bit-identical either way; the flag
+ * is the control a measurement needs (bench.py reports both). */
+#define SDP_NO_ZERO_SKIP 0x800
+/* or-ed into `variant` of sdp_backward_f32 / sdp_adjoint_backward_f32 when `lens` is given: do NOT zero E / Ed outside
+ * each pair's n_b x m_b block -- those cells keep whatever the buffer held.  For callers that never read them: a loss
+ * that masks by the same lengths (deepblast/losses.py:30-40 slices [:x_len, :y_len]), the batched traceback with
+ * lengths, a gather of walks.  The zero fill of a padded batch is as many bytes again as the sweep moves
+ * (BASELINE configs[2]: 784 MB of zeros next to 724 MB). */
+#define SDP_NO_FILL 0x10000
+/* bytes per cell of the packed state (the header's statement of the format; tests/test_abi.py holds sdp_state_bytes to it) */
+#define SDP_PACKED_STATE_BYTES_PER_CELL 5
 
 #define SDP_E_NULLPTR (-1)  /* a required pointer is NULL */
 #define SDP_E_SHAPE (-2)    /* B, N or M non-positive */

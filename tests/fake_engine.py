@@ -40,7 +40,7 @@ class OracleEngine:
         state._oracle_Q = Qs  # opaque, like the real engine's flat state
         return torch.from_numpy(Vt), state
 
-    def backward(self, Et, state, shape, variant, lens=None, exact_state=False, pair_range=None, out=None):
+    def backward(self, Et, state, shape, variant, lens=None, exact_state=False, pair_range=None, out=None, no_fill=False):
         B, N, M = shape
         et = self._np(Et).astype(np.float32).reshape(-1)
         et = np.broadcast_to(et, (B,)) if et.size == 1 else et

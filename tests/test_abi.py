@@ -61,6 +61,26 @@ def test_state_bytes(lib):
     assert lib.sdp_state_bytes(0, 5, 5) == 0
 
 
+def test_header_states_the_packed_state_format_the_library_uses(lib):
+    """include/sdp.h says how many bytes per cell the packed state takes (SDP_PACKED_STATE_BYTES_PER_CELL and the prose
+    next to it): the number must be the one sdp_state_bytes is built on, so that the header cannot rot again (round 4: the
+    header still said 6 bytes / 23-bit fields after the format had become 5 bytes / 20-bit)."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "sdp.h")).read()
+    m = re.search(r"#define\s+SDP_PACKED_STATE_BYTES_PER_CELL\s+(\d+)", hdr)
+    assert m, "include/sdp.h must define SDP_PACKED_STATE_BYTES_PER_CELL"
+    per_cell = int(m.group(1))
+    # (B, N, M) = (1, 64, 2): one strip, 2 + 63 -> 128 steps of 64 lanes; the tail (launch order) is 256 bytes
+    assert lib.sdp_state_bytes(1, 64, 2) == 128 * 64 * per_cell + 256
+    # two pairs more of 512 x 512 cost two records of 8 strips x 576 steps x 64 lanes (+ 1024 bytes of dispatch map for the
+    # parts of the two extra pairs): the per-cell figure again, through a difference that drops the rest of the tail
+    assert lib.sdp_state_pair_stride(512, 512, 0) == 8 * 576 * 64 * per_cell
+    assert f"{per_cell} bytes" in hdr and "20-bit" in hdr and "23-bit" not in hdr and "6 bytes" not in hdr
+    for doc in ("INTEGRATION.md", os.path.join("deepblast_amd", "_engine.py"), os.path.join("deepblast_amd", "_dp.py")):
+        text = open(os.path.join(ROOT, doc)).read()
+        assert "6 bytes per cell" not in text and "6 B/cell" not in text, doc
+
+
 def test_argument_errors_need_no_gpu(lib):
     one = ctypes.c_void_p(16)
     assert lib.sdp_forward_f32(None, one, one, one, 1, 1, 1, None, 0, 0, None) == -1

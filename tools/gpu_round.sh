@@ -5,7 +5,7 @@
 # modes, FETCH_SIZE and WRITE_SIZE counter passes (separate runs, kernel-trace only -- gpurun refuses pmc + other
 # traces), and the source hash the numbers belong to.  Afterwards, in the build container:
 #   python tools/collect_profiles.py <tag>    -> profiles/<tag>_*.csv|json + profiles/traffic.json (stamped)
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/round_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -29,14 +29,14 @@ if [ "$NGPU" -ge 2 ]; then
 else
   echo "multi-GPU dry run SKIPPED: $NGPU GPU visible (needs >= 2; nothing in this repo has run on more than one GPU yet)" | tee $OUT/multigpu_skipped.txt
 fi
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o fwdbwd -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/rocprof.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o train -- python bench.py --steps 10 --warmup 2 --mode train --no-cpu-baseline > $OUT/bench_prof_train.json 2>> $OUT/rocprof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o fwdbwd -- env BENCH_NO_SECONDARY=1 python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/rocprof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o train -- env BENCH_NO_SECONDARY=1 python bench.py --steps 10 --warmup 2 --mode train --no-cpu-baseline > $OUT/bench_prof_train.json 2>> $OUT/rocprof.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_scores -o scores -- python bench.py --steps 10 --warmup 2 --mode scores+dp --no-cpu-baseline > $OUT/bench_prof_scores.json 2>> $OUT/rocprof.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_cfg -o cfg -- python tools/gpu_configs.py > $OUT/configs_prof.txt 2>> $OUT/rocprof.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_scores_bwd -o sb -- python tools/scores_bwd_probe.py 2>> $OUT/rocprof.err | grep ' us' > $OUT/scores_bwd.txt
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o fwdbwd -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$C.err
-  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_train_$C -o train -- python bench.py --steps 3 --warmup 1 --mode train --no-cpu-baseline > /dev/null 2>> $OUT/pmc_$C.err
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o fwdbwd -- env BENCH_NO_SECONDARY=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$C.err
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_train_$C -o train -- env BENCH_NO_SECONDARY=1 python bench.py --steps 3 --warmup 1 --mode train --no-cpu-baseline > /dev/null 2>> $OUT/pmc_$C.err
 done
 # the bench lines LAST, after profiles/traffic.json has been rebuilt (on this box's copy) from the counter passes of this
 # very visit: their roofline.traffic then is the figure measured minutes earlier on the same sources
