@@ -103,6 +103,14 @@ Variant variant(int id)
     case 26: return {(const void *)sdp_fwd_x_tp_pg_kernel, SDP_K_FWD, SDP_MAXW_FWD, 26};
     case 27: return {(const void *)sdp_bwd_pg_kernel, SDP_K_BWD, SDP_MAXW_BWD, 27};
     case 28: return {(const void *)sdp_bwd_x_pg_kernel, SDP_K_BWD, SDP_MAXW_BWD, 28};
+    // 18-bit packed state (sdp_kernels.h: packed_bits): 29 fwd, 30 fwd latency, 31 fwd general pitch, 32 bwd, 33 bwd latency, 34 / 35 their general pitch
+    case 29: return {(const void *)sdp_fwd18_kernel, SDP_K_FWD, SDP_MAXW_FWD, 29};
+    case 30: return {(const void *)sdp_fwd18_lat_kernel, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, 30};
+    case 31: return {(const void *)sdp_fwd18_g_kernel, SDP_K_FWD, SDP_MAXW_FWD, 31};
+    case 32: return {(const void *)sdp_bwd18_kernel, SDP_K_BWD, SDP_MAXW_BWD, 32};
+    case 33: return {(const void *)sdp_bwd18_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 33};
+    case 34: return {(const void *)sdp_bwd18_g_kernel, SDP_K_BWD, SDP_MAXW_BWD, 34};
+    case 35: return {(const void *)sdp_bwd18_lat_g_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 35};
     default: return {(const void *)sdp_bwd_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 4};
     }
 }
@@ -165,9 +173,27 @@ int general_id(int id)
 constexpr int PART_STRIPS = 4;
 inline int parts_per_pair(int N) { return (sdp::state_nstrips(N) + PART_STRIPS - 1) / PART_STRIPS; }
 
+// kernel id -> the build of the same sweep for the 18-bit packed state (or itself: builds that do not touch a packed state)
+int q18_id(int id)
+{
+    switch (id) {
+    case 0: return 29;
+    case 6: return 30;
+    case 11: return 31;
+    case 1: return 32;
+    case 4: return 33;
+    case 12: return 34;
+    case 15: return 35;
+    default: return id;
+    }
+}
+
 Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cus, int forced_waves, bool fused_seed = false,
           bool general_pitch = false, int allow_parts = 1 /* 0 never, 1 where it pays, 2 wherever it is possible */)
 {
+    // the packed state of this problem: 18-bit fields never go with parts (the format is a function of the shape alone, so
+    // that forward and backward agree; sdp_kernels.h: packed_bits)
+    const bool q18 = !exact_state && (pass == sdp::PASS_FWD || pass == sdp::PASS_BWD) && sdp::packed_bits(N, M, has_lens) == 18;
     const int nstrips = sdp::state_nstrips(N);
     const int mcap = (M + 63) / 64 * 64;
     // Waves per pair.  A batch that occupies the GPU is bound by HBM/fabric traffic and runs best with one wave
@@ -197,6 +223,7 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
     const int nin = (pass == sdp::PASS_AFWD && fused_seed) ? 3 : 0;   // three staged planes (ref, pred, G)
     if (nin) v = variant(10);
     if (general_pitch) v = variant(general_id(v.id));
+    if (q18) v = variant(q18_id(v.id));
     // A pair over several workgroups (sdp_kernels.hip, "PARTS"): parts of four strips, each on a CU of its own, one strip
     // per wave of the 4-wave throughput builds, instead of one CU taking all the pair's strips in rounds.  It pays only
     // where CUs would otherwise idle AND the pair is long enough for the extra lag per bridge (measured, round 3, us
@@ -210,7 +237,7 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
     // backward sweep from two; equal pairs only the backward sweep of pairs of four parts.  The adjoint pair (float64
     // carries) keeps one workgroup per pair.
     int parts = 0;
-    const bool parts_fit = sweep12 && forced_waves <= 0 && nstrips > PART_STRIPS;
+    const bool parts_fit = sweep12 && forced_waves <= 0 && nstrips > PART_STRIPS && !q18;
     const bool parts_pay = B <= cus && (has_lens ? (pass == sdp::PASS_BWD || nstrips > 2 * PART_STRIPS)
                                                  : (pass == sdp::PASS_BWD && nstrips > 3 * PART_STRIPS && (long long)B * parts_per_pair(N) <= cus));
     if (parts_fit && (allow_parts == 2 || (allow_parts == 1 && parts_pay))) {
@@ -245,8 +272,9 @@ void state_layout(sdp::Params &p)
 {
     const size_t streams = (size_t)p.B * p.nstrips_max, units = (size_t)p.tpad / sdp::STATE_UNIT_STEPS;
     const bool march = SDP_STATE_MARCH && streams * units * sdp::STATE2_UNIT_BYTES < ((size_t)1 << 31);
-    p.st_ps = march ? sdp::STATEQ_UNIT_BYTES : units * sdp::STATEQ_UNIT_BYTES;
-    p.st_us = march ? (unsigned)(streams * sdp::STATEQ_UNIT_BYTES) : sdp::STATEQ_UNIT_BYTES;
+    const unsigned qunit = sdp::stateq_unit_bytes(p.qbits);   // (18-bit fields: 9216 B per 32 steps, else 10240)
+    p.st_ps = march ? qunit : units * qunit;
+    p.st_us = march ? (unsigned)(streams * qunit) : qunit;
     p.st2_ps = march ? sdp::STATE2_UNIT_BYTES : units * sdp::STATE2_UNIT_BYTES;
     p.st2_us = march ? (unsigned)(streams * sdp::STATE2_UNIT_BYTES) : sdp::STATE2_UNIT_BYTES;
 }
@@ -340,7 +368,7 @@ VariantBits split_variant(int variant)
 // 160 KiB the hardware has, so concurrent callers cannot disagree
 int raise_lds_limit(const Variant &v, int device)
 {
-    static thread_local unsigned long long lds_raised[29] = {0};  // per kernel id: bit d = done on device d
+    static thread_local unsigned long long lds_raised[36] = {0};  // per kernel id: bit d = done on device d
     if (device >= 64 || !(lds_raised[v.id] >> device & 1ull)) {
         hipError_t e = hipFuncSetAttribute(v.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -356,6 +384,7 @@ int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state 
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
     if (int rc = pending_handoff_error(device)) return rc;
     p.nstrips_max = sdp::state_nstrips(p.N);
+    p.qbits = sdp::packed_bits(p.N, p.M, p.lens != nullptr);
     p.tpad = sdp::state_tpad(p.M);
     p.mcap = (p.M + 63) / 64 * 64;
     state_layout(p);
@@ -552,7 +581,7 @@ int sdp_init(int device)
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
     if (device >= 0 && device < MAX_DEV && !status_words(device)) return fail(SDP_E_SELFTEST, "sdp_init: could not create the host-pinned status words");
-    for (int id = 0; id <= 28; ++id) {   // (21-28: the parts instantiations)
+    for (int id = 0; id <= 35; ++id) {   // (21-28: the parts instantiations, 29-35: the 18-bit packed state)
         const Variant v = variant(id);
         if (v.id != id) continue;   // ids without a build of their own map to the default
         if (int rc = raise_lds_limit(v, device)) return rc;
@@ -647,7 +676,7 @@ size_t sdp_state_pair_stride(int N, int M, int exact_state)
     // the body of the state buffer is B equal records, one per pair: nstrips streams of tpad / 32 units
     // (state_layout); order, bridge rows and dispatch map live behind the LAST pair's record, not between records
     const size_t units = (size_t)sdp::state_nstrips(N) * (sdp::state_tpad(M) / sdp::STATE_UNIT_STEPS);
-    return units * (exact_for(exact_state != 0, N, M) ? sdp::STATE2_UNIT_BYTES : sdp::STATEQ_UNIT_BYTES);
+    return units * (exact_for(exact_state != 0, N, M) ? sdp::STATE2_UNIT_BYTES : sdp::stateq_unit_bytes(sdp::packed_bits(N, M, false)));
 }
 
 int sdp_backward_range_f32(const float *Et, const float *state, float *E, int B, int N, int M, int first, int count,

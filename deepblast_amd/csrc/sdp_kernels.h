@@ -104,6 +104,7 @@ struct Params {
     int mcap;            // doubles per boundary row in LDS
     int stage_off;       // byte offset of the per-wave staging area in LDS
     int variant;
+    int qbits;           // field width of the packed state this launch writes / reads (packed_bits): 18 or 20
     int flags;           // bit 0: run every chunk (SDP_NO_ZERO_SKIP), bit 1: no zero fill outside the pairs' blocks (SDP_NO_FILL)
     int dbg;             // experiments build only (sdp_set_debug): bit0 inputs, bit1 outputs, bit2 state: all pairs alias
                          // pair 0; bit3: strips never publish their progress (exercises the hand-off time-out)
@@ -146,6 +147,21 @@ __host__ __device__ inline size_t state_order_bytes(int B) { return ((size_t)B *
 #endif
 constexpr int STATE_UNIT_STEPS = 32;
 constexpr unsigned STATEQ_UNIT_BYTES = SDP_Q20 ? 10 * 1024 : 16 * 768, STATE2_UNIT_BYTES = 32 * 512;
+// Round 5: two 18-bit fields per cell (4.5 bytes; a 32-step unit is two blocks of four dwordx4 rows + one dwordx2 row = 9216 B)
+// for problems whose alignment paths are short enough for the coarser grid to stay ten times inside the parity bound
+// (sdp_kernels.hip, "18-bit fields"): N + M <= 1024, and -- so that the forward and the backward call agree without knowing each
+// other's launch plans -- only problems that can never be spread over several workgroups: no per-pair lengths, N <= 768.
+// sdp_state_bytes keeps sizing the buffer for the 20-bit fields (it is not told about lengths).
+#ifndef SDP_Q18
+#define SDP_Q18 1
+#endif
+constexpr unsigned STATEQ18_UNIT_BYTES = 2 * (4 * 1024 + 512);
+constexpr int PACKED18_MAX_PATH = 1024;
+__host__ __device__ inline int packed_bits(int N, int M, bool has_lens)
+{
+    return (SDP_Q18 && SDP_Q20 && !has_lens && N + M <= PACKED18_MAX_PATH && N <= 768) ? 18 : (SDP_Q20 ? 20 : 24);
+}
+__host__ __device__ inline unsigned stateq_unit_bytes(int qbits) { return qbits == 18 ? STATEQ18_UNIT_BYTES : STATEQ_UNIT_BYTES; }
 // (Sharing the ramp rows of neighbouring strips -- no skew padding -- was implemented in round 2 for both formats, measured
 // slower (partial-line writes) and removed in round 3; see DESIGN.md.)
 __host__ __device__ inline size_t state_rows2(int N, int M) { return (size_t)((N + 63) / 64) * ((M + 63 + 63) / 64 * 64); }
@@ -190,6 +206,13 @@ __global__ void sdp_bwd_lat_g_kernel(const sdp::Params p);
 __global__ void sdp_bwd_x_g_kernel(const sdp::Params p);
 __global__ void sdp_bwd_x_lat_g_kernel(const sdp::Params p);
 __global__ void sdp_adj_bwd_g_kernel(const sdp::Params p);
+__global__ void sdp_fwd18_kernel(const sdp::Params p);
+__global__ void sdp_fwd18_lat_kernel(const sdp::Params p);
+__global__ void sdp_fwd18_g_kernel(const sdp::Params p);
+__global__ void sdp_bwd18_kernel(const sdp::Params p);
+__global__ void sdp_bwd18_lat_kernel(const sdp::Params p);
+__global__ void sdp_bwd18_g_kernel(const sdp::Params p);
+__global__ void sdp_bwd18_lat_g_kernel(const sdp::Params p);
 __global__ void sdp_ref_fwd_kernel(const float *theta, const float *A, float *Q, float *Vt, const int *lens, int N, int M, int sw);
 __global__ void sdp_ref_bwd_kernel(const float *Et, const float *Q, float *E, const int *lens, int N, int M, int sw, int et_bcast);
 __global__ void sdp_ref_adj_fwd_kernel(const float *Q, const float *Ztheta, const float *ZA, float *Vtd, float *Qd, const int *lens, int N, int M);

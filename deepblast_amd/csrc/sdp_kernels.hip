@@ -141,6 +141,21 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #ifndef SDP_FLUSH2
 #define SDP_FLUSH2 1  // reverse sweeps, aligned K = 32 builds: outputs leave two columns per lane (see FLUSH2)
 #endif
+#ifndef SDP_BWD_PIPE
+#define SDP_BWD_PIPE 1  // fp32 backward sweep, aligned K = 32 builds: the chunk as ONE software pipeline (see PIPE in the chunk loop)
+#endif
+#ifndef SDP_BWD_MASKFREE
+#define SDP_BWD_MASKFREE 1  // fp32 backward sweep: the ramps of a full strip run the mask-free step body too (see bwd_mask_free)
+#endif
+#ifndef SDP_DEAD_LINES
+#define SDP_DEAD_LINES 0  // (0: off -- built, bit-identical, measured in round 5 and NOT adopted: forward alone 193 -> 185 us, but the forward;backward sequence 312 +- 4 us either way and the backward sweep 124 -> 128 us when it masks its loads; 1: the forward sweep does not write them; 2: the backward sweep does not read them either)  // packed state: 128-byte lines of the skew padding whose eight lanes are all outside the matrix for a whole 16-step block are neither written nor read
+#endif
+#ifndef SDP_PIPE_ST
+#define SDP_PIPE_ST 1  // PIPE: one of the previous chunk's 16 output stores every SDP_PIPE_ST steps (1: all in the first half of the chunk)
+#endif
+#ifndef SDP_PIPE_PUB
+#define SDP_PIPE_PUB 0  // PIPE: this strip's boundary values leave 0 = after the steps, 1 = four at a time inside them, 2 = in two halves
+#endif
 #ifndef SDP_BWD_HALF
 #define SDP_BWD_HALF 0  // fp32 backward sweep: boundary hand-off in halves of a chunk (see HALF) -- measured slower, off
 #endif
@@ -306,9 +321,20 @@ __device__ __forceinline__ void q20_pack4(const unsigned *fx, const unsigned *fy
     w[3] = __builtin_amdgcn_ubfe(fx[2], 16, 4) | ((fy[2] & 0xfffffu) << 4) | (fx[3] << 24);
     w[4] = __builtin_amdgcn_ubfe(fx[3], 8, 12) | (fy[3] << 12);
 }
+#ifndef SDP_Q20_BFI
+#define SDP_Q20_BFI 1  // the field goes under the exponent of 8.0 with ONE v_bfi_b32 (mask in an SGPR, 0x41000000 in a VGPR) instead of v_and + v_or
+#endif
 __device__ __forceinline__ float q20_field(unsigned u)  // field in the low 20 bits of u, anything above -> f - 8
 {
+#if SDP_Q20_BFI
+    // gfx9 allows one constant-bus operand per VALU instruction, so the compiler, given two literals, emits two
+    // instructions; with the bias in a register the bit-field insert does it in one.  Same bits.
+    unsigned r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(0xfffffu), "v"(u), "v"(0x41000000u));
+    return __uint_as_float(r) - 8.0f;
+#else
     return __uint_as_float((u & 0xfffffu) | 0x41000000u) - 8.0f;
+#endif
 }
 // (f - 8) of both weights of cell `sub` (0..3) of a five-dword record; the caller multiplies by Q20_UNSCALE
 __device__ __forceinline__ float2 q20_unpack(const unsigned *w, int sub)
@@ -318,6 +344,70 @@ __device__ __forceinline__ float2 q20_unpack(const unsigned *w, int sub)
     case 1: return make_float2(q20_field(w[1] >> 8), q20_field(__builtin_amdgcn_alignbit(w[2], w[1], 28)));
     case 2: return make_float2(q20_field(__builtin_amdgcn_alignbit(w[3], w[2], 16)), q20_field(w[3] >> 4));
     default: return make_float2(q20_field(__builtin_amdgcn_alignbit(w[4], w[3], 24)), q20_field(w[4] >> 12));
+    }
+}
+
+// Round 5: two 18-bit fields per cell (4.5 bytes) for problems with N + M <= 1024 (sdp_kernels.h: packed_bits).  A field is
+// the low 18 bits of the float f = 32 + q * (1 - 2^-17): in [32, 64) one ulp is 2^-18 (absolute error <= 2^-19 = 1.9e-6 per
+// weight).  Gate (ten times the bound at every shape the format serves): the float64 oracle's weights rounded to
+// the grid, backward recurrence in float64, max |dE| over three seeds -- 512 x 512: benchmark scores 1.9e-6, theta x 4
+// 4.8e-6, theta x 8 7.4e-6, theta x 12 / A x 6 7.5e-6, theta x 30 5.6e-6; at 1024 x 1024 theta x 8 reaches 1.04e-5, which is why
+// the format stops at N + M = 1024 and the 20-bit fields take over (17-bit: 1.5e-5, 16-bit: 3.5e-5 at 512 x 512).  Eight cells
+// -- sixteen fields -- fill nine dwords; the 18 dwords of a 16-step block are four rows of one dwordx4 per lane and one row
+// of a dwordx2 (4608 bytes per block instead of 5120).
+constexpr float Q18_SCALE = 0.99999237060546875f;       // 1 - 2^-17
+constexpr float Q18_UNSCALE = 1.00000762939453125f;     // 1 + 2^-17 = 1 / (1 - 2^-17) to fp32
+template <int QB>
+struct QFmt;
+template <>
+struct QFmt<20> {
+    static constexpr int REC_STEPS = 4, REC_DW = 5, BLK_DW = 20, BLK_ROWS = 5;   // rows: dwordx4 per lane (the last may be a half row)
+    static constexpr bool TAIL_X2 = false;
+    static constexpr unsigned BLK_BYTES = 5 * 1024;
+    static constexpr float BASE = 8.0f;
+};
+template <>
+struct QFmt<18> {
+    static constexpr int REC_STEPS = 8, REC_DW = 9, BLK_DW = 18, BLK_ROWS = 5;
+    static constexpr bool TAIL_X2 = true;   // row 4 of a block holds two dwords per lane (512 bytes)
+    static constexpr unsigned BLK_BYTES = 4 * 1024 + 512;
+    static constexpr float BASE = 32.0f;
+};
+template <int QB> __device__ __forceinline__ constexpr float qf_scale() { return QB == 18 ? Q18_SCALE : (Q20 ? Q20_SCALE : Q_SCALE); }
+template <int QB> __device__ __forceinline__ constexpr float qf_unscale() { return QB == 18 ? Q18_UNSCALE : (Q20 ? Q20_UNSCALE : Q_UNSCALE); }
+template <int QB> __device__ __forceinline__ constexpr float qf_base() { return QB == 18 ? 32.0f : (Q20 ? 8.0f : 1.0f); }
+// raw bits fx[k], fy[k] of eight cells' biased floats (0x42000000 | field) -> nine dwords (generated and checked by a script:
+// a left shift by >= 7 pushes the exponent bits 25 and 30 out of the dword, bits 18-23 of a biased float are zero)
+__device__ __forceinline__ void q18_pack8(const unsigned *fx, const unsigned *fy, unsigned *w)
+{
+    w[0] = (fx[0] & 0x3ffffu) | (fy[0] << 18);
+    w[1] = __builtin_amdgcn_ubfe(fy[0], 14, 4) | ((fx[1] & 0x3ffffu) << 4) | (fy[1] << 22);
+    w[2] = __builtin_amdgcn_ubfe(fy[1], 10, 8) | (fx[2] << 8) | (fy[2] << 26);
+    w[3] = __builtin_amdgcn_ubfe(fy[2], 6, 12) | (fx[3] << 12) | (fy[3] << 30);
+    w[4] = __builtin_amdgcn_ubfe(fy[3], 2, 16) | (fx[4] << 16);
+    w[5] = __builtin_amdgcn_ubfe(fx[4], 16, 2) | ((fy[4] & 0x3ffffu) << 2) | (fx[5] << 20);
+    w[6] = __builtin_amdgcn_ubfe(fx[5], 12, 6) | ((fy[5] & 0x3ffffu) << 6) | (fx[6] << 24);
+    w[7] = __builtin_amdgcn_ubfe(fx[6], 8, 10) | (fy[6] << 10) | (fx[7] << 28);
+    w[8] = __builtin_amdgcn_ubfe(fx[7], 4, 14) | (fy[7] << 14);
+}
+__device__ __forceinline__ float q18_field(unsigned u)  // field in the low 18 bits of u, anything above -> f - 32
+{
+    unsigned r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(0x3ffffu), "v"(u), "v"(0x42000000u));
+    return __uint_as_float(r) - 32.0f;
+}
+// (f - 32) of both weights of cell `sub` (0..7) of a nine-dword record; the caller multiplies by Q18_UNSCALE
+__device__ __forceinline__ float2 q18_unpack(const unsigned *w, int sub)
+{
+    switch (sub) {
+    case 0: return make_float2(q18_field(w[0]), q18_field(__builtin_amdgcn_alignbit(w[1], w[0], 18)));
+    case 1: return make_float2(q18_field(w[1] >> 4), q18_field(__builtin_amdgcn_alignbit(w[2], w[1], 22)));
+    case 2: return make_float2(q18_field(w[2] >> 8), q18_field(__builtin_amdgcn_alignbit(w[3], w[2], 26)));
+    case 3: return make_float2(q18_field(w[3] >> 12), q18_field(__builtin_amdgcn_alignbit(w[4], w[3], 30)));
+    case 4: return make_float2(q18_field(__builtin_amdgcn_alignbit(w[5], w[4], 16)), q18_field(w[5] >> 2));
+    case 5: return make_float2(q18_field(__builtin_amdgcn_alignbit(w[6], w[5], 20)), q18_field(w[6] >> 6));
+    case 6: return make_float2(q18_field(__builtin_amdgcn_alignbit(w[7], w[6], 24)), q18_field(w[7] >> 10));
+    default: return make_float2(q18_field(__builtin_amdgcn_alignbit(w[8], w[7], 28)), q18_field(w[8] >> 14));
     }
 }
 
@@ -468,7 +558,7 @@ __device__ __forceinline__ float loss_dterm(float r, float y, float sc, int kind
 // start on K-float boundaries (M a multiple of 32, 128-byte aligned tensors): the same formulas with the offsets
 // folded to constants -- the host picks per launch (sdp_api.hip), and the headline shape pays nothing for generality
 // (with one instantiation for both, the forward kernel measured +5 % and the backward +3 % at M = 512).
-template <int PASS, int K, bool QX = false, bool LINES = false, bool GEN = false, bool PARTS = false>
+template <int PASS, int K, bool QX = false, bool LINES = false, bool GEN = false, bool PARTS = false, int QB = 20>
 __device__ __forceinline__ void sweep(const Params &p)
 {
     using T = Traits<PASS, QX>;
@@ -693,6 +783,20 @@ __device__ __forceinline__ void sweep(const Params &p)
         constexpr unsigned ST_RECORDS = 0x7fffffffu;
         const size_t ps_idx = b_st * p.nstrips_max + s;
         const unsigned q_lane = lane * (Q20 ? 16 : 12);
+        // Dead lines (round 5).  The skewed state has a record for every (step, lane), also where the lane's cell lies outside
+        // the matrix: 64 of a strip's M + 64 step rows are such padding (11 % at M = 512).  Round 4 tried to skip the records of
+        // dead LANES and lost (partial 128-byte lines at the edge of a ramp).  Here whole lines only: a row of a 16-step block is
+        // eight lines of eight lanes (16 bytes each); a line is skipped when ALL eight lanes are outside the matrix for ALL 16
+        // steps of the block -- not started yet (8g > tb + 15, g = lane / 8) or done (tb > m + 8g + 6), or below a partial strip's
+        // last row.  Three quarters of the padding are such lines: 8.3 % of the state at M = 512.  Nothing depends on what a
+        // skipped line would have held: every field decodes to a finite weight, and cells outside the matrix hand on e = 0 (or,
+        // left of the matrix, only to each other).  The half rows of the 18-bit format are four lines of sixteen lanes.
+        auto q_lane_blk = [&](int tb, int lanes_per_line) -> unsigned {   // this lane's offset in a row of the block at step tb, or OOB
+            const int g0 = lane & ~(lanes_per_line - 1), g1 = g0 + lanes_per_line - 1;   // the line's first and last lane
+            const bool dead = (REV ? SDP_DEAD_LINES > 1 : SDP_DEAD_LINES > 0) && Q20 && (g0 > tb + 15 || tb > m - 1 + g1 || g0 >= rows);
+            return dead ? OOB : (lanes_per_line == 8 ? lane * 16u : lane * 8u);
+        };
+        unsigned q_lane_st = q_lane, q_lane_st2 = lane * 8;   // forward sweep: offsets of the block being stored (dwordx4 rows / the 18-bit half row)
         __amdgpu_buffer_rsrc_t rs_q = make_rsrc(T::QIN == Q_PACKED ? (const void *)(reinterpret_cast<const char *>(p.qin) + ps_idx * p.st_ps)
                                                 : (T::QOUT == Q_PACKED ? (const void *)(static_cast<char *>(p.dout) + ps_idx * p.st_ps) : (const void *)p.vout),
                                                 (T::QIN == Q_PACKED || T::QOUT == Q_PACKED) ? ST_RECORDS : 0u);
@@ -702,7 +806,10 @@ __device__ __forceinline__ void sweep(const Params &p)
         // dwords 4j .. 4j+3 of every lane -- so that every access is a whole dwordx4 of contiguous 1 KB per wave: five memory
         // instructions per 16 steps (the first layout of round 4, dwordx4 + dword per record, took eight; rounds 1-3 eight
         // dwordx3).  A 32-step unit is two blocks, ten rows.  Scalar offset of row jr (0..4) of the block that holds step t:
-        auto q20_soff = [&](int t, int jr) { return (unsigned)(t >> 5) * p.st_us + (unsigned)((((t >> 4) & 1) * 5 + jr) * 1024); };
+        // (18-bit fields, round 5: a block is 18 dwords -- four such rows and a fifth of one dwordx2 per lane, 512 B)
+        using QF_ = QFmt<QB>;
+        static_assert(QB == 20 || (QB == 18 && Q20 && !PARTS), "18-bit fields: the modern row layout, one workgroup per pair");
+        auto q20_soff = [&](int t, int jr) { return (unsigned)(t >> 5) * p.st_us + (unsigned)(((t >> 4) & 1) * QF_::BLK_BYTES + jr * 1024); };
         typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
         typedef unsigned u32x4q __attribute__((ext_vector_type(4)));
         // (an earlier variant sent the records of lanes that lie outside the matrix for all their steps out of range -- neither
@@ -720,15 +827,27 @@ __device__ __forceinline__ void sweep(const Params &p)
         // refills registers of their own anyway and moved them over at the end of the iteration, behind a vmcnt(0) that the
         // loads issued during the last steps had had a few hundred cycles to meet: the reverse sweeps ran at memory latency.)
         constexpr bool TOPLOAD = Q20 && REV && T::QIN == Q_PACKED;
+        auto load_row = [&](__amdgpu_buffer_rsrc_t rs, int t_base, int jj, u32x4q &dst) {   // row jj of the chunk (five per 16-step block)
+            if constexpr (QF_::TAIL_X2) {
+                if (jj % 5 == 4) {   // the block's two last dwords: one dwordx2 per lane
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, q_lane_blk(t_base + 16 * (jj / 5), 16), q20_soff(t_base + 16 * (jj / 5), 4), AUX_ST_LOAD);
+                    const unsigned v0 = v[0], v1 = v[1];
+                    dst[0] = v0, dst[1] = v1;
+                    return;
+                }
+            }
+            dst = __builtin_amdgcn_raw_buffer_load_b128(rs, q_lane_blk(t_base + 16 * (jj / 5), 8), q20_soff(t_base + 16 * (jj / 5), jj % 5), AUX_ST_LOAD);
+        };
         auto load_q20 = [&](int t_base, int jj, auto set_tag) {   // row jj (0 .. QROWS-1) of the chunk that starts at step t_base -> set S
-            rq2[decltype(set_tag)::value][jj] = __builtin_amdgcn_raw_buffer_load_b128(rs_q, q_lane, q20_soff(t_base + 16 * (jj / 5), jj % 5), AUX_ST_LOAD);
+            load_row(rs_q, t_base, jj, rq2[decltype(set_tag)::value][jj]);
         };
         // the five dwords of the record of steps 4g .. 4g+3 of the chunk, out of the rows of set S
-        auto q20_record = [&](int g, unsigned *w, auto set_tag) {
+        auto q20_record = [&](int g, unsigned *w, auto set_tag) {   // (QB = 18: the nine dwords of the record of steps 8g .. 8g+7)
+            constexpr int RPB = 16 / QF_::REC_STEPS;   // records per block
 #pragma unroll
-            for (int e = 0; e < 5; ++e) {
-                const int d = 5 * (g & 3) + e;           // dword of the block
-                w[e] = rq2[decltype(set_tag)::value][5 * (g >> 2) + (d >> 2)][d & 3];
+            for (int e = 0; e < QF_::REC_DW; ++e) {
+                const int d = QF_::REC_DW * (g % RPB) + e;           // dword of the block
+                w[e] = rq2[decltype(set_tag)::value][5 * (g / RPB) + (d >> 2)][d & 3];
             }
         };
         auto load_q = [&](int t_base, int g, unsigned *dst) {  // 24-bit: steps t_base + 2g, + 1 (3 dwords)
@@ -745,9 +864,18 @@ __device__ __forceinline__ void sweep(const Params &p)
             // is forced here: the no-op "reads" the data registers (nothing that overwrites them can move above
             // it) and is ordered after the store as a memory operation.
             if constexpr (Q20) {   // g: row of the block that holds step t_base (src: its four dwords)
+                if constexpr (QF_::TAIL_X2) {
+                    if (g == 4) {   // (18-bit fields) the block's two last dwords
+                        typedef unsigned u32x2q __attribute__((ext_vector_type(2)));
+                        u32x2q v2;
+                        v2[0] = src[0], v2[1] = src[1];
+                        __builtin_amdgcn_raw_buffer_store_b64(v2, rs_q, q_lane_st2, q20_soff(t_base, 4), AUX_ST_STORE);
+                        return;
+                    }
+                }
                 u32x4q v;
                 v[0] = src[0], v[1] = src[1], v[2] = src[2], v[3] = src[3];
-                __builtin_amdgcn_raw_buffer_store_b128(v, rs_q, q_lane, q20_soff(t_base, g), AUX_ST_STORE);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_q, q_lane_st, q20_soff(t_base, g), AUX_ST_STORE);
                 asm volatile("s_nop 1" : : "v"(v) : "memory");
             } else {
                 u32x3 v;
@@ -787,10 +915,26 @@ __device__ __forceinline__ void sweep(const Params &p)
         // it.  20-bit fields: every fourth step 13 shift / mask / or instructions assemble the 20-byte record of four cells,
         // stored as dwordx4 + dword.
         unsigned qbits_x = 0, qbits_y = 0;
-        unsigned qb_x[3] = {0, 0, 0}, qb_y[3] = {0, 0, 0};
+        unsigned qb_x[QB == 18 ? 7 : 3] = {0, 0, 0}, qb_y[QB == 18 ? 7 : 3] = {0, 0, 0};
         unsigned qblk[20];   // 20-bit fields: the dwords of the current 16-step block; a row leaves as soon as it is complete
         auto store_state_bits = [&](int t_base, int k, unsigned fx, unsigned fy) {
-            if constexpr (Q20) {
+            if constexpr (QB == 18) {
+                // eight cells to a record of nine dwords; a block's rows 0, 1 are complete after its first record, rows 2, 3 and
+                // the half row after its second
+                if ((k & 7) != 7) {
+#pragma unroll
+                    for (int j = 0; j < 7; ++j)
+                        if ((k & 7) == j) qb_x[j] = fx, qb_y[j] = fy;
+                } else {
+                    const unsigned ax[8] = {qb_x[0], qb_x[1], qb_x[2], qb_x[3], qb_x[4], qb_x[5], qb_x[6], fx};
+                    const unsigned ay[8] = {qb_y[0], qb_y[1], qb_y[2], qb_y[3], qb_y[4], qb_y[5], qb_y[6], fy};
+                    const int g = (k >> 3) & 1;   // record of the block
+                    q18_pack8(ax, ay, qblk + 9 * g);
+                    const int tb16 = t_base + (k & ~15);
+                    if (g == 0) store_q(tb16, 0, qblk), store_q(tb16, 1, qblk + 4);
+                    else store_q(tb16, 2, qblk + 8), store_q(tb16, 3, qblk + 12), store_q(tb16, 4, qblk + 16);
+                }
+            } else if constexpr (Q20) {
                 if ((k & 3) == 0) qb_x[0] = fx, qb_y[0] = fy;
                 else if ((k & 3) == 1) qb_x[1] = fx, qb_y[1] = fy;
                 else if ((k & 3) == 2) qb_x[2] = fx, qb_y[2] = fy;
@@ -818,7 +962,7 @@ __device__ __forceinline__ void sweep(const Params &p)
         // the state this pass produces, step t_base + k
         auto store_state = [&](int t_base, int k, float2 qq) {
             if constexpr (T::QOUT == Q_PACKED && Q20) {
-                store_state_bits(t_base, k, __float_as_uint(__builtin_fmaf(qq.x, Q20_SCALE, 8.0f)), __float_as_uint(__builtin_fmaf(qq.y, Q20_SCALE, 8.0f)));
+                store_state_bits(t_base, k, __float_as_uint(__builtin_fmaf(qq.x, qf_scale<QB>(), qf_base<QB>())), __float_as_uint(__builtin_fmaf(qq.y, qf_scale<QB>(), qf_base<QB>())));
             } else if constexpr (T::QOUT == Q_PACKED) {
                 if ((k & 1) == 0) {
                     qhold = qq;
@@ -864,12 +1008,12 @@ __device__ __forceinline__ void sweep(const Params &p)
         constexpr bool LAZY = ZSKIP && !ABL_NOLOAD && (TOPLOAD || TOPLOAD_X) && SDP_ZERO_SKIP > 1;
         bool known_zero = false;   // the chunk about to be processed is a zero chunk (found out an iteration ahead): its rows were not fetched
         int zring = 0;             // bit h: half h of the output ring is known to hold +0 everywhere (written by a zero chunk)
+        int tail_st = 0;           // (PIPE) memory instructions this wave issued BEHIND its latest request for state rows: the stores of a pipelined chunk
         auto load_rows = [&](int tn, auto set_tag, bool wanted) {   // state rows of the chunk that starts at step tn -> set S
             if constexpr (TOPLOAD) {
                 const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const char *>(p.qin) + ps_idx * p.st_ps, wanted ? ST_RECORDS : 0u);
 #pragma unroll
-                for (int jj = 0; jj < QROWS; ++jj)
-                    rq2[decltype(set_tag)::value][jj] = __builtin_amdgcn_raw_buffer_load_b128(rs, q_lane, q20_soff(tn + 16 * (jj / 5), jj % 5), AUX_ST_LOAD);
+                for (int jj = 0; jj < QROWS; ++jj) load_row(rs, tn, jj, rq2[decltype(set_tag)::value][jj]);
             } else if constexpr (T::QIN == Q_EXACT) {
                 const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const char *>(p.qin) + ps_idx * p.st2_ps, wanted ? ST_RECORDS : 0u);
 #pragma unroll
@@ -1327,6 +1471,10 @@ __device__ __forceinline__ void sweep(const Params &p)
                     constexpr int sb = decltype(sb_tag)::value;
                     const int tb = t0 + sb * WB;
                     const bool blk_interior = plain_strip && tb >= 63 && tb + WB < m;
+                    if constexpr (T::QOUT == Q_PACKED) {   // dead lines of the skew padding are not stored (q_lane_blk)
+                        q_lane_st = blk_interior ? q_lane : q_lane_blk(tb, 8);
+                        if constexpr (QF_::TAIL_X2) q_lane_st2 = blk_interior ? lane * 8u : q_lane_blk(tb, 16);
+                    }
                     // experiments build, sdp_set_trace: shader-cycle stamps of this block -- [pair / 64][wave][strip round][block][4]
                     auto stamp = [&](int k) {
                         if constexpr (SDP_EXP_BUILD != 0) {
@@ -1547,7 +1695,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                             } else {
                                 // both weights with one packed multiply, their biased fields with one packed fma
                                 const f32x2 w = (f32x2){u, x} * (f32x2){tq, tq};
-                                const f32x2 f = __builtin_elementwise_fma(w, (f32x2){QF_SCALE, QF_SCALE}, (f32x2){QF_BASE, QF_BASE});
+                                const f32x2 f = __builtin_elementwise_fma(w, (f32x2){qf_scale<QB>(), qf_scale<QB>()}, (f32x2){qf_base<QB>(), qf_base<QB>()});
                                 if constexpr (ABL_NOSTORE) { float fx = f[0], fy = f[1]; keep(fx); keep(fy); }
                                 else store_state_bits(tb, j, __float_as_uint(f[0]), __float_as_uint(f[1]));
                             }
@@ -1645,8 +1793,8 @@ __device__ __forceinline__ void sweep(const Params &p)
                                 q_sharpen(qq.x, qq.y, d * rinv);
                                 if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); }
                                 else if constexpr (QX) store_state(tb, j, qq);
-                                else store_state_bits(tb, j, __float_as_uint(__builtin_fmaf(qq.x, QF_SCALE, QF_BASE)),
-                                                      __float_as_uint(__builtin_fmaf(qq.y, QF_SCALE, QF_BASE)));
+                                else store_state_bits(tb, j, __float_as_uint(__builtin_fmaf(qq.x, qf_scale<QB>(), qf_base<QB>())),
+                                                      __float_as_uint(__builtin_fmaf(qq.y, qf_scale<QB>(), qf_base<QB>())));
                             }
                             const float an = ct * ssum;
                             float na = __builtin_amdgcn_frexp_mantf(an);
@@ -1714,6 +1862,46 @@ __device__ __forceinline__ void sweep(const Params &p)
         // conditional flush counted as zero stores -- every chunk then waited until its own, just issued, output stores had
         // been acknowledged by memory before it touched the first record (`s_waitcnt vmcnt(14)` where 30 were in flight:
         // a write round trip per chunk, the 35 us between the backward sweep on cache-served tensors and on real ones).
+        // PIPE (fp32 backward sweep, aligned K = 32 builds: the kernels of the headline shape).  Round 4's chunk was five phases in
+        // a row -- flush the previous chunk's outputs (16 LDS reads, a wait, 16 stores), wait for the boundary values (an LDS
+        // round trip for the progress word, another for the values), request the next rows, 32 steps, publish (9 LDS writes) --
+        // and a wave that has a SIMD to itself hides none of their latencies: of ~6100 cycles per chunk ~2500 were the
+        // recurrence (cycle stamps, profiles/r04_bwd_trace.txt).  Here the chunk is one pipeline:
+        //   * the LDS reads of the previous chunk's flush are issued at the top of the iteration, the progress word and the K
+        //     boundary values right behind them (speculatively: LDS executes a wave's reads in order, so if the progress word
+        //     covers the chunk the values read behind it are the published ones) -- ONE wait for all of it;
+        //   * the flush's 16 stores leave one per two steps INSIDE the step loop, out of registers;
+        //   * the boundary values this strip hands on are written four at a time as soon as their steps are done, and only
+        //     the progress word is left for the end of the chunk.
+        // The wait for the state rows (requested an iteration ago) sits at the top of the iteration and counts the stores a
+        // pipelined chunk issued behind that request (tail_st).
+        constexpr bool PIPE = FLUSH2 && LAZY && SDP_BWD_PIPE;
+        static_assert(!FLUSH2 || T::SIN == 0 || K <= 16, "FLUSH2 writes one float in front of lds_out: there must be no staged input plane before it");
+        // the plain flush in two halves: LDS -> registers, registers -> memory (all 64 x 32 elements are real cells)
+        auto flush_read = [&](int par, bool zero, float2 *vals) {
+            const int thr_l = K - 1 - f2_rl - f2_el;   // (k2 & 7) < thr_l  <=>  sfull < K - 1
+            if (zero) {
+#pragma unroll
+                for (int k2 = 0; k2 < K / 2; ++k2) vals[k2] = make_float2(0.f, 0.f);
+            } else if (par) {
+#pragma unroll
+                for (int k2 = 0; k2 < K / 2; ++k2) {
+                    const int idx = ((k2 & 7) + 32 * (k2 >> 3)) * PO + (k2 & 7) + f2_l + ((k2 & 7) < thr_l ? K : -K);
+                    vals[k2] = *reinterpret_cast<const float2 *>(__builtin_assume_aligned(lds_out + idx, 8));
+                }
+            } else {
+#pragma unroll
+                for (int k2 = 0; k2 < K / 2; ++k2)
+                    vals[k2] = *reinterpret_cast<const float2 *>(__builtin_assume_aligned(lds_out + f2_l + ((k2 & 7) + 32 * (k2 >> 3)) * PO + (k2 & 7), 8));
+            }
+        };
+        auto flush_store1 = [&](int t0, int k2, float2 v, unsigned lane_off) {   // lane_off: f2_g * 4, or OOB = this store is a dummy
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const int c_r = (k2 & 7) + 32 * (k2 >> 3);
+            if constexpr (ABL_NOSTORE) { keep(v.x); keep(v.y); }
+            else __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(v.x), __float_as_uint(v.y)}, rs_out, lane_off,
+                                                       (i0 * ld + t0) * 4 + (c_r * ld - 32 * (k2 >> 3)) * 4, AUX_OUT_STORE);
+        };
         auto flush_out = [&](int t0, int par, bool active, bool zero = false) {   // zero: both halves of the ring are known to hold +0
             if constexpr (T::SOUT > 0) {
                 const int ubase = (i0 * ld + t0) * 4;
@@ -1747,7 +1935,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                             else __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(vals[k2].x), __float_as_uint(vals[k2].y)}, rs_out, (unsigned)(f2_g * 4),
                                                                        ubase + (c_r * ld - 32 * (k2 >> 3)) * 4, AUX_OUT_STORE);
                         }
-                        if constexpr (LAZY) __builtin_amdgcn_s_waitcnt(0x4F70);   // vmcnt(16): everything older than these K / 2 stores
+                        if constexpr (LAZY && !PIPE) __builtin_amdgcn_s_waitcnt(0x4F70);   // vmcnt(16): everything older than these K / 2 stores
                     } else if ((m & 1) == 0) {   // (uniform)
                         float2 vals[K / 2];
 #pragma unroll
@@ -1768,7 +1956,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                             if constexpr (ABL_NOSTORE) { keep(vals[k2].x); keep(vals[k2].y); }
                             else __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(vals[k2].x), __float_as_uint(vals[k2].y)}, rs_out, off, 0, AUX_OUT_STORE);
                         }
-                        if constexpr (LAZY) __builtin_amdgcn_s_waitcnt(0x4F70);   // vmcnt(16)
+                        if constexpr (LAZY && !PIPE) __builtin_amdgcn_s_waitcnt(0x4F70);   // vmcnt(16)
                     } else {   // an odd number of columns (per-pair lengths): a column at a time, indices formed on the spot
 #pragma unroll
                         for (int k = 0; k < K; ++k) {
@@ -1781,7 +1969,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                             if constexpr (ABL_NOSTORE) { unsigned vv = __float_as_uint(v) ^ off; keep(vv); }
                             else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, off, 0, AUX_OUT_STORE);
                         }
-                        if constexpr (LAZY) __builtin_amdgcn_s_waitcnt(0x8F70);   // vmcnt(32)
+                        if constexpr (LAZY && !PIPE) __builtin_amdgcn_s_waitcnt(0x8F70);   // vmcnt(32)
                     }
                 } else {
                     float vals[K];
@@ -1883,6 +2071,29 @@ __device__ __forceinline__ void sweep(const Params &p)
                     // checks on its next call (sdp_api.hip: SDP_E_HANDOFF) -- it does not carry on silently.
                     bool ready = ABL_NOSYNC;
                     const int spin_cap = (SDP_EXP_BUILD && (p.dbg & 8)) ? (1 << 10) : (1 << 21);
+                    if constexpr (PIPE && VEC_BND && K0 == 0 && K1 == K && !ABL_NOSYNC) {
+                        if (!imported && c_lo >= 0 && c_lo + K <= m) {
+                            // ONE LDS round trip: the progress word first, the values right behind it (and both behind the flush's
+                            // reads issued at the top of the iteration).  LDS executes a wave's reads in order, so if the word
+                            // already covers the chunk -- the steady state: the strip below runs a lag ahead -- the values read
+                            // behind it are the published ones; otherwise spin as before and read them again.
+                            int seen = lds_issue_i32(prog + 4 * pword);
+                            const uint4 *src = reinterpret_cast<const uint4 *>(bnd_in + (c_lo - 1));
+                            unsigned w[K + 1];
+#pragma unroll
+                            for (int g = 0; g < K / 4; ++g) {
+                                const uint4 v = src[g];
+                                w[4 * g] = v.x, w[4 * g + 1] = v.y, w[4 * g + 2] = v.z, w[4 * g + 3] = v.w;
+                            }
+                            w[K] = bnd_in[c_lo + K - 1];
+                            lds_wait(seen);
+                            if (__builtin_amdgcn_readfirstlane(seen) >= pbase + need) {
+#pragma unroll
+                                for (int k = 0; k < K; ++k) bcv[k] = w[k + 1];
+                                return;
+                            }
+                        }
+                    }
                     for (int spin = 0; !ABL_NOSYNC && spin < spin_cap; ++spin) {
                         if (__builtin_amdgcn_readfirstlane(lds_load_i32(prog + 4 * pword)) >= pbase + need) {
                             ready = true;
@@ -1932,13 +2143,17 @@ __device__ __forceinline__ void sweep(const Params &p)
             u64 hist[K];  // the edge-facing carry after each step (published below by one lane)
             const int par = c & 1;
             float *lo = lds_out + lane * PO + par * K;  // this lane's row, this chunk's half of the ring
+            bool pub_vals_done = false;   // (PIPE) the pipelined steps have written this chunk's boundary values already
             // ---- publish boundary values for the next strip (one lane), then the progress word ----
             auto publish_range = [&](auto k0_tag, auto k1_tag, int *wf_frames_) {   // values of steps t0 + k, k in [K0, K1)
                 constexpr int K0 = decltype(k0_tag)::value, K1 = decltype(k1_tag)::value;
                 if (!has_succ) return;
                 // fwd: lane 63 produced column t0+k-63 at step k; rev: lane 0 produced column t0+k
                 const int p_lo = REV ? t0 : t0 - 63;
-                if (lane == PUB_LANE) {
+                // (reverse sweeps: a chunk that lies right of the matrix for the publishing lane -- the first one or two of every
+                //  strip -- has no value to hand on, only its progress word; the column-by-column path below took ~3000 cycles
+                //  to find that out, on the strip above's way to its first chunk)
+                if (lane == PUB_LANE && !pub_vals_done && !(REV && p_lo + K0 >= m)) {
                     if constexpr (VEC_BND && K0 == 0 && K1 == K) {
                         if (p_lo + K <= m) {   // (p_lo = t0: a multiple of K slots of four bytes)
                             uint4 *dst = reinterpret_cast<uint4 *>(bnd_out + p_lo);
@@ -2011,7 +2226,13 @@ __device__ __forceinline__ void sweep(const Params &p)
                 }
                 if constexpr (FLUSH2) lo[-1 - par * K] = 0.f;   // (shared by both halves)
             };
-            if constexpr (LAZY) {
+            if constexpr (PIPE) {
+                // the iteration's one wait for memory: this chunk's rows (requested an iteration ago) and whatever is older.  A
+                // pipelined chunk issued its 16 output stores BEHIND that request (vmcnt retires in order); every other kind of
+                // iteration requested the rows last
+                if (tail_st) __builtin_amdgcn_s_waitcnt(0x4F70);   // vmcnt(16)
+                else __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0)
+            } else if constexpr (LAZY) {
                 // (the fp32 backward sweep waits inside its flush and requests rows further down: see there)
             } else {
             // Everything this wave has in flight is a whole iteration old: the rows loaded at the top of the previous iteration (the
@@ -2042,14 +2263,35 @@ __device__ __forceinline__ void sweep(const Params &p)
                 }
             }
             }
+            float2 fv[PIPE ? K / 2 : 1];   // (PIPE) the previous chunk's outputs, out of LDS and on their way to memory
+            bool fl_defer = false;         // (PIPE) ... their stores have not been issued yet
             if constexpr (T::SOUT > 0) {
-                flush_out(pf_t0, pf_par, ci > 0, ZSKIP && zring == 3);
+                if constexpr (PIPE) {
+                    fl_defer = ci > 0 && rows == 64 && pf_t0 >= K && pf_t0 + K <= m && SDP_FLUSH_FAST;   // the plain flush: every element a real cell
+                    if (fl_defer) flush_read(pf_par, ZSKIP && zring == 3, fv);
+                    else {
+                        flush_out(pf_t0, pf_par, ci > 0, ZSKIP && zring == 3);
+#pragma unroll
+                        for (int k2 = 0; k2 < K / 2; ++k2) fv[k2] = make_float2(0.f, 0.f);
+                    }
+                } else {
+                    flush_out(pf_t0, pf_par, ci > 0, ZSKIP && zring == 3);
+                }
                 stamp_rev(1);
                 if (ci >= nchunks) {
+                    if constexpr (PIPE) {
+                        if (fl_defer) {
+#pragma unroll
+                            for (int k2 = 0; k2 < K / 2; ++k2) flush_store1(pf_t0, k2, fv[k2], (unsigned)(f2_g * 4));
+                        }
+                        tail_st = 0;
+                    }
                     pf_t0 = -K, pf_par = 1;
                     return;
                 }
             }
+            const bool pipe_interior = PIPE && chunk_interior(c);   // this chunk's steps will run in the pipelined body
+            bool pipe_now = false;                                    // ... and carry the previous chunk's stores
             if constexpr (LAZY) {
                 // The flush above ended with a wait for everything older than its own stores (flush_out, LAZY): this chunk's rows,
                 // requested an iteration ago, and that iteration's outputs -- free, and said with the builtin the compiler's
@@ -2067,6 +2309,14 @@ __device__ __forceinline__ void sweep(const Params &p)
                 }
                 stamp_rev(2);
                 const bool next_zero = zero_chunk && more && boundary_zero(t0_next, false);
+                if constexpr (PIPE) {
+                    pipe_now = fl_defer && !zero_chunk && pipe_interior;
+                    if (fl_defer && !pipe_now) {   // no pipelined steps to carry them: the stores leave here, in front of the request for rows
+#pragma unroll
+                        for (int k2 = 0; k2 < K / 2; ++k2) flush_store1(pf_t0, k2, fv[k2], (unsigned)(f2_g * 4));
+                    }
+                    tail_st = (!zero_chunk && pipe_interior) ? K / 2 : 0;   // (a pipelined body issues its 16 stores whether or not they are dummies)
+                }
                 load_rows(t0_next, nxt_t{}, more && !next_zero);
                 known_zero = next_zero;
                 if (zero_chunk) {
@@ -2137,6 +2387,21 @@ __device__ __forceinline__ void sweep(const Params &p)
             float ctv[K], cav[K];
             int ktv[K], kav[K];
             const bool interior = chunk_interior(c);
+            // The fp32 backward sweep needs no masks in the RAMPS of a full strip either (round 5; the masked body costs ~20
+            // instead of ~14 instructions per step, and a strip's first three chunks -- all ramp -- are what the strip above
+            // waits for before it can start: three such lags are a quarter of the launch at 256 x 512^2):
+            //   * right of the matrix (col >= m, the start of the sweep) a cell receives only from cells further right or below,
+            //     all outside as well, and from boundary values that `acquire` hands over as +0 for columns outside: with the
+            //     strip's carries starting at +0 it computes e = 0 + 0 and hands on q * 0 = +0 (the packed weights of cells
+            //     outside the matrix are finite numbers) -- exactly what the mask would have put there;
+            //   * left of the matrix (col < 0, the end of the sweep) a cell computes garbage, but hands it only to cells that are
+            //     further left, never to one inside; its output is not stored (every flush that can meet such a column tests
+            //     it), its boundary values are not published (columns >= 0 only), and the strip's carries die with the strip.
+            // Not for: the chunk that holds the terminal cell (its cotangent is injected under the mask), partial strips (rows
+            // below the matrix do hand upwards), Smith-Waterman's border row and column, float2 states (records of cells outside
+            // may hold NaN).
+            const bool mask_free = interior || (SDP_BWD_MASKFREE && REV && PASS == PASS_BWD && KIND == CK_F32 && T::QIN == Q_PACKED && rows == 64 && !sw &&
+                                                !(s == nstrips - 1 && m - 1 + 63 >= t0 && m - 1 + 63 < t0 + K));
             auto prepass = [&]() {
                 if constexpr (PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_PREPASS) {
 #pragma unroll
@@ -2162,8 +2427,10 @@ __device__ __forceinline__ void sweep(const Params &p)
 
 
             // ---- K steps; EDGE=false is the mask-free body for chunks fully inside the matrix ----
-            auto steps = [&](auto edge_tag, auto kk0_tag, auto kk1_tag) {   // steps kk in [KK0, KK1) of the chunk, in processing order
+            const unsigned pipe_off = pipe_now ? (unsigned)(f2_g * 4) : OOB;   // (PIPE) per-lane offset of the stores the steps carry (OOB: dummies)
+            auto steps = [&](auto edge_tag, auto kk0_tag, auto kk1_tag, auto pipe_tag) {   // steps kk in [KK0, KK1) of the chunk, in processing order
                 constexpr bool EDGE = decltype(edge_tag)::value;
+                constexpr bool PIPED = decltype(pipe_tag)::value;   // the previous chunk's stores and this chunk's boundary values ride along
                 constexpr int KK0 = decltype(kk0_tag)::value, KK1 = decltype(kk1_tag)::value;
 #pragma unroll
                 for (int kk = KK0; kk < KK1; ++kk) {
@@ -2180,14 +2447,18 @@ __device__ __forceinline__ void sweep(const Params &p)
                         if constexpr (!ABL_NOLOAD && !TOPLOAD_X) rqx2[P][k] = load_f2(rs_qx, t0_next, k);
                     }
                     if constexpr (T::QIN == Q_PACKED) {
-                        if constexpr (Q20) {
+                        if constexpr (QB == 18) {
+                            unsigned w9[9];
+                            q20_record(k >> 3, w9, cur_t{});
+                            q0 = q18_unpack(w9, k & 7);
+                        } else if constexpr (Q20) {
                             unsigned w5[5];
                             q20_record(k >> 2, w5, cur_t{});
                             q0 = q20_unpack(w5, k & 3);
                         } else {
                             q0 = q_unpack(rq + 3 * (k >> 1), k & 1);
                         }
-                        q0.x *= QF_UNSCALE, q0.y *= QF_UNSCALE;
+                        q0.x *= qf_unscale<QB>(), q0.y *= qf_unscale<QB>();
                         if constexpr (!ABL_NOLOAD) {   // the record's last step in processing order has been consumed: refill it
                             if (!Q20 && (k & (QREC_STEPS - 1)) == (REV ? 0 : QREC_STEPS - 1)) {
                                 // (the refill must stay BEHIND the last use of what it overwrites: hoisted above it by the
@@ -2330,6 +2601,28 @@ __device__ __forceinline__ void sweep(const Params &p)
                         cy.fc = qm * e;
                         lo[k] = e;
                         hist[k] = (u64)__float_as_uint(cy.fa);
+                        if constexpr (PIPED) {
+                            // one of the previous chunk's 16 output stores per two steps ...
+                            if constexpr (SDP_PIPE_ST == 1) {
+                                if (kk < K / 2) flush_store1(pf_t0, kk, fv[kk], pipe_off);
+                            } else {
+                                if (kk & 1) flush_store1(pf_t0, kk >> 1, fv[kk >> 1], pipe_off);
+                            }
+                            // ... and the four boundary values of steps k .. k + 3 as soon as the lowest of them is done (an interior
+                            // chunk: t0 + K <= m, so the K four-byte slots from t0 on are K / 4 aligned 16-byte writes)
+                            if constexpr (SDP_PIPE_PUB == 1) {
+                                if ((k & 3) == 0 && has_succ && lane == PUB_LANE)
+                                    reinterpret_cast<uint4 *>(bnd_out + t0)[k >> 2] =
+                                        make_uint4((unsigned)hist[k], (unsigned)hist[k + 1], (unsigned)hist[k + 2], (unsigned)hist[k + 3]);
+                            } else if constexpr (SDP_PIPE_PUB == 2) {
+                                if ((k & 15) == 0 && has_succ && lane == PUB_LANE) {
+#pragma unroll
+                                    for (int g = 0; g < 4; ++g)
+                                        reinterpret_cast<uint4 *>(bnd_out + t0)[(k >> 2) + g] =
+                                            make_uint4((unsigned)hist[k + 4 * g], (unsigned)hist[k + 4 * g + 1], (unsigned)hist[k + 4 * g + 2], (unsigned)hist[k + 4 * g + 3]);
+                                }
+                            }
+                        }
                     } else if constexpr (PASS == PASS_BWD) {
                         const double in = dpp_f64<DPP_IN>(__longlong_as_double((long long)bcv[k]), cy.a);
                         const bool live = inside && rowok && !dead;
@@ -2525,8 +2818,14 @@ __device__ __forceinline__ void sweep(const Params &p)
 #pragma unroll
                 for (int sb = 0; sb < K / WB; ++sb) wf_frames[sb] = FRAME_NONE;
                 prepass();
-                if (interior) steps(std::false_type{}, kc0{}, kc1{});
-                else steps(std::true_type{}, kc0{}, kc1{});
+                if constexpr (PIPE) {
+                    if (interior) steps(std::false_type{}, kc0{}, kc1{}, std::true_type{}), pub_vals_done = SDP_PIPE_PUB != 0;
+                    else if (mask_free) steps(std::false_type{}, kc0{}, kc1{}, std::false_type{});
+                    else steps(std::true_type{}, kc0{}, kc1{}, std::false_type{});
+                } else {
+                    if (mask_free) steps(std::false_type{}, kc0{}, kc1{}, std::false_type{});
+                    else steps(std::true_type{}, kc0{}, kc1{}, std::false_type{});
+                }
             }
 
             // The normalised form publishes its values in one frame per block as well whenever they fit (exact
@@ -2558,12 +2857,12 @@ __device__ __forceinline__ void sweep(const Params &p)
 
             if constexpr (HALF) {
                 // upper half of the chunk (steps t0 + 31 .. t0 + 16), hand it down, lower half, hand it down
-                if (interior) steps(std::false_type{}, kc0{}, kch{});
-                else steps(std::true_type{}, kc0{}, kch{});
+                if (interior) steps(std::false_type{}, kc0{}, kch{}, std::false_type{});
+                else steps(std::true_type{}, kc0{}, kch{}, std::false_type{});
                 publish_range(kch{}, kc1{}, nullptr);
                 acquire(kc0{}, kch{});
-                if (interior) steps(std::false_type{}, kch{}, kc1{});
-                else steps(std::true_type{}, kch{}, kc1{});
+                if (interior) steps(std::false_type{}, kch{}, kc1{}, std::false_type{});
+                else steps(std::true_type{}, kch{}, kc1{}, std::false_type{});
                 publish_range(kc0{}, kch{}, nullptr);
             } else {
                 stamp_rev(3);
@@ -2613,6 +2912,22 @@ __device__ __forceinline__ void sweep(const Params &p)
         sdp::sweep<PASS, K, ##__VA_ARGS__>(p);                                             \
     }
 
+// (-DSDP_ONLY=<n>: compile ONE kernel, for ISA inspection with `hipcc -S --cuda-device-only` -- tools/isa.sh; never linked)
+#if defined(SDP_ONLY) && SDP_ONLY == 1
+SDP_KERNEL(sdp_bwd_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD)
+#elif defined(SDP_ONLY) && SDP_ONLY == 0
+SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LINES != 0)
+#elif defined(SDP_ONLY) && SDP_ONLY == 18
+SDP_KERNEL(sdp_fwd18_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LINES != 0, false, false, 18)
+#elif defined(SDP_ONLY) && SDP_ONLY == 19
+SDP_KERNEL(sdp_bwd18_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, false, false, false, false, 18)
+#elif defined(SDP_ONLY) && SDP_ONLY == 7
+SDP_KERNEL(sdp_bwd_x_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, true)
+#elif defined(SDP_ONLY) && SDP_ONLY == 3
+SDP_KERNEL(sdp_adj_bwd_kernel, sdp::PASS_ABWD, SDP_K_ABWD, SDP_MAXW_ABWD)
+#elif defined(SDP_ONLY) && SDP_ONLY == 2
+SDP_KERNEL(sdp_adj_fwd_kernel, sdp::PASS_AFWD, SDP_K_AFWD, SDP_MAXW_AFWD)
+#else
 SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LINES != 0)
 SDP_KERNEL(sdp_fwd_lat_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT)
 SDP_KERNEL(sdp_fwd_x_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, true)
@@ -2641,6 +2956,16 @@ SDP_KERNEL(sdp_bwd_lat_g_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT,
 SDP_KERNEL(sdp_bwd_x_g_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, true, false, true)
 SDP_KERNEL(sdp_bwd_x_lat_g_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, true, false, true)
 SDP_KERNEL(sdp_adj_bwd_g_kernel, sdp::PASS_ABWD, SDP_K_ABWD, SDP_MAXW_ABWD, false, false, true)
+// 18-bit packed state (N + M <= 1024, no per-pair lengths: sdp_kernels.h packed_bits): the forward / backward builds that serve it
+SDP_KERNEL(sdp_fwd18_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LINES != 0, false, false, 18)
+SDP_KERNEL(sdp_fwd18_lat_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, false, false, false, false, 18)
+SDP_KERNEL(sdp_fwd18_g_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LINES != 0, true, false, 18)
+SDP_KERNEL(sdp_bwd18_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, false, false, false, false, 18)
+SDP_KERNEL(sdp_bwd18_lat_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, false, false, false, false, 18)
+SDP_KERNEL(sdp_bwd18_g_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, false, false, true, false, 18)
+SDP_KERNEL(sdp_bwd18_lat_g_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, false, false, true, false, 18)
+
+#endif
 
 // ----------------------------------------------------------------------------------
 // launch order for variable-length batches: order[r] = the pair with the r-th largest n*m (ties: lower index first).

@@ -95,7 +95,16 @@ def test_fused_decode_loss_equals_the_unfused_path(name, use_lengths):
     l2, E = decode_loss(dec, loss_fn, t2, a2, first, xl, yl, G, lengths=ln)
     l2.backward()
     torch.cuda.synchronize()
-    assert torch.equal(E, aln.detach())
+    if use_lengths:
+        # decode_loss leaves E outside the pairs' blocks unwritten by default (SDP_NO_FILL: nothing in the op reads it); inside
+        # the blocks it is the decoder's E bit for bit, and fill=True gives the whole tensor
+        for b in range(B):
+            assert torch.equal(E[b, :xl[b], :yl[b]], aln.detach()[b, :xl[b], :yl[b]]), b
+        t3 = torch.from_numpy(theta).to(dev).requires_grad_()
+        l3, E3 = decode_loss(dec, loss_fn, t3, torch.from_numpy(A).to(dev), first, xl, yl, G, lengths=ln, fill=True)
+        assert torch.equal(E3, aln.detach()) and float(l3) == float(l2)
+    else:
+        assert torch.equal(E, aln.detach())
     assert abs(float(l1) - float(l2)) <= 1e-6 * max(1.0, abs(float(l1)))
     g1, g2 = t1.grad, t2.grad
     assert float((g1 - g2).abs().max()) <= 1e-6 * max(1.0, float(g1.abs().max())), float((g1 - g2).abs().max())

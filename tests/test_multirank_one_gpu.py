@@ -163,7 +163,8 @@ def test_bench_eight_ranks_flow_on_one_gpu():
     """`bench.py --gpus 8` exactly as the driver launches it (torch.distributed.run, 8 ranks, default shape = 256 pairs of
     512 x 512 per rank = BASELINE configs[4]) -- except that the ranks share GPU 0 and gather over gloo: exactly one JSON
     line, n_gpus 8, global batch 2048, the secondary gather figures present."""
-    r = _run_bench(8, ["--steps", "2", "--warmup", "1"], {}, timeout=1500)
+    # (--e-chunks 4: the E gather in pieces under the backward sweep is exercised here; the default is one collective since round 5)
+    r = _run_bench(8, ["--steps", "2", "--warmup", "1", "--e-chunks", "4"], {}, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout

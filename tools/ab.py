@@ -13,9 +13,9 @@ W = W[0] if W else 0
 passes = "fba" if "adj" in sys.argv else "fb"  # adj: also the exact-state forward and the adjoint pair
 for (B, N, M) in shapes:
     res = {k: [] for k in L}
-    for rep in range(3):
+    for rep in range(int(os.environ.get('REPS', '3'))):
         for k, l in L.items():
             res[k].append(gpu_tune.run(l, B, N, M, (W, W, 0, 0), passes))
     for k in L:
         keys = res[k][0].keys()
-        print(f"B={B} {N}x{M} W={W or 'auto'} {k:18s} " + " ".join(f"{kk}={np.median([r[kk] for r in res[k]]):.1f}" for kk in keys), flush=True)
+        print(f"B={B} {N}x{M} W={W or 'auto'} {k:18s} " + " ".join(f"{kk}={np.median([r[kk] for r in res[k]]):.1f}" for kk in keys) + (f"  [fwd;bwd mean {np.mean([r['fwd;bwd'] for r in res[k]]):.1f} sd {np.std([r['fwd;bwd'] for r in res[k]]):.1f}]" if len(res[k]) > 3 else ""), flush=True)

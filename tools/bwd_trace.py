@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
 import gpu_tune
-lib = gpu_tune.load(os.path.join(ROOT, "deepblast_amd", "libsdp_hip_exp.so"))
+lib = gpu_tune.load(os.environ.get("SDP_TRACE_LIB") or os.path.join(ROOT, "deepblast_amd", "libsdp_hip_exp.so"))   # (SDP_TRACE_LIB: another -DSDP_EXPERIMENTS build)
 lib.sdp_set_trace.restype, lib.sdp_set_trace.argtypes = ctypes.c_int, [ctypes.c_void_p]
 B, N, M = 256, 512, 512
 alias = int(sys.argv[1]) if len(sys.argv) > 1 else 0
@@ -30,9 +30,13 @@ for pair in ((0,) if B < 129 else (0, 2)):
             if nb < 6:
                 continue
             x = x[:nb]
+            if x[-1, 4] == 0:   # the extra iteration that only flushes the last chunk's outputs
+                x, nb = x[:-1], nb - 1
             flush, acq, steps, pub = x[:, 1] - x[:, 0], x[:, 2] - x[:, 1], x[:, 3] - x[:, 2], x[:, 4] - x[:, 3]
             total = x[1:, 0] - x[:-1, 0]
             mid = slice(3, nb - 3)
+            if os.environ.get("TRACE_TIMELINE"):   # absolute times: when every chunk of the strip began, and when its last one was published
+                print(f"    wave {w} round {rd} chunk starts: " + " ".join(str(int(u - t0)) for u in x[:, 0]) + f" | end {int(x[-1, 4] - t0)}")
             if os.environ.get("TRACE_BLOCKS"):
                 for name, v in (("flush", flush), ("acq", acq), ("steps", steps), ("pub", pub), ("total", total)):
                     print(f"    wave {w} round {rd} per chunk: {name:6s}" + " ".join(str(int(u)) for u in v))

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
 import gpu_tune
-lib = gpu_tune.load(os.path.join(ROOT, "deepblast_amd", "libsdp_hip_exp.so"))
+lib = gpu_tune.load(os.environ.get("SDP_TRACE_LIB") or os.path.join(ROOT, "deepblast_amd", "libsdp_hip_exp.so"))
 lib.sdp_set_trace.restype, lib.sdp_set_trace.argtypes = ctypes.c_int, [ctypes.c_void_p]
 B, N, M = 256, 512, 512
 alias = int(sys.argv[1]) if len(sys.argv) > 1 else 0
@@ -40,6 +40,8 @@ for pair in ((0,) if B < 129 else (0, 2)):
                       f"write_block end -> next load_block start {(x[8:nb - 2:2, 4] - x[7:nb - 3:2, 5]).mean():.0f}  load_block end -> block start {(ev[:, 0] - ev[:, 5]).mean():.0f}")
             if False:
                 print(f"     odd blocks: start->check {(odd[:, 4] - odd[:, 0]).mean():.0f}  write_block {(odd[:, 5] - odd[:, 4]).mean():.0f}  load_block {(odd[:, 6] - odd[:, 5]).mean():.0f}  prefetch issue {(odd[:, 7] - odd[:, 6]).mean():.0f}  ->compute {(odd[:, 1] - odd[:, 7]).mean():.0f};  even blocks wait {(x[6:nb - 2:2, 1] - x[6:nb - 2:2, 0]).mean():.0f}")
+            if os.environ.get("TRACE_TIMELINE"):
+                print(f"    wave {w} round {rd} block starts: " + " ".join(str(int(u - t0)) for u in x[:, 0]) + f" | end {int(x[-1, 3] - t0)}")
             if os.environ.get("TRACE_BLOCKS"):
                 print(f"    wave {w} round {rd} per block: wait " + " ".join(str(int(v)) for v in wait))
                 print(f"    wave {w} round {rd} per block: comp " + " ".join(str(int(v)) for v in comp))

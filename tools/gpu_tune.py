@@ -73,6 +73,16 @@ def run(lib, B, N, M, waves=(0, 0, 0, 0), passes="fb"):
     out["fwd"] = timeit(f)
     out["bwd"] = timeit(b)
     out["fwd;bwd"] = timeit(lambda: (f(), b()))
+    # the two sweeps INSIDE the back-to-back sequence (events between them): the backward sweep behind a forward sweep is not the
+    # backward sweep re-run on a state that has been lying in memory (what "bwd" above times)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(8)]
+    f(); b()
+    torch.cuda.synchronize()
+    for e0, e1, e2 in evs:
+        e0.record(); f(); e1.record(); b(); e2.record()
+    torch.cuda.synchronize()
+    out["seq_f"] = float(np.median([e0.elapsed_time(e1) for e0, e1, _ in evs])) * 1e3
+    out["seq_b"] = float(np.median([e1.elapsed_time(e2) for _, e1, e2 in evs])) * 1e3
     if "a" in passes:
         stx = torch.empty(dbytes // 4, device="cuda")  # exact state for the adjoint sweeps
         if hasattr(lib, "sdp_state_d_bytes"):
