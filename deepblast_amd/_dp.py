@@ -200,6 +200,9 @@ class _Decoder(nn.Module):
         False = those cells are NOT written and hold whatever the allocator handed out (include/sdp.h: SDP_NO_FILL) --
         for callers that mask by the same lengths (a loss that slices [:x_len, :y_len], `traceback_batch(E, lengths)`):
         the zero fill of a padded batch moves as many bytes as the sweep itself."""
+        tr = self._transposed(theta, A, lengths)
+        if tr is not None:
+            theta, A, lengths = tr
         if self.arithmetic == "reference":
             return self._function.apply(theta, A, self.operator, lengths, _engine.REF)
         if lengths is None:
@@ -208,7 +211,28 @@ class _Decoder(nn.Module):
             return self._function.apply(theta, A, self.operator, lengths, False, True)
         return self._function.apply(theta, A, self.operator, lengths)
 
+    @staticmethod
+    def _transposed(theta, A, lengths):
+        """More columns than the sweeps take (the boundary rows of a strip live in LDS: sdp_max_cols() = 2048, the limit of the
+        reference's GPU classes, nw_cuda.py:11) but not more rows: the recurrence is symmetric in its two axes -- V[i,j] =
+        theta[i,j] + lse(A[i,j] + V[i-1,j], V[i-1,j-1], A[i,j] + V[i,j-1]), one gap score for both directions (nw.py:46-62) --
+        so the problem is swept on the TRANSPOSED tensors (N has no limit) and autograd transposes every gradient back: E, the
+        pass-through A, the second-order results.  The parity oracle nw.py has no column limit.  -> (theta^T, A^T, lengths
+        with their columns swapped), or None when no transposition is needed (or would not help: both sides too long)."""
+        if theta.dim() != 3 or A.shape != theta.shape:
+            return None
+        cap = _engine.get_engine().max_cols()
+        if theta.shape[2] <= cap or theta.shape[1] > cap:
+            return None
+        if lengths is not None:
+            lengths = torch.as_tensor(lengths)
+            lengths = torch.stack([lengths[:, 1], lengths[:, 0]], dim=1)
+        return theta.transpose(1, 2), A.transpose(1, 2), lengths
+
     def _forward_for_decode(self, theta, A, lengths, fill=True):
+        tr = self._transposed(theta, A, lengths)
+        if tr is not None:
+            theta, A, lengths = tr
         # decode() is differentiated again by its callers (training: loss on the alignment matrix): save the
         # state in the exact form all four sweeps can share
         xs = _engine.REF if self.arithmetic == "reference" else True

@@ -147,3 +147,31 @@ def test_public_surface():
     assert deepblast_amd.NeedlemanWunschFunction.__name__ == "NeedlemanWunschFunction"
     dec = NeedlemanWunschDecoder("softmax")
     assert dec.operator == "softmax" and isinstance(dec, torch.nn.Module)
+
+
+def test_wide_problems_are_swept_transposed(fake):
+    """More columns than sdp_max_cols(): the decoder sweeps the transposed problem (the recurrence is symmetric in its axes)
+    and autograd transposes the results back -- here through the oracle-backed engine: values and quirks as for any shape."""
+    from oracle import oracle
+    B, N, M = 2, 5, 2100
+    rng = np.random.default_rng(5)
+    theta = rng.random((B, N, M), dtype=np.float32)
+    A = -rng.random((B, N, M), dtype=np.float32)
+    Z = rng.standard_normal((B, N, M)).astype(np.float32)
+    for name, variant in (("nw", 0), ("sw", 1)):
+        dec = DEC[name]("softmax")
+        t = torch.from_numpy(theta).requires_grad_()
+        a = torch.from_numpy(A).requires_grad_()
+        aln = dec.decode(t, a)
+        assert aln.shape == (B, N, M)
+        (aln * torch.from_numpy(Z)).sum().backward()
+        Vt, E, Q, Ef = oracle.fwd_bwd(theta, A, None, variant)
+        Ed, _, _ = oracle.double_backward(Q, Ef, Z)
+        assert np.abs(aln.detach().numpy() - E).max() <= 1e-6 and np.abs(t.grad.numpy() - Ed).max() <= 1e-5 * max(1.0, np.abs(Ed).max())
+        assert a.grad is None
+        t2 = torch.from_numpy(theta).requires_grad_()
+        a2 = torch.from_numpy(A).requires_grad_()
+        v = dec(t2, a2)
+        assert np.abs(v.detach().numpy() - Vt).max() <= 1e-4
+        v.sum().backward()
+        assert np.abs(t2.grad.numpy() - E).max() <= 1e-6 and torch.equal(a2.grad, a2.detach())

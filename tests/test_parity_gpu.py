@@ -615,6 +615,47 @@ def test_max_cols_is_enforced():
         eng.forward(t, t, 0)
 
 
+@pytest.mark.parametrize("variant", [0, 1], ids=["nw", "sw"])
+def test_more_columns_than_the_sweeps_take_run_transposed(variant):
+    """the parity oracle nw.py has no column limit; the engine's sweeps stop at sdp_max_cols() = 2048 (the
+    limit of the reference's GPU classes).  The decoders sweep such a problem on the transposed tensors (the recurrence is
+    symmetric in its axes): 300 x 4096 against the oracle, first and second order, the reference's gradient quirks intact."""
+    import torch
+    from deepblast_amd import NeedlemanWunschDecoder, SmithWatermanDecoder
+    B, N, M = 2, 300, 4096
+    theta, A = datagen.theta_A(4096 + variant, B, N, M)
+    Z = datagen.normal(4100, (B, N, M))
+    dec = (NeedlemanWunschDecoder, SmithWatermanDecoder)[variant]("softmax")
+    t = torch.from_numpy(theta).cuda().requires_grad_()
+    a = torch.from_numpy(A).cuda().requires_grad_()
+    with torch.no_grad():
+        vt = dec(t, a)
+    aln = dec.decode(t, a)
+    assert aln.shape == (B, N, M)
+    (aln * torch.from_numpy(Z).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    ref = parity.oracle_all(theta, A, None, Z, variant, omp=True)
+    errs = parity.compare({"Vt": vt.cpu().numpy(), "E": aln.detach().cpu().numpy(), "Ed": t.grad.cpu().numpy(), "Vtd": ref["Vtd"]}, ref)
+    _assert(errs, f"transposed sweep {N}x{M} variant={variant}")
+    assert a.grad is None      # second order: no gradient for A (nw.py:386)
+    # first order through forward(): E in theta.grad, the pass-through "gradient" A in A.grad (nw.py:337-339,355)
+    t2 = torch.from_numpy(theta).cuda().requires_grad_()
+    a2 = torch.from_numpy(A).cuda().requires_grad_()
+    dec(t2, a2).sum().backward()
+    assert parity.abs_err(t2.grad.cpu().numpy(), ref["E"]) <= parity.TOL and torch.equal(a2.grad, a2.detach())
+    # per-pair lengths ride along (their columns swapped)
+    lens = np.array([[300, 4096], [123, 3000]], np.int32)
+    refl = parity.oracle_lens(theta, A, None, None, variant, lens)
+    t3 = torch.from_numpy(theta).cuda().requires_grad_()
+    v3 = dec(t3, torch.from_numpy(A).cuda(), torch.from_numpy(lens).cuda())
+    v3.sum().backward()
+    assert parity.rel_err(v3.detach().cpu().numpy(), refl["Vt"]) <= parity.TOL and parity.abs_err(t3.grad.cpu().numpy(), refl["E"]) <= parity.TOL
+    # both sides beyond the limit: still refused
+    big = torch.zeros(1, 2049, 2049, device="cuda")
+    with pytest.raises(ValueError):
+        dec(big, big)
+
+
 def test_fuzz_many_pairs_small_odd_shapes():
     """The corner the line-aligned staging of round 2 first got wrong (found by tools/fuzz2.py, not by the suite): full
     batches (>= 128 pairs: throughput builds) of small matrices whose planes start at arbitrary float offsets (N*M odd),

@@ -25,9 +25,9 @@ def timeit(fn, n=10):
     return s.elapsed_time(e) / n
 
 
-def step(dec, theta, A, lens=None):
+def step(dec, theta, A, lens=None, fill=True):
     t = theta.detach().requires_grad_(True)
-    v = dec(t, A, lens) if lens is not None else dec(t, A)
+    v = (dec(t, A, lens) if fill else dec(t, A, lens, fill=False)) if lens is not None else dec(t, A)
     v.sum().backward()
 
 
@@ -51,6 +51,19 @@ def main():
           f"  ({2 * work / ms * 1e3:.3e} counting true lengths)")
     ms = timeit(lambda: step(dec, th, A, ln), 5)
     print(f"configs[2] lengths-aware: {ms:.3f} ms/step  {2 * work / ms * 1e3:.3e} true cell-updates/s (sum n_b*m_b = {work})")
+    # what a consumer that masks by the same lengths runs (decode_loss, traceback_batch(E, lengths), gather="paths"): E outside
+    # the pairs' blocks is not zero-filled (include/sdp.h: SDP_NO_FILL; dec(theta, A, lengths, fill=False))
+    ms = timeit(lambda: step(dec, th, A, ln, fill=False), 5)
+    print(f"configs[2] lengths-aware, no zero fill outside the blocks (SDP_NO_FILL): {ms:.3f} ms/step  {2 * work / ms * 1e3:.3e} true cell-updates/s")
+    from deepblast_amd._engine import get_engine
+    eng = get_engine()
+    Vt, Q = eng.forward(th, A, 0, ln)
+    et = torch.ones(B, device="cuda")
+    for nf in (False, True):
+        ms = timeit(lambda: eng.backward(et, Q, (B, N, M), 0, ln, no_fill=nf), 5)
+        print(f"   backward sweep alone, lengths-aware, no_fill={nf}: {ms * 1e3:.1f} us")
+    ms = timeit(lambda: eng.forward(th, A, 0, ln), 5)
+    print(f"   forward sweep alone, lengths-aware: {ms * 1e3:.1f} us")
 
 
 if __name__ == "__main__":
