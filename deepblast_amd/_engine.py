@@ -278,7 +278,8 @@ class HipEngine:
         Ed = torch.empty((B, N, M), dtype=torch.float32, device=state.device)
         with torch.cuda.device(dev), self._bracket("sdp_adj_bwd_kernel"):
             rc = self.lib.sdp_adjoint_backward_f32(_ptr(E), _ptr(state), _ptr(state_d), _ptr(Ed), B, N, M,
-                                                   _ptr(lens), self._v(3, variant) | (REF_ROUNDING if ref else 0), dev, self._stream(dev))
+                                                   _ptr(lens), self._v(3, variant) | (REF_ROUNDING if ref else 0) | (0 if self.zero_skip else _lib.SDP_NO_ZERO_SKIP),
+                                                   dev, self._stream(dev))
         _lib.check(rc, "sdp_adjoint_backward_f32")
         return Ed
 

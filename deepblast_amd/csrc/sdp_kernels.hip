@@ -147,6 +147,9 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #ifndef SDP_BWD_MASKFREE
 #define SDP_BWD_MASKFREE 1  // fp32 backward sweep: the ramps of a full strip run the mask-free step body too (see bwd_mask_free)
 #endif
+#ifndef SDP_ZERO_SKIP_ADJ
+#define SDP_ZERO_SKIP_ADJ 1  // adjoint backward sweep: chunks over which E, the carries and the boundary values are all zero are not run, nor their Q / Qd rows read (see ZSKIP_A)
+#endif
 #ifndef SDP_DEAD_LINES
 #define SDP_DEAD_LINES 0  // (0: off -- built, bit-identical, measured in round 5 and NOT adopted: forward alone 193 -> 185 us, but the forward;backward sequence 312 +- 4 us either way and the backward sweep 124 -> 128 us when it masks its loads; 1: the forward sweep does not write them; 2: the backward sweep does not read them either)  // packed state: 128-byte lines of the skew padding whose eight lanes are all outside the matrix for a whole 16-step block are neither written nor read
 #endif
@@ -985,7 +988,17 @@ __device__ __forceinline__ void sweep(const Params &p)
         cy.xe = cy.de = EXP_ONE_E;
         u64 vt_keep = edge_zero<KIND>();  // fwd passes: terminal cell's value, captured when this lane reaches it
 
-        float rs[NS][K];   // staged inputs of the NEXT chunk (registers)
+        // Exact zeros in the ADJOINT backward sweep (round 5, ZSKIP_A).  Where E is exactly zero -- 47 % of its cells on the
+        // benchmark's scores, see ZSKIP -- the adjoint backward recurrence ed = in + b, (a, b, c) = (dx e + qx ed + c', dy e + qy ed,
+        // dm e + qm ed) with e = E = 0 computes nothing but zeros as long as what reaches the chunk is zero: Ed = 0 there.  Such a
+        // chunk is not run, and its Q and Qd rows (16 of the sweep's 28 bytes per cell) are not read.  Whether E is zero over a
+        // chunk must be known BEFORE that chunk's rows are requested, a chunk ahead: the staged E blocks therefore travel two
+        // chunks ahead of the sweep instead of one (two register sets; an arriving block set is tested with one ballot), and a
+        // chunk's E is zero if the two block sets that cover it are.  Zeros with a sign: a computed zero chunk leaves +0 in
+        // a and b but may leave -0 in c (qm < 0 by a rounding, times +0); the skipped one leaves +0.  The difference can only
+        // ever surface as the SIGN of a zero in Ed, so Ed is stored as (float)ed + 0.0f in both paths: bit-identical results.
+        constexpr bool ZSKIP_A = PASS == PASS_ABWD && KIND == CK_F64 && SDP_ZERO_SKIP_ADJ && !ABL_NOMATH && !ABL_NOLOAD && SDP_TOPLOAD != 0;
+        float rs[ZSKIP_A ? 2 : 1][NS][K];   // staged inputs of the NEXT chunk (registers); ZSKIP_A: of the next two chunks
         constexpr int QREC_STEPS = Q20 ? 4 : 2, QREC_DW = Q20 ? 5 : 3;   // steps and dwords of one packed record
         unsigned rq[Q20 ? 1 : QREC_DW * K / QREC_STEPS];  // 24-bit fields: packed Q of the current chunk, one record per 2 steps; a record is refilled
                                  // with the same steps of the next chunk as soon as both have been consumed
@@ -1007,6 +1020,7 @@ __device__ __forceinline__ void sweep(const Params &p)
         constexpr bool ZSKIP = REV && PASS == PASS_BWD && KIND == CK_F32 && !SDP_BWD_HALF && !ABL_NOMATH && SDP_ZERO_SKIP;
         constexpr bool LAZY = ZSKIP && !ABL_NOLOAD && (TOPLOAD || TOPLOAD_X) && SDP_ZERO_SKIP > 1;
         bool known_zero = false;   // the chunk about to be processed is a zero chunk (found out an iteration ahead): its rows were not fetched
+        bool za_b1 = false, za_b2 = false;   // (ZSKIP_A) the staged E block sets c and c + 1 -- the two that cover the chunk about to be processed -- are all zero
         int zring = 0;             // bit h: half h of the output ring is known to hold +0 everywhere (written by a zero chunk)
         int tail_st = 0;           // (PIPE) memory instructions this wave issued BEHIND its latest request for state rows: the stores of a pipelined chunk
         auto load_rows = [&](int tn, auto set_tag, bool wanted) {   // state rows of the chunk that starts at step tn -> set S
@@ -1190,8 +1204,9 @@ __device__ __forceinline__ void sweep(const Params &p)
         // add and no reliance on how the hardware range-checks the scalar offset)
         // (blocks moved left by up to K-1 columns: one block set later)
         auto block_plain = [&](int bb) { return rows == 64 && bb >= QMAX + (li_unaligned ? 1 : 0) && (bb + 1) * K <= m; };
-        auto load_block_i = [&](int bb, auto plain_tag, int i) {  // instruction i of block set bb -> registers
-            constexpr bool plain = decltype(plain_tag)::value;   // (a compile-time flag: with a run-time one every load sat behind its own branch)
+        auto load_block_i = [&](int bb, auto plain_tag, int i, auto rset_tag) {  // instruction i of block set bb -> registers (set RS)
+            constexpr bool plain = decltype(plain_tag)::value;
+            constexpr int RS = decltype(rset_tag)::value;   // (a compile-time flag: with a run-time one every load sat behind its own branch)
             if constexpr (T::SIN > 0) {
                 const int ubase = (i0 * ld + bb * K) * 4;
                 // non-plain: a group that lies entirely left or right of the row would be a real fetch (of the
@@ -1208,30 +1223,41 @@ __device__ __forceinline__ void sweep(const Params &p)
                 for (int q = 0; q < T::SIN; ++q) {
                     if constexpr (ABL_NOLOAD) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) rs[q][4 * i + j] = __uint_as_float((off + ubase + j) & 0x3fffffu) * 1e30f;
+                        for (int j = 0; j < 4; ++j) rs[RS][q][4 * i + j] = __uint_as_float((off + ubase + j) & 0x3fffffu) * 1e30f;
                     } else {
                         // each dword is range-checked on its own (tools/ubench/bufx4.hip), and only dword
                         // alignment is needed, so M need not be a multiple of 4
                         const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_in[q], off, plain ? ubase - bias : 0, (LINES && SDP_LINES_NT) ? 2 : AUX_IN_LOAD);
                         const unsigned v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
-                        rs[q][4 * i] = __uint_as_float(v0);
-                        rs[q][4 * i + 1] = __uint_as_float(v1);
-                        rs[q][4 * i + 2] = __uint_as_float(v2);
-                        rs[q][4 * i + 3] = __uint_as_float(v3);
+                        rs[RS][q][4 * i] = __uint_as_float(v0);
+                        rs[RS][q][4 * i + 1] = __uint_as_float(v1);
+                        rs[RS][q][4 * i + 2] = __uint_as_float(v2);
+                        rs[RS][q][4 * i + 3] = __uint_as_float(v3);
                     }
                 }
             }
         };
-        auto load_block = [&](int bb) {  // whole block set at once
+        using rs0_t = std::integral_constant<int, 0>;
+        auto load_block_s = [&](int bb, auto rset_tag) {  // whole block set at once
             if (block_plain(bb)) {
 #pragma unroll
-                for (int i = 0; i < NLD; ++i) load_block_i(bb, std::true_type{}, i);
+                for (int i = 0; i < NLD; ++i) load_block_i(bb, std::true_type{}, i, rset_tag);
             } else {
 #pragma unroll
-                for (int i = 0; i < NLD; ++i) load_block_i(bb, std::false_type{}, i);
+                for (int i = 0; i < NLD; ++i) load_block_i(bb, std::false_type{}, i, rset_tag);
             }
         };
-        auto write_block = [&](int bb) {  // registers -> LDS ring
+        auto load_block = [&](int bb) { load_block_s(bb, rs0_t{}); };
+        // (ZSKIP_A) every value of plane 0 of register set RS is +0 / -0 in every lane
+        auto block_zero = [&](auto rset_tag) -> bool {
+            constexpr int RS = decltype(rset_tag)::value;
+            unsigned any = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) any |= __float_as_uint(rs[RS][0][k]) << 1;   // (the sign does not matter: e = -0 multiplies like +0 here)
+            return __builtin_amdgcn_ballot_w64(any != 0) == 0;
+        };
+        auto write_block_s = [&](int bb, auto rset_tag) {  // registers -> LDS ring
+            constexpr int RS = decltype(rset_tag)::value;
             if constexpr (T::SIN > 0 && !ABL_NOLDS) {
                 const int flip = (bb & 1) * K;
 #pragma unroll
@@ -1241,7 +1267,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         if constexpr (LINES && !GEN) {
                             // aligned planes and pitch: ring position of the group's first column = r mod 4 = i mod 4 (mod 4)
                             float *dst = lds_in + q * PLANE;
-                            const float v0 = rs[q][4 * i], v1 = rs[q][4 * i + 1], v2 = rs[q][4 * i + 2], v3 = rs[q][4 * i + 3];
+                            const float v0 = rs[RS][q][4 * i], v1 = rs[RS][q][4 * i + 1], v2 = rs[RS][q][4 * i + 2], v3 = rs[RS][q][4 * i + 3];
                             if ((i & 3) == 0) {
                                 *reinterpret_cast<float4 *>(dst + (li_w[i][0] ^ flip)) = make_float4(v0, v1, v2, v3);
                             } else if ((i & 3) == 2) {
@@ -1254,14 +1280,15 @@ __device__ __forceinline__ void sweep(const Params &p)
                             }
                         } else if constexpr (LINES) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) lds_in[q * PLANE + (li_w[i][j] ^ flip)] = rs[q][4 * i + j];
+                            for (int j = 0; j < 4; ++j) lds_in[q * PLANE + (li_w[i][j] ^ flip)] = rs[RS][q][4 * i + j];
                         } else {
                             *reinterpret_cast<float4 *>(lds_in + q * PLANE + (li_w[i][0] ^ flip)) =
-                                make_float4(rs[q][4 * i], rs[q][4 * i + 1], rs[q][4 * i + 2], rs[q][4 * i + 3]);
+                                make_float4(rs[RS][q][4 * i], rs[RS][q][4 * i + 1], rs[RS][q][4 * i + 2], rs[RS][q][4 * i + 3]);
                         }
                     }
             }
         };
+        auto write_block = [&](int bb) { write_block_s(bb, rs0_t{}); };
 
         const int c_first = REV ? nchunks - 1 : 0;
         const int dir = REV ? -1 : 1;
@@ -1310,8 +1337,14 @@ __device__ __forceinline__ void sweep(const Params &p)
         }
         load_block(c_first);
         write_block(c_first);
+        if constexpr (ZSKIP_A) za_b1 = block_zero(rs0_t{});
         load_block(c_first + 1);
         write_block(c_first + 1);
+        if constexpr (ZSKIP_A) {
+            za_b2 = block_zero(rs0_t{});
+            known_zero = false;                     // (the first chunk's rows are fetched whatever it turns out to be)
+            load_block_s(c_first - 1, rs0_t{});     // the staged blocks travel two chunks ahead: the first body finds this one in set 0
+        }
         // Every load of the prologue has returned before the chunk loop is entered (vmcnt(0), expcnt / lgkmcnt untouched) -- said
         // with the builtin, which the compiler's own wait-count bookkeeping understands.  Without it the state records of the
         // FIRST chunk are "pending loads into v[0:31]" on the loop-entry path only; the compiler merges that with the back
@@ -2243,7 +2276,7 @@ __device__ __forceinline__ void sweep(const Params &p)
             // are stores and the wait takes the rows just requested for the NEXT chunk along: the prefetch distance shrinks to
             // the few hundred cycles of the flush.
             if constexpr (ROT && SDP_PROLOGUE_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);
-            if constexpr (TOPLOAD_X && !ABL_NOLOAD) {
+            if constexpr (TOPLOAD_X && !ABL_NOLOAD && !ZSKIP_A) {   // (ZSKIP_A: requested further down, once the kind of the next chunk is known)
                 if (ci < nchunks) {   // (uniform; the extra flush iterations load nothing)
                     const int c_ = REV ? nchunks - 1 - ci : ci;
                     const int tn = (ci + 1 < nchunks) ? (c_ + dir) * K : c_ * K;   // the last chunk re-reads its own rows: harmless
@@ -2287,6 +2320,65 @@ __device__ __forceinline__ void sweep(const Params &p)
                         tail_st = 0;
                     }
                     pf_t0 = -K, pf_par = 1;
+                    return;
+                }
+            }
+            bool za_acquired = false;
+            if constexpr (ZSKIP_A) {
+                using ecur_t = std::integral_constant<int, P>;       // the E block set that arrived for the NEXT chunk (c - 1) ...
+                using enxt_t = std::integral_constant<int, 1 - P>;   // ... and the set the one after it is loaded into
+                const bool zb_new = block_zero(ecur_t{});
+                auto zero64 = [](u64 v) -> unsigned { return (hi32(v) << 1) | lo32(v); };   // 0 iff +0.0 or -0.0
+                bool zc = known_zero;
+                if (!zc) {
+                    acquire(kc0{}, kc1{});
+                    za_acquired = true;
+                    unsigned any = zero64((u64)__double_as_longlong(cy.a)) | zero64((u64)__double_as_longlong(cy.b)) | zero64((u64)__double_as_longlong(cy.c));
+#pragma unroll
+                    for (int k = 0; k < K; ++k) any |= zero64(bcv[k]);
+                    zc = za_b1 && za_b2 && __builtin_amdgcn_ballot_w64(any != 0) == 0 && !(p.flags & 1);
+                }
+                // will the next chunk be one too?  Its carries stay zero if this one is; its E is known (zb_new, za_b1); its
+                // boundary values only if the strip below has published them already (not waited for)
+                bool nz = zc && more && zb_new && za_b1;
+                if (nz) {
+                    unsigned any = 0;
+                    if (has_pred) {
+                        const int c_lo_n = t0_next - 63;
+                        const int need = (c_lo_n + K > 0 && c_lo_n < m) ? m - (c_lo_n < 0 ? 0 : c_lo_n) : 0;
+                        if (imported || (need > 0 && __builtin_amdgcn_readfirstlane(lds_load_i32(prog + 4 * pword)) < pbase + need)) any = 1;
+                        else {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) {
+                                const int col = c_lo_n + k;
+                                if (col >= 0 && col < m) any |= zero64((u64)bnd_in[col]);
+                            }
+                        }
+                    }
+                    nz = __builtin_amdgcn_ballot_w64(any != 0) == 0;
+                }
+                // the next chunk's Q and Qd rows -- or nothing (a descriptor of zero records returns zeros without touching memory)
+                {
+                    const int tn = more ? t0_next : t0;
+                    const bool wanted = more && !nz;
+                    const __amdgpu_buffer_rsrc_t rq_ = make_rsrc(reinterpret_cast<const char *>(p.qin) + ps_idx * p.st2_ps, wanted ? ST_RECORDS : 0u);
+                    const __amdgpu_buffer_rsrc_t rd_ = make_rsrc(reinterpret_cast<const char *>(p.din) + ps_idx * p.st2_ps, wanted ? ST_RECORDS : 0u);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        rqx2[nxt_t::value][k] = load_f2(rq_, tn, k);
+                        rdd2[nxt_t::value][k] = load_f2(rd_, tn, k);
+                    }
+                }
+                load_block_s((ci + 2 < nchunks) ? c - 2 : c - 1, enxt_t{});   // E two chunks ahead
+                za_b2 = za_b1, za_b1 = zb_new;
+                known_zero = nz;
+                if (zc) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) hist[k] = 0, lo[k] = 0.f;
+                    cy.a = cy.b = cy.c = 0.0;
+                    publish_range(kc0{}, kc1{}, nullptr);
+                    pf_t0 = t0, pf_par = par;
+                    if (more) write_block_s(bb_new, ecur_t{});
                     return;
                 }
             }
@@ -2336,7 +2428,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                 }
             };
             stamp_chunk(t0 / WB, 4);
-            load_block(bb_new);
+            if constexpr (!ZSKIP_A) load_block(bb_new);   // (ZSKIP_A: requested a chunk earlier, see there)
             stamp_chunk(t0 / WB, 5);
 
             if constexpr (FWD_SUB) {
@@ -2348,6 +2440,7 @@ __device__ __forceinline__ void sweep(const Params &p)
             }
 
             if constexpr (HALF) acquire(kch{}, kc1{});   // the reverse sweep starts with the chunk's upper steps
+            else if constexpr (ZSKIP_A) { if (!za_acquired) acquire(kc0{}, kc1{}); }
             else if constexpr (!LAZY) acquire(kc0{}, kc1{});   // (LAZY: further up, in front of the decision what kind of chunk this is)
             if constexpr (!LAZY) stamp_rev(2);
 
@@ -2357,9 +2450,9 @@ __device__ __forceinline__ void sweep(const Params &p)
                 if constexpr (ABL_NOLDS) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        in0[k] = rs[0][k];
-                        if constexpr (T::SIN > 1) in1[k] = rs[1][k];
-                        if constexpr (T::SIN > 2) in2[k] = rs[2][k];
+                        in0[k] = rs[0][0][k];
+                        if constexpr (T::SIN > 1) in1[k] = rs[0][1][k];
+                        if constexpr (T::SIN > 2) in2[k] = rs[0][2][k];
                     }
                 } else {
                     const int pr = (t0 & (RING - 1)) + 4 * ring_pi(lane & 7);  // ring position of step t0 for this lane
@@ -2670,7 +2763,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         cy.b = __builtin_fma(dy, e, qy * ed);
                         cy.a = __builtin_fma(dx, e, __builtin_fma(qx, ed, cy.c));  // gx + gm of the previous step
                         cy.c = __builtin_fma(dm, e, qm * ed);
-                        lo[k] = (float)ed;
+                        lo[k] = ZSKIP_A ? (float)ed + 0.0f : (float)ed;   // (ZSKIP_A: no -0 in Ed, whichever way a zero came about)
                         hist[k] = (u64)__double_as_longlong(cy.a);
                     }
                 }
@@ -2876,7 +2969,8 @@ __device__ __forceinline__ void sweep(const Params &p)
             // ---- flush: one memory-aligned K-element block per row (see fo_* above) ----
             pf_t0 = t0, pf_par = par;
 
-            if (more) write_block(bb_new);
+            if constexpr (ZSKIP_A) { if (more) write_block_s(bb_new, std::integral_constant<int, P>{}); }
+            else { if (more) write_block(bb_new); }
         };
         if constexpr (ROT) {
             for (int ci = 0; ci < nchunks + nflush; ci += 2) {

@@ -99,7 +99,7 @@ extern "C" {
  * (sdp_state_bytes_v / sdp_state_d_bytes_v).  Unoptimised: milliseconds where the default path takes a fraction of one.
  * Not available for sdp_adjoint_forward_loss_f32. */
 #define SDP_REF_ROUNDING 0x400
-/* or-ed into `variant` of sdp_backward_f32 / sdp_backward_range_f32: run EVERY chunk of the sweep.  By default the fp32
+/* or-ed into `variant` of sdp_backward_f32 / sdp_backward_range_f32 / sdp_adjoint_backward_f32: run EVERY chunk of the sweep.  By default the fp32
  * backward sweep neither runs 32-step chunks that can only produce +0 nor reads their state (E underflows to exactly +0
  * away from the alignment) -- a data-dependent saving.  The results are bit-identical either way; the flag
  * is the control a measurement needs (bench.py reports both). */

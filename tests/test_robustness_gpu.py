@@ -284,3 +284,58 @@ def test_exact_zero_chunks_are_skipped_without_changing_a_bit():
             assert np.array_equal(outs[0], outs[1]), (B, N, M, variant, exact)
             nzero += int((outs[0] == 0).sum())
     assert nzero > 0
+
+
+def test_zero_chunks_of_the_adjoint_backward_sweep_do_not_change_a_bit():
+    """Round 5: the adjoint backward sweep does not run chunks over which E, its carries and its boundary values are all zero,
+    nor reads their Q / Qd rows (sdp_kernels.hip, ZSKIP_A).  `variant | SDP_NO_ZERO_SKIP` (the shipped library's control flag)
+    runs them all: Ed must be equal as BIT PATTERNS -- the rule for signed zeros: Ed is stored as (float)ed + 0.0f, so no -0
+    ever leaves the sweep, whichever way a zero came about -- on soft and steep scores, with negative / zero / -0 cotangents of
+    the first-order sweep (E = -0 cells), Smith-Waterman, per-pair lengths, rectangular shapes and many strips; and the same
+    flag on the fp32 backward sweep of the shipped library (E bit-identical)."""
+    from deepblast_amd import _lib
+    from deepblast_amd._engine import get_engine
+    lib = get_engine().lib
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(0).cuda_stream
+    NOSKIP = _lib.SDP_NO_ZERO_SKIP
+    cases = [(6, 512, 512, 0, 1.0, False), (3, 700, 330, 1, 8.0, False), (5, 300, 900, 0, 30.0, True), (2, 1100, 1030, 0, 4.0, True),
+             (9, 1024, 1024, 0, 8.0, False), (40, 130, 77, 1, 2.0, True)]
+    nzero = 0
+    for ci, (B, N, M, variant, steep, use_lens) in enumerate(cases):
+        theta, A = datagen.theta_A(5400 + ci, B, N, M)
+        theta *= steep
+        et_np = np.ones(B, np.float32)
+        et_np[0] = -2.5
+        if B > 2:
+            et_np[1] = 0.0
+            et_np[2] = -0.0
+        Z = datagen.normal(5500 + ci, (B, N, M))
+        lens = None
+        if use_lens:
+            lens = torch.from_numpy(np.minimum(datagen.lengths(5600 + ci, B, 1, N), np.array([N, M])).astype(np.int32)).to(dev)
+        t, a, et, z = (torch.from_numpy(x).to(dev) for x in (theta, A, et_np, Z))
+        lp = None if lens is None else lens.data_ptr()
+        X = 0x100 | variant
+        state = torch.empty(lib.sdp_state_d_bytes(B, N, M) // 4 + 1, dtype=torch.float32, device=dev)
+        state_d = torch.empty_like(state)
+        vt, vtd = torch.empty(B, device=dev), torch.empty(B, device=dev)
+        assert lib.sdp_forward_f32(t.data_ptr(), a.data_ptr(), state.data_ptr(), vt.data_ptr(), B, N, M, lp, X, 0, stream) == 0, lib.sdp_last_error_string()
+        Es = []
+        for flag in (0, NOSKIP):
+            E = torch.full((B, N, M), float("nan"), device=dev)
+            assert lib.sdp_backward_f32(et.data_ptr(), state.data_ptr(), E.data_ptr(), B, N, M, lp, X | flag, 0, stream) == 0, lib.sdp_last_error_string()
+            Es.append(E)
+        torch.cuda.synchronize()
+        assert np.array_equal(Es[0].view(torch.int32).cpu().numpy(), Es[1].view(torch.int32).cpu().numpy()), ("E", B, N, M)
+        assert lib.sdp_adjoint_forward_f32(state.data_ptr(), z.data_ptr(), None, vtd.data_ptr(), state_d.data_ptr(), B, N, M, lp, variant, 0, stream) == 0
+        outs = []
+        for flag in (0, NOSKIP):
+            Ed = torch.full((B, N, M), float("nan"), device=dev)
+            assert lib.sdp_adjoint_backward_f32(Es[0].data_ptr(), state.data_ptr(), state_d.data_ptr(), Ed.data_ptr(), B, N, M, lp, variant | flag, 0, stream) == 0, lib.sdp_last_error_string()
+            torch.cuda.synchronize()
+            outs.append(Ed.view(torch.int32).cpu().numpy())
+        assert np.array_equal(outs[0], outs[1]), ("Ed", B, N, M, variant, int((outs[0] != outs[1]).sum()))
+        assert not (outs[0] == np.int32(-2**31)).any()      # no -0 in Ed
+        nzero += int((outs[0] == 0).sum())
+    assert nzero > 0

@@ -1,9 +1,14 @@
 // Memory-system microbenchmark for the traffic MIX of the forward sweep (gfx950): per "chunk" a wave loads 16 KB
-// (16 x buffer_load_dwordx4, prefetched DEPTH chunks ahead in registers) and stores 12 KB of state, as
+// (16 x buffer_load_dwordx4, prefetched DEPTH chunks ahead in registers) and stores OUT_BYTES (9 KB) of state, as
 // dwordx3 (16 instr, 12-byte lane stride -- what the packed state does), dwordx4 (12 instr) or dwordx2 (24 instr),
 // with a chosen cache policy, optionally with a dependent VALU chain per chunk that stands in for the recurrence.
-// Total traffic is that of B=256, N=M=512: 537 MB read + 453 MB written, whatever the geometry.
+// Total traffic is that of B=256, N=M=512: 537 MB read + 32768 x OUT_BYTES written (302 MB at 9 KB), whatever the geometry.
 // build: hipcc --offload-arch=gfx950 -O3 tools/ubench/mix.hip -o tools/ubench/mix
+// (round 5: the record the forward sweep writes per wave and 32-step chunk is 9216 B -- the 18-bit packed state; -DOUT_BYTES=10240: the 20-bit
+//  state, 12288: the 24-bit state of rounds 1-3)
+#ifndef OUT_BYTES
+#define OUT_BYTES 9216
+#endif
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -27,7 +32,7 @@ __global__ void __launch_bounds__(MAXT) mix(const char *in, char *out, int chunk
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     const int wave = blockIdx.x * wpb + (threadIdx.x >> 6);
-    const size_t in_bytes = (size_t)chunks * 16384, out_bytes = (size_t)chunks * 12288;
+    const size_t in_bytes = (size_t)chunks * 16384, out_bytes = (size_t)chunks * OUT_BYTES;
     __amdgpu_buffer_rsrc_t ri = make_rsrc(in + (size_t)wave * in_bytes, (unsigned)in_bytes);
     __amdgpu_buffer_rsrc_t ro = make_rsrc(out + (size_t)wave * out_bytes, (unsigned)out_bytes);
     u32x4 ring[DEPTH][16];
@@ -54,18 +59,18 @@ __global__ void __launch_bounds__(MAXT) mix(const char *in, char *out, int chunk
             for (int w = 0; w < work; ++w) acc = __builtin_fmaf(acc, 1.0000001f, 1e-9f);  // dependent chain, ~5 cycles each
             s += __float_as_uint(acc);
             if (WR) {
-                constexpr int NST = 12288 / (64 * STW * 4);
+                constexpr int NST = OUT_BYTES / (64 * STW * 4);
 #pragma unroll
                 for (int i = 0; i < NST; ++i) {
                     if constexpr (STW == 4) {
                         u32x4 v = {s, s + 1, s + 2, s + 3};
-                        __builtin_amdgcn_raw_buffer_store_b128(v, ro, lane * 16 + i * 1024, c * 12288, AUXS);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, ro, lane * 16 + i * 1024, c * OUT_BYTES, AUXS);
                     } else if constexpr (STW == 3) {
                         u32x3 v = {s, s + 1, s + 2};
-                        __builtin_amdgcn_raw_buffer_store_b96(v, ro, lane * 12 + i * 768, c * 12288, AUXS);
+                        __builtin_amdgcn_raw_buffer_store_b96(v, ro, lane * 12 + i * 768, c * OUT_BYTES, AUXS);
                     } else {
                         u32x2 v = {s, s + 1};
-                        __builtin_amdgcn_raw_buffer_store_b64(v, ro, lane * 8 + i * 512, c * 12288, AUXS);
+                        __builtin_amdgcn_raw_buffer_store_b64(v, ro, lane * 8 + i * 512, c * OUT_BYTES, AUXS);
                     }
                 }
             }
@@ -76,12 +81,12 @@ __global__ void __launch_bounds__(MAXT) mix(const char *in, char *out, int chunk
 
 int main(int argc, char **argv)
 {
-    const size_t total_chunks = 256 * 4 * 32;   // 32768 chunks: 537 MB in, 403 MB out (the state without its padding)
+    const size_t total_chunks = 256 * 4 * 32;   // 32768 chunks: 537 MB in, 302 MB out at 9 KB per chunk (the state without its padding)
     char *in, *out;
     CHECK(hipMalloc(&in, total_chunks * 16384 + 65536));
-    CHECK(hipMalloc(&out, total_chunks * 12288 + 65536));
+    CHECK(hipMalloc(&out, total_chunks * OUT_BYTES + 65536));
     CHECK(hipMemset(in, 1, total_chunks * 16384));
-    CHECK(hipMemset(out, 0, total_chunks * 12288));
+    CHECK(hipMemset(out, 0, total_chunks * OUT_BYTES));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
@@ -98,7 +103,7 @@ int main(int argc, char **argv)
             CHECK(hipEventElapsedTime(&ms, e0, e1));
             best = ms / 4 < best ? ms / 4 : best;
         }
-        const double bytes = (double)total_chunks * ((rd ? 16384 : 0) + (wr ? 12288 : 0));
+        const double bytes = (double)total_chunks * ((rd ? 16384 : 0) + (wr ? OUT_BYTES : 0));
         printf("%-44s grid %4d x %3d work %4d: %7.1f us  %5.2f TB/s\n", name, blocks, threads, work, best * 1e3, bytes / (best * 1e-3) / 1e12);
         fflush(stdout);
     };
