@@ -2328,19 +2328,33 @@ __device__ __forceinline__ void sweep(const Params &p)
                 using ecur_t = std::integral_constant<int, P>;       // the E block set that arrived for the NEXT chunk (c - 1) ...
                 using enxt_t = std::integral_constant<int, 1 - P>;   // ... and the set the one after it is loaded into
                 const bool zb_new = block_zero(ecur_t{});
-                auto zero64 = [](u64 v) -> unsigned { return (hi32(v) << 1) | lo32(v); };   // 0 iff +0.0 or -0.0
+                // "Zero" for the float64 carries means NEGLIGIBLE: below 2^-170 in magnitude.  The carries of this sweep are float64 and
+                // do not underflow where the fp32 E did; but with e = 0 over the chunk they only get redistributed by weights that
+                // sum to 1, so if everything that enters the chunk is below 2^-170 every Ed in it is below 2^-162 -- and is stored as
+                // the float 0 (the smallest fp32 denormal is 2^-149).  THE RULE, part of the algorithm in both modes: a chunk with
+                // E = 0 whose incoming carries and boundary values are all below 2^-170 starts from exact zeros (what that drops from
+                // any later Ed is below 2^-162, a 2^-13th of the last bit of the smallest denormal).  With the rule applied either
+                // way, skipping such a chunk or computing it (SDP_NO_ZERO_SKIP) gives the same bits.
+                constexpr unsigned TINY = (1023u - 170u) << 20;   // high word of 2^-170
+                auto mag64 = [](u64 v) -> unsigned { return hi32(v) & 0x7fffffffu; };   // < TINY iff |v| < 2^-170
                 bool zc = known_zero;
                 if (!zc) {
                     acquire(kc0{}, kc1{});
                     za_acquired = true;
-                    unsigned any = zero64((u64)__double_as_longlong(cy.a)) | zero64((u64)__double_as_longlong(cy.b)) | zero64((u64)__double_as_longlong(cy.c));
+                    unsigned big = max(max(mag64((u64)__double_as_longlong(cy.a)), mag64((u64)__double_as_longlong(cy.b))), mag64((u64)__double_as_longlong(cy.c)));
 #pragma unroll
-                    for (int k = 0; k < K; ++k) any |= zero64(bcv[k]);
-                    zc = za_b1 && za_b2 && __builtin_amdgcn_ballot_w64(any != 0) == 0 && !(p.flags & 1);
+                    for (int k = 0; k < K; ++k) big = max(big, mag64(bcv[k]));
+                    zc = za_b1 && za_b2 && __builtin_amdgcn_ballot_w64(big >= TINY) == 0;
+                    if (zc) {   // the rule: from exact zeros
+                        cy.a = cy.b = cy.c = 0.0;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) bcv[k] = 0;
+                    }
                 }
+                const bool zskip = zc && !(p.flags & 1);   // (SDP_NO_ZERO_SKIP: the chunk is computed all the same -- from the same zeros)
                 // will the next chunk be one too?  Its carries stay zero if this one is; its E is known (zb_new, za_b1); its
                 // boundary values only if the strip below has published them already (not waited for)
-                bool nz = zc && more && zb_new && za_b1;
+                bool nz = zskip && more && zb_new && za_b1;
                 if (nz) {
                     unsigned any = 0;
                     if (has_pred) {
@@ -2351,7 +2365,7 @@ __device__ __forceinline__ void sweep(const Params &p)
 #pragma unroll
                             for (int k = 0; k < K; ++k) {
                                 const int col = c_lo_n + k;
-                                if (col >= 0 && col < m) any |= zero64((u64)bnd_in[col]);
+                                if (col >= 0 && col < m) any |= mag64((u64)bnd_in[col]) >= TINY ? 1u : 0u;
                             }
                         }
                     }
@@ -2372,7 +2386,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                 load_block_s((ci + 2 < nchunks) ? c - 2 : c - 1, enxt_t{});   // E two chunks ahead
                 za_b2 = za_b1, za_b1 = zb_new;
                 known_zero = nz;
-                if (zc) {
+                if (zskip) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) hist[k] = 0, lo[k] = 0.f;
                     cy.a = cy.b = cy.c = 0.0;
