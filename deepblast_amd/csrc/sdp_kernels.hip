@@ -1935,6 +1935,16 @@ __device__ __forceinline__ void sweep(const Params &p)
             else __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(v.x), __float_as_uint(v.y)}, rs_out, lane_off,
                                                        (i0 * ld + t0) * 4 + (c_r * ld - 32 * (k2 >> 3)) * 4, AUX_OUT_STORE);
         };
+        // an all-zero plain flush: 64 rows x 128 bytes of +0 as eight dwordx4 stores (eight rows each), no LDS
+        auto flush_zero8 = [&](int t0) {
+            typedef unsigned u32x4z __attribute__((ext_vector_type(4)));
+            const unsigned lane_off = (unsigned)(((lane >> 3) * ld + 4 * (lane & 7)) * 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (!ABL_NOSTORE)
+                    __builtin_amdgcn_raw_buffer_store_b128((u32x4z){0u, 0u, 0u, 0u}, rs_out, lane_off, ((i0 + 8 * j) * ld + t0 - (j >= 4 ? K : 0)) * 4, AUX_OUT_STORE);
+            }
+        };
         auto flush_out = [&](int t0, int par, bool active, bool zero = false) {   // zero: both halves of the ring are known to hold +0
             if constexpr (T::SOUT > 0) {
                 const int ubase = (i0 * ld + t0) * 4;
@@ -2263,8 +2273,9 @@ __device__ __forceinline__ void sweep(const Params &p)
                 // the iteration's one wait for memory: this chunk's rows (requested an iteration ago) and whatever is older.  A
                 // pipelined chunk issued its 16 output stores BEHIND that request (vmcnt retires in order); every other kind of
                 // iteration requested the rows last
-                if (tail_st) __builtin_amdgcn_s_waitcnt(0x4F70);   // vmcnt(16)
-                else __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0)
+                if (tail_st == K / 2) __builtin_amdgcn_s_waitcnt(0x4F70);        // vmcnt(16)
+                else if (tail_st == K / 4) __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8): the eight wide stores of an all-zero flush
+                else __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0)
             } else if constexpr (LAZY) {
                 // (the fp32 backward sweep waits inside its flush and requests rows further down: see there)
             } else {
@@ -2298,10 +2309,11 @@ __device__ __forceinline__ void sweep(const Params &p)
             }
             float2 fv[PIPE ? K / 2 : 1];   // (PIPE) the previous chunk's outputs, out of LDS and on their way to memory
             bool fl_defer = false;         // (PIPE) ... their stores have not been issued yet
+            const bool fl_zero = ZSKIP && zring == 3;   // ... and they are all +0 (the last two chunks were zero chunks)
             if constexpr (T::SOUT > 0) {
                 if constexpr (PIPE) {
                     fl_defer = ci > 0 && rows == 64 && pf_t0 >= K && pf_t0 + K <= m && SDP_FLUSH_FAST;   // the plain flush: every element a real cell
-                    if (fl_defer) flush_read(pf_par, ZSKIP && zring == 3, fv);
+                    if (fl_defer) flush_read(pf_par, fl_zero, fv);
                     else {
                         flush_out(pf_t0, pf_par, ci > 0, ZSKIP && zring == 3);
 #pragma unroll
@@ -2314,8 +2326,11 @@ __device__ __forceinline__ void sweep(const Params &p)
                 if (ci >= nchunks) {
                     if constexpr (PIPE) {
                         if (fl_defer) {
+                            if (fl_zero) flush_zero8(pf_t0);
+                            else {
 #pragma unroll
-                            for (int k2 = 0; k2 < K / 2; ++k2) flush_store1(pf_t0, k2, fv[k2], (unsigned)(f2_g * 4));
+                                for (int k2 = 0; k2 < K / 2; ++k2) flush_store1(pf_t0, k2, fv[k2], (unsigned)(f2_g * 4));
+                            }
                         }
                         tail_st = 0;
                     }
@@ -2415,16 +2430,23 @@ __device__ __forceinline__ void sweep(const Params &p)
                 }
                 stamp_rev(2);
                 const bool next_zero = zero_chunk && more && boundary_zero(t0_next, false);
-                if constexpr (PIPE) {
-                    pipe_now = fl_defer && !zero_chunk && pipe_interior;
-                    if (fl_defer && !pipe_now) {   // no pipelined steps to carry them: the stores leave here, in front of the request for rows
-#pragma unroll
-                        for (int k2 = 0; k2 < K / 2; ++k2) flush_store1(pf_t0, k2, fv[k2], (unsigned)(f2_g * 4));
-                    }
-                    tail_st = (!zero_chunk && pipe_interior) ? K / 2 : 0;   // (a pipelined body issues its 16 stores whether or not they are dummies)
-                }
+                if constexpr (PIPE) pipe_now = fl_defer && !zero_chunk && pipe_interior;
                 load_rows(t0_next, nxt_t{}, more && !next_zero);
                 known_zero = next_zero;
+                if constexpr (PIPE) {
+                    tail_st = (!zero_chunk && pipe_interior) ? K / 2 : 0;   // (a pipelined body issues its 16 stores whether or not they are dummies)
+                    if (fl_defer && !pipe_now) {
+                        // no pipelined steps to carry them: the stores leave here, BEHIND the request for rows -- the next iteration's
+                        // wait then leaves them outstanding (in a run of zero chunks nothing ever waits for a store's acknowledgement);
+                        // an all-zero flush is eight wide stores out of no registers at all
+                        if (fl_zero) flush_zero8(pf_t0), tail_st += K / 4;
+                        else {
+#pragma unroll
+                            for (int k2 = 0; k2 < K / 2; ++k2) flush_store1(pf_t0, k2, fv[k2], (unsigned)(f2_g * 4));
+                            tail_st += K / 2;
+                        }
+                    }
+                }
                 if (zero_chunk) {
                     zero_fill_ring();
                     stamp_rev(3);

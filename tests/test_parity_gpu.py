@@ -615,6 +615,30 @@ def test_max_cols_is_enforced():
         eng.forward(t, t, 0)
 
 
+@pytest.mark.parametrize("scale", [(1.0, 1.0), (8.0, 1.0), (30.0, 10.0)], ids=["soft", "theta-x8", "theta-x30-A-x10"])
+def test_packed_state_at_the_longest_paths_it_serves(scale):
+    """the packed-state limits re-measured for the formats in use.  The 20-bit fields serve problems up to
+    N + M = 4096 (sdp_api.hip: PACKED_MAX_PATH), the 18-bit fields up to N + M = 1024 (sdp_kernels.h: packed_bits); their
+    rounding error travels along a path like a random walk, so the longest paths are the test: max |dE| against the oracle at
+    2048 x 2048 (20-bit) and at 512 x 512 / 300 x 724 (18-bit), soft, steep and saturated scores, held to HALF the bound."""
+    import torch
+    from deepblast_amd._engine import get_engine
+    eng = get_engine()
+    ts, as_ = scale
+    for (B, N, M, bits) in ((2, 2048, 2048, 20), (3, 512, 512, 18), (3, 300, 724, 18)):
+        assert eng.lib.sdp_state_pair_stride(N, M, 0) * 8 == ((N + 63) // 64) * ((M + 126) // 64 * 64) * 64 * 2 * bits   # the format under test
+        theta, A = datagen.theta_A(2048 + N, B, N, M)
+        theta, A = theta * np.float32(ts), A * np.float32(as_)
+        ref = parity.oracle_all(theta, A, None, None, 0, omp=True)
+        t, a = torch.from_numpy(theta).cuda(), torch.from_numpy(A).cuda()
+        Vt, Q = eng.forward(t, a, 0)
+        E = eng.backward(torch.ones(B, device="cuda"), Q, (B, N, M), 0)
+        err = parity.abs_err(E.cpu().numpy(), ref["E"])
+        print(f"packed {bits}-bit state, {N} x {M}, theta x{ts} A x{as_}: max |dE| = {err:.2e}")
+        assert err <= 0.5 * parity.TOL, (N, M, bits, err)
+        assert parity.rel_err(Vt.cpu().numpy(), ref["Vt"]) <= parity.TOL
+
+
 @pytest.mark.parametrize("variant", [0, 1], ids=["nw", "sw"])
 def test_more_columns_than_the_sweeps_take_run_transposed(variant):
     """the parity oracle nw.py has no column limit; the engine's sweeps stop at sdp_max_cols() = 2048 (the
