@@ -9,7 +9,7 @@ own B pairs (weak scaling, no data-path collective) and the step ends with the R
 that collects the terminal scores Vt from all ranks (--gather e also gathers E).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the mode (the one with the longest
-mean launch; sdp_fwd18_kernel -- the forward sweep with the 18-bit packed state -- in the headline mode): algorithmic bytes (12 B per cell-update for the forward
+mean launch; sdp_fwd_kernel in the headline mode): algorithmic bytes (12 B per cell-update for the forward
 and backward sweeps, 32 B for each adjoint sweep; flops on the matrix pipe when the scores
 GEMM dominates) over its mean launch duration measured with HIP events on the launch stream inside the
 timed region.  `cpu_baseline` is the CPU oracle (a port of

@@ -103,6 +103,7 @@ Variant variant(int id)
     case 26: return {(const void *)sdp_fwd_x_tp_pg_kernel, SDP_K_FWD, SDP_MAXW_FWD, 26};
     case 27: return {(const void *)sdp_bwd_pg_kernel, SDP_K_BWD, SDP_MAXW_BWD, 27};
     case 28: return {(const void *)sdp_bwd_x_pg_kernel, SDP_K_BWD, SDP_MAXW_BWD, 28};
+#if SDP_Q18
     // 18-bit packed state (sdp_kernels.h: packed_bits): 29 fwd, 30 fwd latency, 31 fwd general pitch, 32 bwd, 33 bwd latency, 34 / 35 their general pitch
     case 29: return {(const void *)sdp_fwd18_kernel, SDP_K_FWD, SDP_MAXW_FWD, 29};
     case 30: return {(const void *)sdp_fwd18_lat_kernel, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, 30};
@@ -111,6 +112,7 @@ Variant variant(int id)
     case 33: return {(const void *)sdp_bwd18_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 33};
     case 34: return {(const void *)sdp_bwd18_g_kernel, SDP_K_BWD, SDP_MAXW_BWD, 34};
     case 35: return {(const void *)sdp_bwd18_lat_g_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 35};
+#endif
     default: return {(const void *)sdp_bwd_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 4};
     }
 }

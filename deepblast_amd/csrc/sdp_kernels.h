@@ -153,7 +153,7 @@ constexpr unsigned STATEQ_UNIT_BYTES = SDP_Q20 ? 10 * 1024 : 16 * 768, STATE2_UN
 // other's launch plans -- only problems that can never be spread over several workgroups: no per-pair lengths, N <= 768.
 // sdp_state_bytes keeps sizing the buffer for the 20-bit fields (it is not told about lengths).
 #ifndef SDP_Q18
-#define SDP_Q18 1
+#define SDP_Q18 0   // NOT adopted (round 5): the gate holds only barely and only for near-square shapes, the gain is ~1 % -- see sdp_kernels.hip "18-bit fields"
 #endif
 constexpr unsigned STATEQ18_UNIT_BYTES = 2 * (4 * 1024 + 512);
 constexpr int PACKED18_MAX_PATH = 1024;
@@ -206,6 +206,7 @@ __global__ void sdp_bwd_lat_g_kernel(const sdp::Params p);
 __global__ void sdp_bwd_x_g_kernel(const sdp::Params p);
 __global__ void sdp_bwd_x_lat_g_kernel(const sdp::Params p);
 __global__ void sdp_adj_bwd_g_kernel(const sdp::Params p);
+#if SDP_Q18
 __global__ void sdp_fwd18_kernel(const sdp::Params p);
 __global__ void sdp_fwd18_lat_kernel(const sdp::Params p);
 __global__ void sdp_fwd18_g_kernel(const sdp::Params p);
@@ -213,6 +214,7 @@ __global__ void sdp_bwd18_kernel(const sdp::Params p);
 __global__ void sdp_bwd18_lat_kernel(const sdp::Params p);
 __global__ void sdp_bwd18_g_kernel(const sdp::Params p);
 __global__ void sdp_bwd18_lat_g_kernel(const sdp::Params p);
+#endif
 __global__ void sdp_ref_fwd_kernel(const float *theta, const float *A, float *Q, float *Vt, const int *lens, int N, int M, int sw);
 __global__ void sdp_ref_bwd_kernel(const float *Et, const float *Q, float *E, const int *lens, int N, int M, int sw, int et_bcast);
 __global__ void sdp_ref_adj_fwd_kernel(const float *Q, const float *Ztheta, const float *ZA, float *Vtd, float *Qd, const int *lens, int N, int M);

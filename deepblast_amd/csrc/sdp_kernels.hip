@@ -350,14 +350,18 @@ __device__ __forceinline__ float2 q20_unpack(const unsigned *w, int sub)
     }
 }
 
-// Round 5: two 18-bit fields per cell (4.5 bytes) for problems with N + M <= 1024 (sdp_kernels.h: packed_bits).  A field is
-// the low 18 bits of the float f = 32 + q * (1 - 2^-17): in [32, 64) one ulp is 2^-18 (absolute error <= 2^-19 = 1.9e-6 per
-// weight).  Gate (ten times the bound at every shape the format serves): the float64 oracle's weights rounded to
-// the grid, backward recurrence in float64, max |dE| over three seeds -- 512 x 512: benchmark scores 1.9e-6, theta x 4
-// 4.8e-6, theta x 8 7.4e-6, theta x 12 / A x 6 7.5e-6, theta x 30 5.6e-6; at 1024 x 1024 theta x 8 reaches 1.04e-5, which is why
-// the format stops at N + M = 1024 and the 20-bit fields take over (17-bit: 1.5e-5, 16-bit: 3.5e-5 at 512 x 512).  Eight cells
-// -- sixteen fields -- fill nine dwords; the 18 dwords of a 16-step block are four rows of one dwordx4 per lane and one row
-// of a dwordx2 (4608 bytes per block instead of 5120).
+// Round 5, -DSDP_Q18=1 (built, bit-checked, measured, NOT adopted): two 18-bit fields per cell (4.5 bytes) for problems with
+// N + M <= 1024 (sdp_kernels.h: packed_bits).  A field is the low 18 bits of the float f = 32 + q * (1 - 2^-17): in [32, 64) one
+// ulp is 2^-18 (absolute error <= 2^-19 = 1.9e-6 per weight).  Eight cells -- sixteen fields -- fill nine dwords; the 18 dwords
+// of a 16-step block are four rows of one dwordx4 per lane and one row of a dwordx2 (4608 bytes per block instead of 5120).
+// Gate (ten times inside the bound at every shape the format serves; tools/emu_field_bits.py, float64 oracle
+// weights rounded to the grid, backward recurrence in float64, max |dE| over three seeds and five score families;
+// profiles/r05_emu_state_formats.txt): 512 x 512 <= 7.5e-6, 400 x 400 9.6e-6, 384 x 512 1.0e-5 -- AT the gate -- and thin shapes
+// beyond it: 300 x 724 1.2e-5, 512 x 128 1.0e-5, 128 x 896 1.6e-5, 64 x 512 2.1e-5 (a row of gap steps carries the rounding of
+// every weight along).  On the GPU, against the oracle: 1.0e-5 at 512 x 512 (theta x 30, A x 10), 1.3e-5 at 300 x 724 -- a
+// factor 8, where the 20-bit fields keep 30.  The gain: forward 923 -> 887 MB, backward 562 -> 527 MB per launch at
+// 256 x 512^2, the two sweeps back to back 317 -> 314 us (+- 4).  One per cent of time is not worth three quarters of the
+// margin: the shipped library keeps the 20-bit fields for every shape.
 constexpr float Q18_SCALE = 0.99999237060546875f;       // 1 - 2^-17
 constexpr float Q18_UNSCALE = 1.00000762939453125f;     // 1 + 2^-17 = 1 / (1 - 2^-17) to fp32
 template <int QB>
@@ -3086,6 +3090,7 @@ SDP_KERNEL(sdp_bwd_lat_g_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT,
 SDP_KERNEL(sdp_bwd_x_g_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, true, false, true)
 SDP_KERNEL(sdp_bwd_x_lat_g_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, true, false, true)
 SDP_KERNEL(sdp_adj_bwd_g_kernel, sdp::PASS_ABWD, SDP_K_ABWD, SDP_MAXW_ABWD, false, false, true)
+#if SDP_Q18
 // 18-bit packed state (N + M <= 1024, no per-pair lengths: sdp_kernels.h packed_bits): the forward / backward builds that serve it
 SDP_KERNEL(sdp_fwd18_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LINES != 0, false, false, 18)
 SDP_KERNEL(sdp_fwd18_lat_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, false, false, false, false, 18)
@@ -3095,6 +3100,7 @@ SDP_KERNEL(sdp_bwd18_lat_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT,
 SDP_KERNEL(sdp_bwd18_g_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, false, false, true, false, 18)
 SDP_KERNEL(sdp_bwd18_lat_g_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, false, false, true, false, 18)
 
+#endif
 #endif
 
 // ----------------------------------------------------------------------------------

@@ -31,13 +31,7 @@
  *     this library reads them.  For the backward sweep Q is kept as two 20-bit
  *     fixed-point weights per cell (absolute error <= 2^-21 = 4.8e-7 per weight,
  *     SDP_PACKED_STATE_BYTES_PER_CELL = 5 bytes per cell, times 1.125 for the skew
- *     padding at M = 512; a weight within 2^-21 of 1 / of 0 decodes to exactly 1 / 0);
- *     problems with N + M <= 1024, N <= 768 and no per-pair lengths -- the benchmark's
- *     512 x 512 among them -- take two 18-bit weights (error <= 2^-19 per weight,
- *     SDP_PACKED18_STATE_BITS_PER_CELL = 36 bits = 4.5 bytes per cell: max |dE| <= 7.5e-6
- *     on soft, steep and peaked scores at 512 x 512, more than ten times inside the
- *     1e-4 bound; csrc/sdp_kernels.hip "18-bit fields").  sdp_state_bytes sizes the
- *     buffer for the 20-bit form in either case.
+ *     padding at M = 512; a weight within 2^-21 of 1 / of 0 decodes to exactly 1 / 0).
  *     The adjoint sweeps (second order) multiply the weights with
  *     directional derivatives of any size and need them at full fp32 precision:
  *     run sdp_forward_f32 with SDP_EXACT_STATE for them (float2 per cell, the
@@ -73,7 +67,7 @@
 extern "C" {
 #endif
 
-#define SDP_VERSION 104 /* 0.1.3: + the float64 entry points (sdp_*_f64) */
+#define SDP_VERSION 105 /* 0.1.4: + SDP_NO_ZERO_SKIP, SDP_NO_FILL */
 
 #define SDP_NW 0
 #define SDP_SW 1
@@ -112,7 +106,6 @@ extern "C" {
 #define SDP_NO_FILL 0x10000
 /* bytes per cell of the packed state (the header's statement of the format; tests/test_abi.py holds sdp_state_bytes to it) */
 #define SDP_PACKED_STATE_BYTES_PER_CELL 5
-#define SDP_PACKED18_STATE_BITS_PER_CELL 36 /* the short-path form (N + M <= 1024, N <= 768, no lengths): 4.5 bytes per cell */
 
 #define SDP_E_NULLPTR (-1)  /* a required pointer is NULL */
 #define SDP_E_SHAPE (-2)    /* B, N or M non-positive */

@@ -42,7 +42,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_limits(lib):
-    assert lib.sdp_version() == 104
+    assert lib.sdp_version() == 105
     assert lib.sdp_max_cols() == 2048  # reference GPU path: max_cols = 2048 (nw_cuda.py:11)
 
 
@@ -75,10 +75,7 @@ def test_header_states_the_packed_state_format_the_library_uses(lib):
     # two pairs more of 512 x 512 cost two records of 8 strips x 576 steps x 64 lanes (+ 1024 bytes of dispatch map for the
     # parts of the two extra pairs): the per-cell figure again, through a difference that drops the rest of the tail
     assert lib.sdp_state_pair_stride(1024, 1024, 0) == 16 * 1088 * 64 * per_cell
-    # ... and the 18-bit form of short problems (the records are 4.5 bytes per cell; the buffer is sized for 5)
-    m18 = re.search(r"#define\s+SDP_PACKED18_STATE_BITS_PER_CELL\s+(\d+)", hdr)
-    assert m18 and lib.sdp_state_pair_stride(512, 512, 0) * 8 == 8 * 576 * 64 * int(m18.group(1))
-    assert lib.sdp_state_bytes(256, 512, 512) >= 256 * lib.sdp_state_pair_stride(512, 512, 0)
+    assert lib.sdp_state_pair_stride(512, 512, 0) == 8 * 576 * 64 * per_cell
     assert f"{per_cell} bytes" in hdr and "20-bit" in hdr and "23-bit" not in hdr and "6 bytes" not in hdr
     for doc in ("INTEGRATION.md", os.path.join("deepblast_amd", "_engine.py"), os.path.join("deepblast_amd", "_dp.py")):
         text = open(os.path.join(ROOT, doc)).read()
@@ -114,16 +111,12 @@ def test_launch_plan_policy(lib):
     """Which build / how many waves a launch uses, checked without a device."""
     LDS = 160 * 1024
     # headline: one pair per CU -> throughput builds, 4 waves, long chunks
-    # (N + M <= 1024 without per-pair lengths: the builds of the 18-bit packed state, ids 29 .. 35; with lengths or beyond: 20-bit)
-    assert _plan(lib, 0, 256, 512, 512)[:3] == (29, 32, 4)
-    assert _plan(lib, 1, 256, 512, 512)[:3] == (32, 32, 4)
-    assert _plan(lib, 0, 256, 512, 512, lens=1)[0] in (0, 6) and _plan(lib, 1, 256, 512, 512, lens=1)[0] in (1, 4, 23)
-    assert _plan(lib, 0, 256, 512, 640)[:3] == (0, 32, 4) and _plan(lib, 1, 256, 512, 640)[:3] == (1, 32, 4)
-    assert _plan(lib, 0, 256, 800, 200)[0] == 0 and _plan(lib, 1, 256, 800, 200)[0] == 1     # (N > 768: could be spread over workgroups)
+    # (ids 29 .. 35 would be the builds of the 18-bit packed state, -DSDP_Q18=1: measured in round 5 and not adopted)
+    assert _plan(lib, 0, 256, 512, 512)[:3] == (0, 32, 4)
+    assert _plan(lib, 1, 256, 512, 512)[:3] == (1, 32, 4)
     # small batch -> latency builds, 8 waves, short chunks
-    assert _plan(lib, 0, 16, 512, 512)[:3] == (30, 16, 8)
-    assert _plan(lib, 1, 16, 512, 512)[:3] == (33, 16, 8)
-    assert _plan(lib, 0, 16, 640, 512)[:3] == (6, 16, 8) and _plan(lib, 1, 16, 640, 512)[:3] == (4, 16, 8)
+    assert _plan(lib, 0, 16, 512, 512)[:3] == (6, 16, 8)
+    assert _plan(lib, 1, 16, 512, 512)[:3] == (4, 16, 8)
     # a pair spread over several CUs, four strips (one per wave of the throughput builds) per workgroup: where it was
     # measured to pay -- per-pair lengths and a batch within the CU count: forward sweep from three parts on, backward sweep
     # from two; equal pairs: the backward sweep of a few pairs of more than twelve strips; never the adjoint pair
