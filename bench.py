@@ -60,11 +60,11 @@ def parse():
 class KernelTimer:
     """Brackets engine launches with a pair of events on the launch stream, inside the timed region.
 
-    Every `every`-th launch of each kernel is bracketed (default: every second one): a pair of event records costs
+    Every `every`-th launch of each kernel is bracketed (default: every fourth one): a pair of event records costs
     the step ~3 us per kernel (measured: 0.402 vs 0.387 ms per step with all launches bracketed / none), and the
-    mean of half the launches of the timed region is as good an estimate as the mean of all of them."""
+    mean of a quarter of the launches of the timed region is as good an estimate as the mean of all of them."""
 
-    def __init__(self, every=2):
+    def __init__(self, every=4):
         self.spans = []
         self.enabled = False
         self.every = every
@@ -287,7 +287,7 @@ def main():
     aligner = ShardedAligner(dec, gather=args.gather if multi else "none", e_chunks=args.e_chunks,
                              idiom="sum_backward" if args.mode == "fwdbwd" else "grad")
     eng = get_engine()
-    timer = KernelTimer()
+    timer = KernelTimer(every=4 if args.steps >= 8 else 1)   # (a short run brackets every launch: it must still see each kernel)
     eng.launch_hook = None if os.environ.get("BENCH_NO_KERNEL_EVENTS") else timer   # (experiment: cost of the event pairs)
 
     emb = None

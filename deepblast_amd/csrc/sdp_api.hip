@@ -235,12 +235,19 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
     //   532 / 385 -> 462 / 309; more pairs than CUs, <= 1022 x 1020: 384 pairs 752 / 761 -> 778 / 743, 512 pairs 832 / 1023 ->
     //   1000 / 950, 700 pairs 998 / 1188 -> 1250 / 1300;
     //   equal pairs: 16 x 1024^2 445 / 330 -> 451 / 291; 64 x 640 x 500 240 / 163 -> 260 / 183 (worse); 16 x 512^2 worse.
-    // So: with per-pair lengths whenever the batch does not outnumber the CUs -- the forward sweep from three parts on, the
-    // backward sweep from two; equal pairs only the backward sweep of pairs of four parts.  The adjoint pair (float64
+    // So (round 3; round 5's re-measurement below drops the backward sweep with per-pair lengths): with per-pair lengths whenever
+    // the batch does not outnumber the CUs -- the forward sweep from three parts on, the backward sweep from two; equal pairs
+    // only the backward sweep of pairs of four parts.  The adjoint pair (float64
     // carries) keeps one workgroup per pair.
     int parts = 0;
     const bool parts_fit = sweep12 && forced_waves <= 0 && nstrips > PART_STRIPS && !q18;
-    const bool parts_pay = B <= cus && (has_lens ? (pass == sdp::PASS_BWD || nstrips > 2 * PART_STRIPS)
+    // Round 5, re-measured after the backward sweep's changes (profiles/r05_parts_table.txt; us, one workgroup per pair -> parts):
+    // with per-pair lengths the BACKWARD sweep no longer gains from parts anywhere but at BASELINE configs[2] (540 -> 512-522,
+    // and 515 when only the forward sweep uses them) and loses elsewhere (<= 640^2: 213 -> 236, <= 512^2: 146 -> 160, 64 pairs
+    // <= 1022 x 1020: 336 -> 355, 32 pairs <= 2000 x 1000: 528 -> 582): dropped.  The forward sweep keeps them from three parts
+    // on (<= 1022 x 1020: 600 -> 514, <= 640^2: 277 -> 257, 64 pairs: 510 -> 400; <= 512^2: 176 -> 195, not taken), equal pairs
+    // the backward sweep of a few pairs of more than twelve strips (16 x 1024^2: 303 -> 279).
+    const bool parts_pay = B <= cus && (has_lens ? (pass == sdp::PASS_FWD && nstrips > 2 * PART_STRIPS)
                                                  : (pass == sdp::PASS_BWD && nstrips > 3 * PART_STRIPS && (long long)B * parts_per_pair(N) <= cus));
     if (parts_fit && (allow_parts == 2 || (allow_parts == 1 && parts_pay))) {
         const Variant tv = variant(21 + (pass == sdp::PASS_FWD ? 0 : 2) + (exact_state ? 1 : 0) + (general_pitch ? 4 : 0));
@@ -257,6 +264,10 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
         lds = lds_bytes(pass, v.K, W, mcap, &off, nin);
         if (lds <= 160 * 1024 || W == 1) break;
     }
+    // Two-wave workgroups (more pairs than CUs) are meant to share a CU in PAIRS, one wave per SIMD.  Since round 5 the backward
+    // build needs fewer than 256 registers, so the hardware would also take four of them -- two waves per SIMD, each at half
+    // speed, other CUs short of work: 247 -> 262 us at 512 x 512^2.  Asking for half a CU's LDS keeps it at two.
+    if (sweep12 && W == 2 && B > cus && lds < 80 * 1024) lds = 80 * 1024;
     return {v, W, lds, off, parts};
 }
 

@@ -1200,6 +1200,7 @@ __device__ __forceinline__ void sweep(const Params &p)
         //   global float offset  = r ld - D_r + e_l   = [c ld - 32 (k2 >> 3)] + f2_g, f2_g = rl ld + e_l
         const int f2_rl = 8 * ((lane >> 4) >> 1) + 16 * ((lane >> 4) & 1), f2_el = 2 * (lane & 15);
         const int f2_l = f2_rl * PO + f2_rl + f2_el, f2_g = f2_rl * ld + f2_el;
+        const int f2_rl_c = f2_rl, f2_el_c = f2_el, f2_l_c = f2_l, f2_g_c = f2_g, r_l_c = r_l, s_l_c = s_l;   // (for the opaque copies in flush_out's rare paths)
 
         // Chunk c of this strip touches only real cells of a full, unmasked strip: no masking needed.
         auto chunk_interior = [&](int c) { return plain_strip && c * K >= 63 && c * K + K < m; };
@@ -1985,6 +1986,11 @@ __device__ __forceinline__ void sweep(const Params &p)
                         if constexpr (LAZY && !PIPE) __builtin_amdgcn_s_waitcnt(0x4F70);   // vmcnt(16): everything older than these K / 2 stores
                     } else if ((m & 1) == 0) {   // (uniform)
                         float2 vals[K / 2];
+                        // (the per-lane constants pass through an opaque copy: the compiler otherwise hoists the 16 + 32 index /
+                        //  offset calculations of these two rare paths out of the chunk loop into the strip's set-up -- ~250
+                        //  instructions per strip and ~100 registers held across the whole sweep, round 5 ISA)
+                        int f2_rl = f2_rl_c, f2_el = f2_el_c, f2_l = f2_l_c, f2_g = f2_g_c;
+                        asm volatile("" : "+v"(f2_rl), "+v"(f2_el), "+v"(f2_l), "+v"(f2_g));
 #pragma unroll
                         for (int k2 = 0; k2 < K / 2; ++k2) {
                             const int sfull = (k2 & 7) + f2_rl + f2_el;
@@ -2005,6 +2011,8 @@ __device__ __forceinline__ void sweep(const Params &p)
                         }
                         if constexpr (LAZY && !PIPE) __builtin_amdgcn_s_waitcnt(0x4F70);   // vmcnt(16)
                     } else {   // an odd number of columns (per-pair lengths): a column at a time, indices formed on the spot
+                        int r_l = r_l_c, s_l = s_l_c;
+                        asm volatile("" : "+v"(r_l), "+v"(s_l));
 #pragma unroll
                         for (int k = 0; k < K; ++k) {
                             const int row = k * RPI + r_l, rho = row & (K - 1), sfull = rho + s_l;

@@ -121,8 +121,9 @@ def test_launch_plan_policy(lib):
     # measured to pay -- per-pair lengths and a batch within the CU count: forward sweep from three parts on, backward sweep
     # from two; equal pairs: the backward sweep of a few pairs of more than twelve strips; never the adjoint pair
     pp = lambda pass_, B, N, M, lens, exact=0: lib.sdp_plan_parts(pass_, B, N, M, lens, exact, 256)
-    assert pp(0, 256, 1022, 1020, 1) == 4 and pp(1, 256, 1022, 1020, 1) == 4 and pp(0, 256, 640, 640, 1) == 4
-    assert pp(0, 256, 512, 512, 1) == 0 and pp(1, 256, 512, 512, 1) == 4 and pp(1, 256, 256, 512, 1) == 0
+    # (round 5: the backward sweep no longer takes parts with per-pair lengths -- re-measured, profiles/r05_parts_table.txt)
+    assert pp(0, 256, 1022, 1020, 1) == 4 and pp(1, 256, 1022, 1020, 1) == 0 and pp(0, 256, 640, 640, 1) == 4
+    assert pp(0, 256, 512, 512, 1) == 0 and pp(1, 256, 512, 512, 1) == 0 and pp(1, 256, 256, 512, 1) == 0
     assert pp(0, 700, 1022, 1020, 1) == 0 and pp(1, 700, 1022, 1020, 1) == 0
     assert pp(0, 16, 1024, 1024, 0) == 0 and pp(1, 16, 1024, 1024, 0) == 4 and pp(1, 64, 640, 500, 0) == 0 and pp(1, 128, 1024, 512, 0) == 0
     assert pp(2, 16, 1024, 1024, 1, 1) == 0 and pp(3, 16, 1024, 1024, 1, 1) == 0
