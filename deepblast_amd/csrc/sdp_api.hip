@@ -77,7 +77,7 @@ Variant variant(int id)
 {
     switch (id) {
     case 0: return {(const void *)sdp_fwd_kernel, SDP_K_FWD, SDP_MAXW_FWD, 0};
-    case 1: return {(const void *)sdp_bwd_kernel, SDP_K_BWD, SDP_MAXW_BWD, 1};
+    case 1: return {(const void *)sdp_bwd_kernel, SDP_K_BWD, SDP_MAXW_BWD_Q, 1};
     case 2: return {(const void *)sdp_adj_fwd_kernel, SDP_K_AFWD, SDP_MAXW_AFWD, 2};
     case 3: return {(const void *)sdp_adj_bwd_kernel, SDP_K_ABWD, SDP_MAXW_ABWD, 3};
     case 5: return {(const void *)sdp_fwd_x_kernel, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, 5};
@@ -88,7 +88,7 @@ Variant variant(int id)
     case 10: return {(const void *)sdp_adj_fwd_loss_kernel, SDP_K_AFWD, 4, 10};  // adj-fwd with the loss seed formed in the kernel
     // general-pitch instantiations (staged blocks aligned to lines of memory through run-time per-row offsets): id + 11
     case 11: return {(const void *)sdp_fwd_g_kernel, SDP_K_FWD, SDP_MAXW_FWD, 11};
-    case 12: return {(const void *)sdp_bwd_g_kernel, SDP_K_BWD, SDP_MAXW_BWD, 12};
+    case 12: return {(const void *)sdp_bwd_g_kernel, SDP_K_BWD, SDP_MAXW_BWD, 12};   // (general pitch: 87 spills under an 8-wave bound, stays at 4)
     case 14: return {(const void *)sdp_adj_bwd_g_kernel, SDP_K_ABWD, SDP_MAXW_ABWD, 14};
     case 15: return {(const void *)sdp_bwd_lat_g_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 15};
     case 18: return {(const void *)sdp_bwd_x_g_kernel, SDP_K_BWD, SDP_MAXW_BWD, 18};
@@ -204,7 +204,10 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
     // With per-pair lengths the longest pairs set the time of a batch that does not queue up on the CUs, so such
     // a batch is treated like a small one (measured, 256 pairs with n, m ~ U[64,1024]: 1.27 ms vs 1.41 ms).
     const bool sweep12 = pass == sdp::PASS_FWD || pass == sdp::PASS_BWD;
-    const bool full = B * 2 >= cus && !(has_lens && B <= 2 * cus);  // measured crossover: ~100 pairs on 256 CUs
+    // measured crossover (round 5, 512 x 512, 256 CUs; profiles/r05_small_batches.txt): the forward sweep's latency build holds 133 us
+    // up to 64 pairs and is at 170-190 us from 80 on, where the throughput build takes 148-151 -- ~72 pairs; the backward sweep's
+    // 8-wave form is level with its 4-wave form up to 128 pairs
+    const bool full = (pass == sdp::PASS_FWD ? B * 7 >= cus * 2 : B * 2 >= cus) && !(has_lens && B <= 2 * cus);
     Variant v = variant(pass);
     int W = forced_waves;
     if (W <= 0) {
@@ -218,7 +221,10 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
         // the throughput builds need 4 waves' worth of LDS for their longer chunks; fall back to the latency
         // builds when that does not fit (long M) or when more waves are wanted
         const int w4 = nstrips < 4 ? nstrips : 4;
-        if (W > v.maxw || lds_bytes(pass, v.K, w4, mcap, nullptr) > 160 * 1024) v = variant(pass == sdp::PASS_FWD ? 6 : 4);
+        // (the packed backward build runs up to 8 waves since round 5 -- its general-pitch and exact-state twins only 4: a launch
+        //  that will end up in one of those is judged by their limit)
+        const int maxw = (pass == sdp::PASS_BWD && (general_pitch || exact_state)) ? SDP_MAXW_BWD : v.maxw;
+        if (W > maxw || lds_bytes(pass, v.K, w4, mcap, nullptr) > 160 * 1024) v = variant(pass == sdp::PASS_FWD ? 6 : 4);
     }
     if (pass == sdp::PASS_FWD && exact_state) v = variant(v.id == 0 ? 9 : 5);
     if (pass == sdp::PASS_BWD && exact_state) v = variant(v.id == 1 ? 7 : 8);

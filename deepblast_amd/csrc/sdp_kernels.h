@@ -39,6 +39,12 @@
 #ifndef SDP_MAXW_BWD
 #define SDP_MAXW_BWD 4
 #endif
+// Round 5: the packed-state backward build (K = 32) needs 246 registers since its rare flush paths stopped being hoisted into
+// the strip set-up, so EIGHT of its waves fit a CU without a spill -- and for batches that do not fill the GPU they beat the
+// K = 16 latency build by a fifth (64 x 512^2: 125 -> 101 us).  The exact-state and parts builds (298+ registers) stay at 4.
+#ifndef SDP_MAXW_BWD_Q
+#define SDP_MAXW_BWD_Q 8
+#endif
 // Second build of the backward sweep for batches that do not fill the GPU: shorter chunks and up to 8
 // waves shorten the strip pipeline (the kernel is then bound by per-pair latency, not by HBM).
 #ifndef SDP_K_BWD_LAT
