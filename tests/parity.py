@@ -138,11 +138,18 @@ def unscaled(got, ref, key="Ed"):
     return abs_err(got[key], ref[key], scale=False)
 
 
-def compare(got, ref):
-    """-> dict of errors, already normalised so that each must be <= TOL."""
+def compare(got, ref, plain=True):
+    """-> dict of errors, already normalised so that each must be <= TOL.
+
+    Second order: SURVEY 8c states the bound as a plain max-abs, and `Ed_plain` holds exactly that.  `plain=False` -- only
+    the scaled figure `Ed` (error / max(1, max|Ed_ref|)) -- is for the NAMED steep cases whose Ed reaches 5-30 and whose plain
+    error is 1.0-1.7e-4 (first screen: there the fp32 reference's own rounding against its float64 run is of
+    that size; tests/test_parity_gpu.py::test_where_the_fp32_reference_is_the_noisy_one)."""
     errs = {"Vt": rel_err(got["Vt"], ref["Vt"]), "E": abs_err(got["E"], ref["E"])}
     if "Ed" in ref:
         errs["Ed"] = abs_err(got["Ed"], ref["Ed"], scale=True)
+        if plain:
+            errs["Ed_plain"] = abs_err(got["Ed"], ref["Ed"], scale=False)
         errs["Vtd"] = rel_err(got["Vtd"], ref["Vtd"])
     if "Ex" in got:  # backward sweep reading the exact state (training path) against the same reference E
         errs["Ex"] = abs_err(got["Ex"], ref["E"])
