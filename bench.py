@@ -38,8 +38,11 @@ ALGO_BYTES_PER_CELL_UPDATE = 12  # theta 4 + A 4 + state 4 | sta
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)   # (0.06 s of GPU time at the headline shape; see --warmup)
+    ap.add_argument("--warmup", type=int, default=50,
+                    help="untimed steps before the timed region.  The defaults measure the steady state: K = 20 behind W = 3 -- 7 ms "
+                         "after an idle GPU -- reads 0.316-0.321 ms per step where K = 200 behind W = 50 reads 0.289-0.297 on the same "
+                         "box, interleaved (clocks still rising, and the fixed costs of a short region; DESIGN.md 4)")
     ap.add_argument("--B", type=int, default=256, help="pairs per GPU")
     ap.add_argument("--N", type=int, default=512)
     ap.add_argument("--M", type=int, default=512)
@@ -287,7 +290,7 @@ def main():
     aligner = ShardedAligner(dec, gather=args.gather if multi else "none", e_chunks=args.e_chunks,
                              idiom="sum_backward" if args.mode == "fwdbwd" else "grad")
     eng = get_engine()
-    timer = KernelTimer(every=4 if args.steps >= 8 else 1)   # (a short run brackets every launch: it must still see each kernel)
+    timer = KernelTimer(every=max(4, args.steps // 8) if args.steps >= 8 else 1)   # (<= 8 bracketed launches per kernel at the default K: a bracketed step pays ~16 us for its three extra holes; a short run brackets every launch: it must still see each kernel)
     eng.launch_hook = None if os.environ.get("BENCH_NO_KERNEL_EVENTS") else timer   # (experiment: cost of the event pairs)
 
     emb = None
@@ -342,24 +345,28 @@ def main():
         step()
     fence()
     def timed(nsteps):
-        """EXACTLY nsteps steps between two fences; -> (wall seconds, max over ranks; per-step ms from events)."""
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(nsteps + 1)]
+        """EXACTLY nsteps steps between two fences; -> (wall seconds, max over ranks; ms per step between two events).
+
+        ONE pair of events around the whole loop, not one per step: an event record between two dependent kernels costs the
+        stream ~6 us (rocprofv3 kernel trace of this loop with a record after every step: a 6.0-6.3 us hole in front of every
+        forward sweep, none without; tools/gap_probe.py) -- 2 % of a 0.32 ms step spent on the measurement itself."""
+        m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         fence()
         t0 = time.perf_counter()
-        marks[0].record()
+        m0.record()
         for i in range(nsteps):
             step()
-            marks[i + 1].record()
+        m1.record()
         fence()
         dt = time.perf_counter() - t0
         if multi:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        return dt, [marks[i].elapsed_time(marks[i + 1]) for i in range(nsteps)]
+        return dt, m0.elapsed_time(m1) / nsteps
 
     timer.enabled = True
-    elapsed, per_step_ms = timed(args.steps)
+    elapsed, ms_per_step_events = timed(args.steps)
     timer.enabled = False
     cells = B * N * M if args.variant == "nw" else B * (N - 1) * (M - 1)
     per_step_updates = (4 if args.mode.startswith("train") else 2) * cells
@@ -416,7 +423,7 @@ def main():
                            "train-mce": "DP cell-updates/sec (train: decode + MatrixCrossEntropy + backward)",
                            "train-mce-fused": "DP cell-updates/sec (train: fused decode + MatrixCrossEntropy + backward)"}[args.mode],
                 "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": float(np.median(per_step_ms)),
+                "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_events": ms_per_step_events,
                 "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"{args.variant.upper()} soft-DP " + {"fwdbwd": "fwd+bwd", "align+traceback": "fwd+bwd+traceback", "train": "decode+loss.backward",
@@ -516,7 +523,8 @@ def main():
     e_gather = e_gather_one = None
     # (a secondary figure must not cost the primary one: an error here -- the same on every rank, e.g. out of memory for
     # the gathered E -- is reported on stderr and the line goes out without that field)
-    def secondary(kind, e_chunks=None, idiom=None):
+    def secondary(kind, e_chunks=None, idiom=None, nsteps=None):
+        nsteps = nsteps or min(args.steps, 20)    # (the gathers of E move gigabytes per step: a bounded region)
         try:
             aligner.gather = kind
             aligner.e_chunks = args.e_chunks if e_chunks is None else e_chunks
@@ -524,8 +532,8 @@ def main():
             if os.environ.get("BENCH_TEST_HANG_RANK") == str(rank):   # test hook: this rank never reaches the collective
                 time.sleep(3600)
             step()
-            dt_s, _ = timed(min(args.steps, 5))
-            return dt_s / min(args.steps, 5)
+            dt_s, _ = timed(nsteps)
+            return dt_s / nsteps
         except Exception as ex:   # noqa: BLE001
             print(f"[bench] rank {rank}: secondary measurement gather={kind!r} failed: {ex}", file=sys.stderr, flush=True)
             return None
@@ -555,22 +563,22 @@ def main():
         dog.start()
     direct = None
     if args.mode == "fwdbwd" and not os.environ.get("BENCH_NO_SECONDARY"):
-        direct = secondary(args.gather if multi else "none", idiom="grad")
+        direct = secondary(args.gather if multi else "none", idiom="grad", nsteps=args.steps)   # (the primary's own step count: like for like)
     # the control of the data-dependent saving: the same step with the backward sweep running EVERY chunk
     # (variant | SDP_NO_ZERO_SKIP; E is bit-identical) -- a number that moves with the data travels with its control
     if rank == 0 and not multi and args.mode in ("fwdbwd", "train") and not os.environ.get("BENCH_NO_SECONDARY"):
         try:
             eng.zero_skip = False
             step()
-            ns_timer = KernelTimer(every=1)
+            ns_timer = KernelTimer(every=timer.every)   # (the primary's own step count and bracketing: a like-for-like control)
             eng.launch_hook = ns_timer
             ns_timer.enabled = True
-            dt_ns, _ = timed(min(args.steps, 10))
+            dt_ns, _ = timed(args.steps)
             ns_timer.enabled = False
             nm = ns_timer.means_ms()
-            no_skip = {"ms_per_step": dt_ns / min(args.steps, 10) * 1e3, "value": per_step_updates * min(args.steps, 10) / dt_ns,
+            no_skip = {"ms_per_step": dt_ns / args.steps * 1e3, "value": per_step_updates * args.steps / dt_ns,
                        "bwd_ms": next((v for k, v in nm.items() if k.startswith("sdp_bwd")), None),
-                       "fwd_ms": next((v for k, v in nm.items() if k.startswith("sdp_fwd")), None), "steps": min(args.steps, 10),
+                       "fwd_ms": next((v for k, v in nm.items() if k.startswith("sdp_fwd")), None), "steps": args.steps,
                        "what": "the same step with variant | SDP_NO_ZERO_SKIP: the backward sweep runs every chunk and reads all of its state (bit-identical E)"}
         except Exception as ex:   # noqa: BLE001
             print(f"[bench] no_skip control failed: {ex}", file=sys.stderr, flush=True)

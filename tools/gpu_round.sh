@@ -29,9 +29,9 @@ if [ "$NGPU" -ge 2 ]; then
 else
   echo "multi-GPU dry run SKIPPED: $NGPU GPU visible (needs >= 2; nothing in this repo has run on more than one GPU yet)" | tee $OUT/multigpu_skipped.txt
 fi
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o fwdbwd -- env BENCH_NO_SECONDARY=1 python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/rocprof.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o train -- env BENCH_NO_SECONDARY=1 python bench.py --steps 10 --warmup 2 --mode train --no-cpu-baseline > $OUT/bench_prof_train.json 2>> $OUT/rocprof.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_scores -o scores -- python bench.py --steps 10 --warmup 2 --mode scores+dp --no-cpu-baseline > $OUT/bench_prof_scores.json 2>> $OUT/rocprof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o fwdbwd -- env BENCH_NO_SECONDARY=1 python bench.py --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/rocprof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o train -- env BENCH_NO_SECONDARY=1 python bench.py --mode train --no-cpu-baseline > $OUT/bench_prof_train.json 2>> $OUT/rocprof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_scores -o scores -- python bench.py --mode scores+dp --no-cpu-baseline > $OUT/bench_prof_scores.json 2>> $OUT/rocprof.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_cfg -o cfg -- python tools/gpu_configs.py > $OUT/configs_prof.txt 2>> $OUT/rocprof.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_scores_bwd -o sb -- python tools/scores_bwd_probe.py 2>> $OUT/rocprof.err | grep ' us' > $OUT/scores_bwd.txt
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -41,10 +41,10 @@ done
 # the bench lines LAST, after profiles/traffic.json has been rebuilt (on this box's copy) from the counter passes of this
 # very visit: their roofline.traffic then is the figure measured minutes earlier on the same sources
 python tools/collect_profiles.py $TAG > $OUT/collect.txt 2>&1
-timeout 600 python bench.py --steps 20 --warmup 3 2> $OUT/bench.err | tee $OUT/bench.json
-timeout 600 python bench.py --steps 20 --warmup 3 --mode train --no-cpu-baseline 2>> $OUT/bench.err | tee $OUT/bench_train.json
-timeout 600 python bench.py --steps 20 --warmup 3 --mode scores+dp --no-cpu-baseline 2>> $OUT/bench.err | tee $OUT/bench_scores.json
-timeout 600 python bench.py --steps 20 --warmup 3 --mode align+traceback --no-cpu-baseline 2>> $OUT/bench.err | tee $OUT/bench_traceback.json
+timeout 600 python bench.py 2> $OUT/bench.err | tee $OUT/bench.json
+timeout 600 python bench.py --mode train --no-cpu-baseline 2>> $OUT/bench.err | tee $OUT/bench_train.json
+timeout 600 python bench.py --mode scores+dp --no-cpu-baseline 2>> $OUT/bench.err | tee $OUT/bench_scores.json
+timeout 600 python bench.py --mode align+traceback --no-cpu-baseline 2>> $OUT/bench.err | tee $OUT/bench_traceback.json
 # BASELINE configs[1..3] through the public API (configs[2]: reference semantics and lengths-aware), and the per-pair-lengths
 # batch through the library with and without the pairs spread over several workgroups
 timeout 300 python tools/gpu_configs.py 2> /dev/null | tee $OUT/configs.txt
@@ -60,7 +60,7 @@ timeout 300 python tools/fwd_trace.py 7 > $OUT/fwd_trace_alias7.txt 2>&1
 timeout 300 python tools/zero_probe.py 2>&1 | grep -v amdgpu > $OUT/zero_probe.txt
 timeout 300 python tools/zero_probe.py 256 1024 1024 2>&1 | grep -v amdgpu >> $OUT/zero_probe.txt
 for B in 512 1024; do
-  timeout 300 python bench.py --steps 10 --warmup 2 --B $B --no-cpu-baseline 2> /dev/null | python -c "
+  timeout 300 python bench.py --B $B --no-cpu-baseline 2> /dev/null | python -c "
 import json, sys
 d = json.loads([ln for ln in sys.stdin if ln.startswith('{')][-1])
 print(f\"B=$B: {d['ms_per_step']:.4f} ms/step  {d['value']:.4g} cell-updates/s  fwd {[v for k, v in d['kernel_ms'].items() if k.startswith('sdp_fwd')][0] * 1e3:.1f} us  bwd {[v for k, v in d['kernel_ms'].items() if k.startswith('sdp_bwd')][0] * 1e3:.1f} us  roofline frac {d['roofline']['frac']:.3f}\")"
