@@ -61,7 +61,7 @@ class HipEngine:
                     21: "sdp_fwd_p_kernel", 22: "sdp_fwd_x_tp_p_kernel", 23: "sdp_bwd_p_kernel", 24: "sdp_bwd_x_p_kernel",
                     25: "sdp_fwd_pg_kernel", 26: "sdp_fwd_x_tp_pg_kernel", 27: "sdp_bwd_pg_kernel", 28: "sdp_bwd_x_pg_kernel",
                     29: "sdp_fwd18_kernel", 30: "sdp_fwd18_lat_kernel", 31: "sdp_fwd18_g_kernel", 32: "sdp_bwd18_kernel",
-                    33: "sdp_bwd18_lat_kernel", 34: "sdp_bwd18_g_kernel", 35: "sdp_bwd18_lat_g_kernel"}
+                    33: "sdp_bwd18_lat_kernel", 34: "sdp_bwd18_g_kernel", 35: "sdp_bwd18_lat_g_kernel", 36: "sdp_bwd_pipe_kernel"}
 
     def _label(self, pass_, B, N, M, has_lens, exact, dev, default):
         """Name of the kernel a launch will use (for the launch hook: bench.py's per-kernel timers must carry the names the

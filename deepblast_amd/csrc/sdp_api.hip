@@ -113,6 +113,7 @@ Variant variant(int id)
     case 34: return {(const void *)sdp_bwd18_g_kernel, SDP_K_BWD, SDP_MAXW_BWD, 34};
     case 35: return {(const void *)sdp_bwd18_lat_g_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 35};
 #endif
+    case 36: return {(const void *)sdp_bwd_pipe_kernel, SDP_K_BWD, SDP_MAXW_BWD_Q, 36};   // [1] with the chunk as one software pipeline (long pairs)
     default: return {(const void *)sdp_bwd_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 4};
     }
 }
@@ -232,6 +233,17 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
     if (nin) v = variant(10);
     if (general_pitch) v = variant(general_id(v.id));
     if (q18) v = variant(q18_id(v.id));
+    // The packed backward sweep's pipelined twin (sdp_kernels.hip, sdp_bwd_pipe_kernel) trades instruction issue for memory
+    // latency.  Steady-state A/B over 24 shapes (tools/steady.py, +- 0.3 us; profiles/r05_steady_pipe.txt): it pays 2.3 % where
+    // every CU holds ONE pair of long rows (256 x 1024^2, 256 x 512 x 1024), is level at 256 x 768 x 640 / 300 x 2000 / 192 x 1024^2, and
+    // costs 1.1-3.7 % everywhere else -- shorter rows (the headline 256 x 512^2: 279.0 vs 272.5 us; 256 x 2048 x 256: 2.7 %), fewer
+    // pairs than CUs (128 x 1024^2), more (384 x 1024^2, 512 x 768^2), 8 waves per pair (64 x 512^2).  So: only there.
+    // (-DSDP_BWD_PIPE_RULE=0 never, 2 always: the A/B builds of that table)
+#ifndef SDP_BWD_PIPE_RULE
+#define SDP_BWD_PIPE_RULE 1
+#endif
+    const bool bwd_pipe_pays = W == 4 && B <= cus && B * 8 >= cus * 7 && M >= 1024 && (long long)N * M >= 450000;
+    if (v.id == 1 && (SDP_BWD_PIPE_RULE == 2 || (SDP_BWD_PIPE_RULE == 1 && bwd_pipe_pays))) v = variant(36);
     // A pair over several workgroups (sdp_kernels.hip, "PARTS"): parts of four strips, each on a CU of its own, one strip
     // per wave of the 4-wave throughput builds, instead of one CU taking all the pair's strips in rounds.  It pays only
     // where CUs would otherwise idle AND the pair is long enough for the extra lag per bridge (measured, round 3, us
@@ -387,7 +399,7 @@ VariantBits split_variant(int variant)
 // 160 KiB the hardware has, so concurrent callers cannot disagree
 int raise_lds_limit(const Variant &v, int device)
 {
-    static thread_local unsigned long long lds_raised[36] = {0};  // per kernel id: bit d = done on device d
+    static thread_local unsigned long long lds_raised[37] = {0};  // per kernel id: bit d = done on device d
     if (device >= 64 || !(lds_raised[v.id] >> device & 1ull)) {
         hipError_t e = hipFuncSetAttribute(v.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -600,7 +612,7 @@ int sdp_init(int device)
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
     if (device >= 0 && device < MAX_DEV && !status_words(device)) return fail(SDP_E_SELFTEST, "sdp_init: could not create the host-pinned status words");
-    for (int id = 0; id <= 35; ++id) {   // (21-28: the parts instantiations, 29-35: the 18-bit packed state)
+    for (int id = 0; id <= 36; ++id) {   // (21-28: the parts instantiations, 29-35: the 18-bit packed state, 36: the pipelined backward twin)
         const Variant v = variant(id);
         if (v.id != id) continue;   // ids without a build of their own map to the default
         if (int rc = raise_lds_limit(v, device)) return rc;

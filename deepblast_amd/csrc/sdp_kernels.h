@@ -191,6 +191,7 @@ __global__ void sdp_fwd_lat_kernel(const sdp::Params p);
 __global__ void sdp_fwd_x_kernel(const sdp::Params p);
 __global__ void sdp_fwd_x_tp_kernel(const sdp::Params p);
 __global__ void sdp_bwd_kernel(const sdp::Params p);
+__global__ void sdp_bwd_pipe_kernel(const sdp::Params p);
 __global__ void sdp_bwd_lat_kernel(const sdp::Params p);
 __global__ void sdp_bwd_x_kernel(const sdp::Params p);
 __global__ void sdp_bwd_x_lat_kernel(const sdp::Params p);

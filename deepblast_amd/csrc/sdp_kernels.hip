@@ -565,7 +565,7 @@ __device__ __forceinline__ float loss_dterm(float r, float y, float sc, int kind
 // start on K-float boundaries (M a multiple of 32, 128-byte aligned tensors): the same formulas with the offsets
 // folded to constants -- the host picks per launch (sdp_api.hip), and the headline shape pays nothing for generality
 // (with one instantiation for both, the forward kernel measured +5 % and the backward +3 % at M = 512).
-template <int PASS, int K, bool QX = false, bool LINES = false, bool GEN = false, bool PARTS = false, int QB = 20>
+template <int PASS, int K, bool QX = false, bool LINES = false, bool GEN = false, bool PARTS = false, int QB = 20, bool NOPIPE = false>
 __device__ __forceinline__ void sweep(const Params &p)
 {
     using T = Traits<PASS, QX>;
@@ -1913,7 +1913,7 @@ __device__ __forceinline__ void sweep(const Params &p)
         //     the progress word is left for the end of the chunk.
         // The wait for the state rows (requested an iteration ago) sits at the top of the iteration and counts the stores a
         // pipelined chunk issued behind that request (tail_st).
-        constexpr bool PIPE = FLUSH2 && LAZY && SDP_BWD_PIPE;
+        constexpr bool PIPE = FLUSH2 && LAZY && SDP_BWD_PIPE && !NOPIPE;   // (NOPIPE: the twin build for short pairs, see sdp_bwd_kernel below)
         static_assert(!FLUSH2 || T::SIN == 0 || K <= 16, "FLUSH2 writes one float in front of lds_out: there must be no staged input plane before it");
         // the plain flush in two halves: LDS -> registers, registers -> memory (all 64 x 32 elements are real cells)
         auto flush_read = [&](int par, bool zero, float2 *vals) {
@@ -3056,7 +3056,9 @@ __device__ __forceinline__ void sweep(const Params &p)
 
 // (-DSDP_ONLY=<n>: compile ONE kernel, for ISA inspection with `hipcc -S --cuda-device-only` -- tools/isa.sh; never linked)
 #if defined(SDP_ONLY) && SDP_ONLY == 1
-SDP_KERNEL(sdp_bwd_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q)
+SDP_KERNEL(sdp_bwd_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q, false, false, false, false, 20, true)
+#elif defined(SDP_ONLY) && SDP_ONLY == 21
+SDP_KERNEL(sdp_bwd_pipe_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q)
 #elif defined(SDP_ONLY) && SDP_ONLY == 0
 SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LINES != 0)
 #elif defined(SDP_ONLY) && SDP_ONLY == 18
@@ -3074,7 +3076,13 @@ SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LI
 SDP_KERNEL(sdp_fwd_lat_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT)
 SDP_KERNEL(sdp_fwd_x_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, true)
 SDP_KERNEL(sdp_fwd_x_tp_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, SDP_LINES != 0)
-SDP_KERNEL(sdp_bwd_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q)
+// The packed backward sweep twice: with the chunk as ONE software pipeline (PIPE: deferred flush, stores inside the steps) for
+// long pairs on one wave per SIMD, and without it for everything else -- steady-state A/B, fwd;bwd us, +- 0.3 (tools/steady.py,
+// profiles/r05_steady_pipe.txt; no pipeline -> pipeline): 256 x 1024^2 1064.5 -> 1036.2, 256 x 512 x 1024 665.5 -> 650.7, 256 x 768 x 640
+// 576.1 -> 569.3, 256 x 1024 x 512 602.6 -> 596.6; but 256 x 512^2 272.5 -> 279.0, 64 x 512^2 218.3 -> 224.2, 128 x 512^2 243.3 -> 249.1,
+// 512 x 256^2 163.4 -> 169.6, 128 x 1024^2 (8 waves) 816.3 -> 825.1.  sdp_api.hip plan() picks (bwd_pipe_pays).
+SDP_KERNEL(sdp_bwd_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q, false, false, false, false, 20, true)
+SDP_KERNEL(sdp_bwd_pipe_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q)
 SDP_KERNEL(sdp_bwd_lat_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT)
 SDP_KERNEL(sdp_bwd_x_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, true)
 SDP_KERNEL(sdp_bwd_x_lat_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, true)

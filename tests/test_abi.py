@@ -118,6 +118,10 @@ def test_launch_plan_policy(lib):
     assert _plan(lib, 0, 16, 512, 512)[:3] == (6, 16, 8)
     # (backward sweep, round 5: the K = 32 packed build with 8 waves -- it needs < 256 registers now; the exact state keeps K = 16)
     assert _plan(lib, 1, 16, 512, 512)[:3] == (1, 32, 8) and _plan(lib, 1, 100, 512, 512)[:3] == (1, 32, 8)
+    # the packed backward sweep's pipelined twin (id 36): only where every CU holds one pair of long rows (steady-state table, sdp_api.hip)
+    assert _plan(lib, 1, 256, 512, 512)[:3] == (1, 32, 4) and _plan(lib, 1, 256, 1024, 1024)[:3] == (36, 32, 4)
+    assert _plan(lib, 1, 256, 512, 1024)[0] == 36 and _plan(lib, 1, 256, 768, 640)[0] == 1 and _plan(lib, 1, 128, 1024, 1024)[:3] == (1, 32, 4)
+    assert _plan(lib, 1, 1024, 512, 512)[:3] == (1, 32, 2) and _plan(lib, 1, 384, 1024, 1024)[0] == 1 and _plan(lib, 1, 256, 2048, 256)[0] == 1
     # (forward sweep: the throughput build from ~72 pairs on)
     assert _plan(lib, 0, 64, 512, 512)[:3] == (6, 16, 8) and _plan(lib, 0, 80, 512, 512)[:3] == (0, 32, 4)
     # a pair spread over several CUs, four strips (one per wave of the throughput builds) per workgroup: where it was
@@ -146,5 +150,5 @@ def test_launch_plan_policy(lib):
             kid, chunk, waves, lds = _plan(lib, pass_, B, N, M)
             assert 1 <= waves <= 8 and lds <= LDS, (pass_, B, N, M, kid, waves, lds)
     # the long-M fallback: throughput builds do not fit with 2048 columns
-    assert _plan(lib, 0, 256, 512, 2048)[0] == 6 and _plan(lib, 1, 256, 512, 2048)[0] in (1, 4)
+    assert _plan(lib, 0, 256, 512, 2048)[0] == 6 and _plan(lib, 1, 256, 512, 2048)[0] in (1, 4, 36)
     assert _plan(lib, 1, 256, 512, 2048, exact=1)[0] in (7, 8)
