@@ -22,18 +22,19 @@ shapes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:] if "x" in a 
 ROUNDS, ITERS = int(arg.get("ROUNDS", 5)), int(arg.get("ITERS", 200))
 WF, WB = int(arg.get("WF", 0)), int(arg.get("WB", 0))
 FLAGS_B = int(arg.get("BFLAGS", "0"), 0)   # e.g. BFLAGS=0x800: SDP_NO_ZERO_SKIP
+XS = 0x100 if arg.get("X") else 0            # X=1: the exact (float2) state of the training path (SDP_EXACT_STATE)
 for (B, N, M) in shapes:
     th, A = datagen.theta_A(1, min(B, 64), N, M)
     reps = (B + th.shape[0] - 1) // th.shape[0]
     t = torch.from_numpy(np.tile(th, (reps, 1, 1))[:B]).cuda()
     a = torch.from_numpy(np.tile(A, (reps, 1, 1))[:B]).cuda()
     vt, et, E = torch.empty(B, device="cuda"), torch.ones(B, device="cuda"), torch.empty(B, N, M, device="cuda")
-    st = torch.empty(max(l.sdp_state_bytes(B, N, M) for l in L.values()) // 4, device="cuda")
+    st = torch.empty(max((l.sdp_state_d_bytes(B, N, M) if XS else l.sdp_state_bytes(B, N, M)) for l in L.values()) // 4, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     fn = {}
     for k, l in L.items():
-        f = (lambda l: lambda: l.sdp_forward_f32(t.data_ptr(), a.data_ptr(), st.data_ptr(), vt.data_ptr(), B, N, M, None, (WF & 0xf) << 12, 0, stream))(l)
-        b = (lambda l: lambda: l.sdp_backward_f32(et.data_ptr(), st.data_ptr(), E.data_ptr(), B, N, M, None, ((WB & 0xf) << 12) | FLAGS_B, 0, stream))(l)
+        f = (lambda l: lambda: l.sdp_forward_f32(t.data_ptr(), a.data_ptr(), st.data_ptr(), vt.data_ptr(), B, N, M, None, ((WF & 0xf) << 12) | XS, 0, stream))(l)
+        b = (lambda l: lambda: l.sdp_backward_f32(et.data_ptr(), st.data_ptr(), E.data_ptr(), B, N, M, None, ((WB & 0xf) << 12) | FLAGS_B | XS, 0, stream))(l)
         assert f() == 0 and b() == 0
         fn[k] = (f, b)
     res = {k: {"seq": [], "f": [], "b": []} for k in L}
