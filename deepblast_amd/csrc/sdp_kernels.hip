@@ -144,6 +144,9 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #ifndef SDP_BWD_PIPE
 #define SDP_BWD_PIPE 1  // fp32 backward sweep, aligned K = 32 builds: the chunk as ONE software pipeline (see PIPE in the chunk loop)
 #endif
+#ifndef SDP_FLUSH4
+#define SDP_FLUSH4 1  // reverse sweeps without the pipelined chunk, plain flush: the same 16 aligned 8-byte LDS reads, but 8 dwordx4 stores (four columns per lane) instead of 16 dwordx2 -- bit-identical; steady state, fwd;bwd us: 256 x 512^2 282.9 -> 282.5, 64 x 512^2 217.3 -> 215.3, 512 x 512^2 544.2 -> 543.1, 256 x 768 x 640 529.0 -> 525.6 (what a chunk's stores cost goes with their BYTES, not their number: profiles/r05_flusher_waves.txt)
+#endif
 #ifndef SDP_BWD_MASKFREE
 #define SDP_BWD_MASKFREE 1  // fp32 backward sweep: the ramps of a full strip run the mask-free step body too (see bwd_mask_free)
 #endif
@@ -1201,6 +1204,12 @@ __device__ __forceinline__ void sweep(const Params &p)
         const int f2_rl = 8 * ((lane >> 4) >> 1) + 16 * ((lane >> 4) & 1), f2_el = 2 * (lane & 15);
         const int f2_l = f2_rl * PO + f2_rl + f2_el, f2_g = f2_rl * ld + f2_el;
         const int f2_rl_c = f2_rl, f2_el_c = f2_el, f2_l_c = f2_l, f2_g_c = f2_g, r_l_c = r_l, s_l_c = s_l;   // (for the opaque copies in flush_out's rare paths)
+        // FLUSH4 (-DSDP_FLUSH4=1): four columns per lane and store.  Instruction k4 (0..7), lane -> row r = c + rl, c = 4 (k4 & 3) + 32 (k4 >> 2),
+        //   rl = (a & 1) + 16 ((a >> 1) & 1) + 2 (a >> 2), a = lane >> 3 -- the four rows of a 32-lane LDS group are r, r + 1 (bank bases two
+        //   floats apart: their 8-byte reads at columns 4 g interleave) and r + 16, r + 17 (32 banks further); columns e_l .. e_l + 3, e_l = 4 (lane & 7)
+        //   LDS index (parity 0) of pair j = [c PO + 4 (k4 & 3)] + f4_l + 2 j;  global float offset = [c ld - 32 (k4 >> 2)] + f4_g
+        const int f4_a = lane >> 3, f4_rl = (f4_a & 1) + 16 * ((f4_a >> 1) & 1) + 2 * (f4_a >> 2), f4_el = 4 * (lane & 7);
+        const int f4_l = f4_rl * PO + f4_rl + f4_el, f4_g = f4_rl * ld + f4_el, f4_s = f4_rl + f4_el;
 
         // Chunk c of this strip touches only real cells of a full, unmasked strip: no masking needed.
         auto chunk_interior = [&](int c) { return plain_strip && c * K >= 63 && c * K + K < m; };
@@ -1958,7 +1967,31 @@ __device__ __forceinline__ void sweep(const Params &p)
                     // per-lane tests, the global offset is one per-lane base plus a scalar, the LDS index one per-lane base plus a
                     // constant -- no vector arithmetic at all when the chunk has parity 0, a compare-and-select per row class when 1
                     const bool flush_plain = active && rows == 64 && t0 >= K && t0 + K <= m;
-                    if (flush_plain && SDP_FLUSH_FAST) {
+                    if (flush_plain && SDP_FLUSH_FAST && SDP_FLUSH4 && !PIPE) {
+                        if (zero) flush_zero8(t0);
+                        else {
+                            float2 vals[K / 2];
+#pragma unroll
+                            for (int k4 = 0; k4 < K / 4; ++k4)
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) {
+                                    const int cc = 4 * (k4 & 3) + 32 * (k4 >> 2);
+                                    const int sfull = 4 * (k4 & 3) + f4_s + 2 * j;
+                                    const int idx = cc * PO + 4 * (k4 & 3) + f4_l + 2 * j + (par ? (sfull < K - 1 ? K : -K) : 0);
+                                    vals[2 * k4 + j] = *reinterpret_cast<const float2 *>(__builtin_assume_aligned(lds_out + idx, 8));
+                                }
+#pragma unroll
+                            for (int k4 = 0; k4 < K / 4; ++k4) {
+                                typedef unsigned u32x4f __attribute__((ext_vector_type(4)));
+                                const int cc = 4 * (k4 & 3) + 32 * (k4 >> 2);
+                                const float2 v0 = vals[2 * k4], v1 = vals[2 * k4 + 1];
+                                if constexpr (ABL_NOSTORE) { keep(vals[2 * k4].x); keep(vals[2 * k4 + 1].y); }
+                                else __builtin_amdgcn_raw_buffer_store_b128((u32x4f){__float_as_uint(v0.x), __float_as_uint(v0.y), __float_as_uint(v1.x), __float_as_uint(v1.y)},
+                                                                            rs_out, (unsigned)(f4_g * 4), ubase + (cc * ld - 32 * (k4 >> 2)) * 4, AUX_OUT_STORE);
+                            }
+                        }
+                        if constexpr (LAZY && !PIPE) __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8): everything older than these K / 4 stores
+                    } else if (flush_plain && SDP_FLUSH_FAST) {
                         float2 vals[K / 2];
                         const int thr_l = K - 1 - f2_rl - f2_el;   // (k2 & 7) < thr_l  <=>  sfull < K - 1
                         if (zero) {
