@@ -111,6 +111,9 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #ifndef SDP_LINES
 #define SDP_LINES 1  // throughput forward build: line-aligned input blocks (see "Staged INPUT geometry")
 #endif
+#ifndef SDP_LINES_AUX
+#define SDP_LINES_AUX 2   // policy bits of those loads (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
 #ifndef SDP_LINES_NT
 #define SDP_LINES_NT 1  // line-aligned input blocks are touched once: stream them past the caches
 #endif
@@ -192,7 +195,7 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #endif
 constexpr int AUX_ST_STORE = SDP_AUX_ST_STORE, AUX_ST_LOAD = SDP_AUX_ST_LOAD;
 #ifndef SDP_AUX_OUT_STORE   // explicit policy bits of the staged output stores (E, Ed)
-#define SDP_AUX_OUT_STORE ((SDP_NT & 8) ? 2 : 0)
+#define SDP_AUX_OUT_STORE ((SDP_NT & 8) ? 18 : 0)   // nt sc1 (round 5, steady state: fwd;bwd 292.0 -> 288.5 us on one box, 272.3 -> 271.0 on another, 512 x 512^2 587.4 -> 581.7; plain nt was round 4's choice; anything without nt: backward -15 us, the next forward +31)
 #endif
 constexpr int AUX_IN_LOAD = (SDP_NT & 4) ? 2 : 0, AUX_OUT_STORE = SDP_AUX_OUT_STORE;
 constexpr bool ABL_NOSTORE = (SDP_ABL & 1) != 0;
@@ -1241,7 +1244,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                     } else {
                         // each dword is range-checked on its own (tools/ubench/bufx4.hip), and only dword
                         // alignment is needed, so M need not be a multiple of 4
-                        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_in[q], off, plain ? ubase - bias : 0, (LINES && SDP_LINES_NT) ? 2 : AUX_IN_LOAD);
+                        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_in[q], off, plain ? ubase - bias : 0, (LINES && SDP_LINES_NT) ? SDP_LINES_AUX : AUX_IN_LOAD);
                         const unsigned v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
                         rs[RS][q][4 * i] = __uint_as_float(v0);
                         rs[RS][q][4 * i + 1] = __uint_as_float(v1);

@@ -15,9 +15,13 @@ libs = {"main": os.path.join(gpu_tune.ROOT, "deepblast_amd", "libsdp_hip.so")}
 for p in sorted(glob.glob(os.path.join(gpu_tune.ROOT, "build_variants", "libsdp_*.so"))):
     libs[os.path.basename(p)[7:-3]] = p
 arg = {a.split("=")[0]: a.split("=")[1] for a in sys.argv[1:] if "=" in a}
+if arg.get("EXP"):   # EXP=1: the experiments build too (DBG=n: its sdp_set_debug mask -- 1 inputs, 2 outputs, 4 state aliased to pair 0)
+    libs["exp"] = os.path.join(gpu_tune.ROOT, "deepblast_amd", "libsdp_hip_exp.so")
 if "only" in arg:
-    libs = {k: v for k, v in libs.items() if k == "main" or k in arg["only"].split(",")}
+    libs = {k: v for k, v in libs.items() if k in ("main", "exp") or k in arg["only"].split(",")}
 L = {k: gpu_tune.load(v) for k, v in libs.items()}
+if arg.get("DBG"):
+    gpu_tune.set_debug(L["exp"], int(arg["DBG"], 0))
 shapes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:] if "x" in a and "=" not in a] or [(256, 512, 512)]
 ROUNDS, ITERS = int(arg.get("ROUNDS", 5)), int(arg.get("ITERS", 200))
 WF, WB = int(arg.get("WF", 0)), int(arg.get("WB", 0))
