@@ -26,7 +26,8 @@ shapes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:] if "x" in a 
 ROUNDS, ITERS = int(arg.get("ROUNDS", 5)), int(arg.get("ITERS", 200))
 WF, WB = int(arg.get("WF", 0)), int(arg.get("WB", 0))
 FLAGS_B = int(arg.get("BFLAGS", "0"), 0)   # e.g. BFLAGS=0x800: SDP_NO_ZERO_SKIP
-XS = 0x100 if arg.get("X") else 0            # X=1: the exact (float2) state of the training path (SDP_EXACT_STATE)
+XS = 0x100 if (arg.get("X") or arg.get("ADJ")) else 0            # X=1: the exact (float2) state of the training path (SDP_EXACT_STATE)
+ADJ = bool(arg.get("ADJ"))   # ADJ=1: the four sweeps of a training step (exact forward, exact backward, adjoint forward, adjoint backward)
 for (B, N, M) in shapes:
     th, A = datagen.theta_A(1, min(B, 64), N, M)
     reps = (B + th.shape[0] - 1) // th.shape[0]
@@ -35,11 +36,20 @@ for (B, N, M) in shapes:
     vt, et, E = torch.empty(B, device="cuda"), torch.ones(B, device="cuda"), torch.empty(B, N, M, device="cuda")
     st = torch.empty(max((l.sdp_state_d_bytes(B, N, M) if XS else l.sdp_state_bytes(B, N, M)) for l in L.values()) // 4, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    if ADJ:
+        std = torch.empty(max(l.sdp_state_d_bytes(B, N, M) for l in L.values()) // 4, device="cuda")
+        Ed, z = torch.empty(B, N, M, device="cuda"), torch.randn(B, N, M, device="cuda")
     fn = {}
     for k, l in L.items():
         f = (lambda l: lambda: l.sdp_forward_f32(t.data_ptr(), a.data_ptr(), st.data_ptr(), vt.data_ptr(), B, N, M, None, ((WF & 0xf) << 12) | XS, 0, stream))(l)
         b = (lambda l: lambda: l.sdp_backward_f32(et.data_ptr(), st.data_ptr(), E.data_ptr(), B, N, M, None, ((WB & 0xf) << 12) | FLAGS_B | XS, 0, stream))(l)
         assert f() == 0 and b() == 0
+        if ADJ:   # "b" becomes: exact backward, adjoint forward, adjoint backward
+            b0 = b
+            af = (lambda l: lambda: l.sdp_adjoint_forward_f32(st.data_ptr(), z.data_ptr(), None, vt.data_ptr(), std.data_ptr(), B, N, M, None, 0, 0, stream))(l)
+            ab = (lambda l: lambda: l.sdp_adjoint_backward_f32(E.data_ptr(), st.data_ptr(), std.data_ptr(), Ed.data_ptr(), B, N, M, None, 0, 0, stream))(l)
+            assert af() == 0 and ab() == 0
+            b = (lambda b0, af, ab: lambda: (b0(), af(), ab()))(b0, af, ab)
         fn[k] = (f, b)
     res = {k: {"seq": [], "f": [], "b": []} for k in L}
     for k, (f, b) in fn.items():     # warm: 100 iterations each, back to back
