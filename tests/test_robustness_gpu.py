@@ -342,3 +342,44 @@ def test_zero_chunks_of_the_adjoint_backward_sweep_do_not_change_a_bit():
         assert not (outs[0] == np.int32(-2**31)).any()      # no -0 in Ed
         nzero += int((outs[0] == 0).sum())
     assert nzero > 0
+
+
+def test_the_two_builds_of_the_packed_backward_sweep_agree_bit_for_bit():
+    """Round 5: the packed backward sweep exists twice -- `sdp_bwd_kernel` and `sdp_bwd_pipe_kernel` (the chunk as one software
+    pipeline) -- and the launch plan takes the second only where every CU holds one pair of long rows (sdp_api.hip: bwd_pipe_pays).
+    Which build a pair meets depends on the BATCH it arrives in, so the two must agree as bit patterns: the same pairs swept as one
+    batch of 256 (pipelined build) and as two batches of 128 (the other one), soft and steep scores, NW and SW, and with the
+    zero-chunk skip switched off."""
+    from deepblast_amd import _lib
+    from deepblast_amd._engine import get_engine
+    lib = get_engine().lib
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(0).cuda_stream
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    B, N, M = cus, 512, 1024
+
+    def plan_id(b):
+        kid, chunk, waves, lds = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
+        assert lib.sdp_plan(1, b, N, M, 0, 0, cus, ctypes.byref(kid), ctypes.byref(chunk), ctypes.byref(waves), ctypes.byref(lds)) == 0
+        return kid.value
+    assert plan_id(B) == 36 and plan_id(B // 2) == 1, (plan_id(B), plan_id(B // 2))
+    for ci, (variant, steep, flag) in enumerate([(0, 1.0, 0), (1, 6.0, 0), (0, 3.0, _lib.SDP_NO_ZERO_SKIP)]):
+        th, A = datagen.theta_A(5900 + ci, 32, N, M)
+        th = th * np.float32(steep)
+        t = torch.from_numpy(np.tile(th, (B // 32, 1, 1))).to(dev)
+        a = torch.from_numpy(np.tile(A, (B // 32, 1, 1))).to(dev)
+        et = torch.from_numpy((datagen.uniform(5950 + ci, (B,)) + np.float32(0.5))).to(dev)
+        E1 = torch.full((B, N, M), float("nan"), device=dev)
+        E2 = torch.full((B, N, M), float("nan"), device=dev)
+        vt1, vt2 = torch.empty(B, device=dev), torch.empty(B, device=dev)
+        st = torch.empty(lib.sdp_state_bytes(B, N, M) // 4 + 1, dtype=torch.float32, device=dev)
+        assert lib.sdp_forward_f32(t.data_ptr(), a.data_ptr(), st.data_ptr(), vt1.data_ptr(), B, N, M, None, variant, 0, stream) == 0, lib.sdp_last_error_string()
+        assert lib.sdp_backward_f32(et.data_ptr(), st.data_ptr(), E1.data_ptr(), B, N, M, None, variant | flag, 0, stream) == 0, lib.sdp_last_error_string()
+        h = B // 2
+        for lo in (0, h):
+            assert lib.sdp_forward_f32(t[lo:].data_ptr(), a[lo:].data_ptr(), st.data_ptr(), vt2[lo:].data_ptr(), h, N, M, None, variant, 0, stream) == 0
+            assert lib.sdp_backward_f32(et[lo:].data_ptr(), st.data_ptr(), E2[lo:].data_ptr(), h, N, M, None, variant | flag, 0, stream) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(vt1.view(torch.int32), vt2.view(torch.int32)), ci
+        assert torch.equal(E1.view(torch.int32), E2.view(torch.int32)), (ci, int((E1.view(torch.int32) != E2.view(torch.int32)).sum()))
+        assert bool(torch.isfinite(E1).all())
