@@ -1693,7 +1693,13 @@ __device__ __forceinline__ void sweep(const Params &p)
                         float d = __builtin_amdgcn_ldexpf(cy.da, cy.de - R);
                         const float xz = __builtin_amdgcn_ldexpf(EXP_ONE_A, EXP_ONE_E - R);  // V = 0 in this frame
                         const int Rn = dpp_i32<DPP_IN>(R, R);
-                        const float sc = __builtin_amdgcn_ldexpf(1.f, Rn - R);
+                        // The neighbour's value enters this lane's frame as ldexp(ua, Rn - R) -- NOT as ua * 2^(Rn - R): the factor
+                        // alone underflows to zero for Rn - R < -149 while the product need not (ua reaches 2^110 in its own frame,
+                        // and lane 0's frame is the PRODUCER's, which may lie far from its own exponent).  Found by the 1200-case
+                        // soak of round 5 (tools/cases/fuzz2_1172.npz: SW, theta x 8, 71 x 81, one pair of 133, plane starting 3
+                        // floats off a 16-byte boundary: lane 1's `up` weight at (65, 79) came out 0 instead of 0.975, Vt off by
+                        // 0.033, E by 5e-3; present since the windowed form exists).  Same bits wherever nothing underflowed.
+                        const int dR = Rn - R;
                         unsigned mx = max(__float_as_uint(x), __float_as_uint(d)), mn = 0x3f800000u, mc = 0;
                         if (!EDGE || tb > thr) mn = __float_as_uint(x);  // a value that is not live yet may be arbitrarily small
                         float bf[WB];  // lane 0's `up` values in its frame
@@ -1733,7 +1739,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         for (int j = 0; j < WB; ++j) {
                             const float ct = ctv[j], ca = cav[j];
                             const float ua = __uint_as_float(dpp_i32<DPP_IN>(__float_as_int(bf[j]), __float_as_int(x)));
-                            const float u = ua * sc;
+                            const float u = __builtin_amdgcn_ldexpf(ua, dR);
                             const float ssum = __builtin_fmaf(ca, u + x, d);
                             const float rinv = __builtin_amdgcn_rcpf(ssum);
                             const float tq = ca * rinv;
@@ -1884,13 +1890,21 @@ __device__ __forceinline__ void sweep(const Params &p)
                     };
 
                     bool done = false;
-                    if (wf_skip == 0) {
+                    // (experiments build: sdp_set_debug bits 16-23 = 1 + block, bits 24-30 = strip position: that block runs in the normalised form)
+                    const bool dbg_norm = SDP_EXP_BUILD && ((p.dbg >> 16) & 0xff) == (unsigned)(tb / WB + 1) && ((p.dbg >> 24) & 0x7f) == (unsigned)sidx;
+                    int dbg_code = wf_skip > 0 ? 8 : 0;
+                    if (wf_skip == 0 && !dbg_norm) {
                         const int rc = use_pred ? (blk_interior ? wf_block(std::false_type{}, std::true_type{}) : wf_block(std::true_type{}, std::true_type{}))
                                                 : (blk_interior ? wf_block(std::false_type{}, std::false_type{}) : wf_block(std::true_type{}, std::false_type{}));
                         done = rc > 0;
+                        dbg_code = rc > 0 ? 1 : (rc < 0 ? 2 : 4);
                         if (rc < 0) wf_skip = 2;  // values move too fast for one frame per block here: try again two blocks later (the same in every build)
-                    } else {
+                    } else if (wf_skip > 0) {
                         --wf_skip;
+                    }
+                    if constexpr (SDP_EXP_BUILD != 0) {   // which form the block ran in: 1 windowed, 2 out of range, 4 not applicable (frames), 8 skipped after a failure, 0 forced
+                        if (p.trace && !(p.dbg & 1024) && (b & 63) == 0 && b < 256 && lane == 0 && (parts ? part < 4 : sidx / W < 2) && tb / WB < 40)
+                            p.trace[((((b >> 6) * 4 + wave) * 4 + (parts ? part : sidx / W)) * 40 + tb / WB) * 8 + 6] = 100 + dbg_code;
                     }
                     if (!done) {
                         if (blk_interior) norm_block(std::false_type{});
@@ -2899,7 +2913,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                     float d = __builtin_amdgcn_ldexpf(cy.da, cy.de - R);
                     const float xz = __builtin_amdgcn_ldexpf(EXP_ONE_A, EXP_ONE_E - R);  // V = 0 in this frame
                     const int Rn = dpp_i32<DPP_IN>(R, R);
-                    const float sc = __builtin_amdgcn_ldexpf(1.f, Rn - R);
+                    const int dR = Rn - R;   // (see fwd_blocks: the neighbour's value is rescaled with ldexp, the factor alone can underflow)
                     unsigned mx = max(__float_as_uint(x), __float_as_uint(d)), mn = 0x3f800000u, mc = 0;
                     if (!EDGE || tb > thr) mn = __float_as_uint(x);  // a value that is not live yet may be arbitrarily small
                     float bf[WB];  // lane 0's `up` values in its frame
@@ -2917,7 +2931,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         const float ct = __builtin_amdgcn_exp2f(in0[k] * 1.44269504088896340736f);
                         const float ca = __builtin_amdgcn_exp2f(in1[k] * 1.44269504088896340736f);
                         const float ua = __uint_as_float(dpp_i32<DPP_IN>(__float_as_int(bf[j]), __float_as_int(x)));
-                        const float u = ua * sc;
+                        const float u = __builtin_amdgcn_ldexpf(ua, dR);
                         const float ssum = __builtin_fmaf(ca, u + x, d);
                         const float rinv = __builtin_amdgcn_rcpf(ssum);
                         const float tq = ca * rinv;

@@ -11,8 +11,9 @@ with one launch of a hand-written batched GEMM on the matrix cores whose epilogu
 f32-input MFMA for ragged D).  Differentiable: the backward needs no saved
 pre-activations -- d softplus(s)/ds = sigmoid(s) = 1 - exp(-theta) and d logsigmoid(s)/ds = 1 - exp(A) -- and
 forms the gradients of the embeddings with the same three-piece product (`sdp_scores_backward_f32`: the two contractions
-per tensor run over the ROWS of the tensors as they lie in memory, no transposed copies); shapes it does not take
-(M or D not a multiple of 4) use library GEMMs (torch.bmm).
+per tensor run over the ROWS of the tensors as they lie in memory, no transposed copies); ragged widths (M or D not a
+multiple of 4) are padded with zeros on the way in, unaligned views copied; only a few very large pairs -- too few tiles to
+fill the chip -- are left to library GEMMs (torch.bmm).
 """
 import torch
 
@@ -58,7 +59,7 @@ class _Scores(torch.autograd.Function):
 
 
 def _torch_backward(zx, zy, gx, gy, theta, A, g_theta, g_A):
-    """Library GEMMs (torch.bmm) -- shapes the native kernels do not take (M or D not a multiple of 4, unaligned views)."""
+    """Library GEMMs (torch.bmm) -- what `_native_backward_ok` leaves to them: a few very large pairs, oversized grids."""
     out = [None, None, None, None]
     if g_theta is not None:
         ds = g_theta * (-torch.expm1(-theta))            # sigmoid(s) = 1 - exp(-softplus(s)); expm1: no cancellation for small theta
@@ -70,9 +71,13 @@ def _torch_backward(zx, zy, gx, gy, theta, A, g_theta, g_A):
 
 
 def _native_backward_ok(zx, zy, g_theta, g_A):
+    """Does the backward run on the native kernels?  Ragged widths (M or D not a multiple of 4) and unaligned views do -- padded /
+    copied by `_native_backward`; what is left to the library GEMMs: a few very large pairs (below), grids beyond 65535, other
+    dtypes or devices."""
     B, N, D = zx.shape
     M = zy.shape[1]
-    if M % 4 or D % 4 or 2 * B > 65535 or max(N * M, N * D, M * D) > (1 << 28):
+    M4, D4 = -(-M // 4) * 4, -(-D // 4) * 4
+    if 2 * B > 65535 or max(N * M4, N * D4, M4 * D4) > (1 << 28):
         return False
     # one workgroup per 256 x 256 tile of an output: a few large pairs leave most CUs idle (4 x 2000 x 2000 x 256: 542 us
     # against 431 us for the library GEMMs; everything else measured was faster or equal, tools/scores_bwd_shapes.py)
@@ -82,26 +87,58 @@ def _native_backward_ok(zx, zy, g_theta, g_A):
     return all(g is None or (g.dtype == torch.float32 and g.device == zx.device) for g in (g_theta, g_A))
 
 
+def _pad_last(t, to):
+    """(…, n) -> (…, to) with zeros behind (a fresh, aligned tensor); None stays None."""
+    if t is None or t.shape[-1] == to:
+        return t
+    out = t.new_zeros(t.shape[:-1] + (to,))
+    out[..., :t.shape[-1]] = t
+    return out
+
+
+def _pad_rows(t, to):
+    """(B, n, D) -> (B, to, D) with zero rows behind."""
+    if t is None or t.shape[1] == to:
+        return t
+    out = t.new_zeros((t.shape[0], to, t.shape[2]))
+    out[:, :t.shape[1]] = t
+    return out
+
+
 def _native_backward(zx, zy, gx, gy, theta, A, g_theta, g_A):
     """sdp_scores_backward_f32: dS = g * dact/ds in one pass, then the two products per tensor on the bf16 pipe with exact
-    three-piece operands (fp32 accuracy) -- one launch per side for both tensors (deepblast_amd/csrc/sdp_scores.hip)."""
+    three-piece operands (fp32 accuracy) -- one launch per side for both tensors (deepblast_amd/csrc/sdp_scores.hip).
+
+    The kernels take M and D in multiples of 4 and 16-byte aligned tensors.  Ragged shapes -- the usual case: M is the longest
+    sequence of the batch -- are padded with zeros here (columns of g, theta, A and rows of zy / gy for M; columns of the four
+    embeddings for D: a zero cotangent column contributes nothing, a zero embedding column neither) and the results sliced;
+    views that are not aligned are copied.  Round 5: until then such shapes went to torch.bmm."""
     eng = get_engine()
     dev = eng._dev(zx)
     B, N, D = zx.shape
     M = zy.shape[1]
+    M4, D4 = -(-M // 4) * 4, -(-D // 4) * 4
     gt = None if g_theta is None else g_theta.contiguous()
     ga = None if g_A is None else g_A.contiguous()
-    ws = torch.empty(eng.lib.sdp_scores_backward_ws_bytes(B, N, M) // 4, dtype=torch.float32, device=zx.device)
+    if M4 != M:
+        gt, ga, theta, A = (_pad_last(t, M4) for t in (gt, ga, theta, A))
+        zy, gy = _pad_rows(zy, M4), _pad_rows(gy, M4)
+    if D4 != D:
+        zx, zy, gx, gy = (_pad_last(t, D4) for t in (zx, zy, gx, gy))
+    aligned = lambda t: t if (t is None or (t.is_contiguous() and (t.data_ptr() & 15) == 0)) else t.clone(memory_format=torch.contiguous_format)
+    gt, ga, theta, A, zx, zy, gx, gy = (aligned(t) for t in (gt, ga, theta, A, zx, zy, gx, gy))
+    ws = torch.empty(eng.lib.sdp_scores_backward_ws_bytes(B, N, M4) // 4, dtype=torch.float32, device=zx.device)
     new = lambda like: torch.empty_like(like)
     dzx, dzy = (new(zx), new(zy)) if gt is not None else (None, None)
     dgx, dgy = (new(gx), new(gy)) if ga is not None else (None, None)
     tensors = (gt, ga, theta, A, zx, zy, gx, gy, ws, dzx, dzy, dgx, dgy)
-    if any(t is not None and (t.data_ptr() & 15) for t in tensors):
-        return _torch_backward(zx, zy, gx, gy, theta, A, g_theta, g_A)
+    if any(t is not None and (t.data_ptr() & 15) for t in tensors):   # (cannot happen with torch's allocator; never a silent wrong launch)
+        raise RuntimeError("deepblast_amd.scores: a tensor of the native backward is not 16-byte aligned")
     with torch.cuda.device(dev), eng._bracket("sdp_scores_bwd"):
-        rc = eng.lib.sdp_scores_backward_f32(*[_ptr(t) for t in tensors], B, N, M, D, dev, eng._stream(dev))
+        rc = eng.lib.sdp_scores_backward_f32(*[_ptr(t) for t in tensors], B, N, M4, D4, dev, eng._stream(dev))
     _lib.check(rc, "sdp_scores_backward_f32")
-    return dzx, dzy, dgx, dgy
+    cut = lambda t, rows: None if t is None else (t[:, :rows, :D] if (t.shape[1] != rows or D4 != D) else t)
+    return cut(dzx, N), cut(dzy, M), cut(dgx, N), cut(dgy, M)
 
 
 def alignment_scores(zx, zy, gx, gy):

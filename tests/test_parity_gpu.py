@@ -837,3 +837,37 @@ def test_pairs_spread_over_several_workgroups(case):
         assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), (case, exact)
         if all(eng.lib.sdp_plan_parts(p_, B, N, M, int(use_lens), int(exact), 256) == 4 for p_ in (0, 1)):   # what the library does by itself
             assert torch.equal(res[1][0], out[exact][0]) and torch.equal(res[1][1], out[exact][2]), (case, exact)
+
+
+@pytest.mark.parametrize("offset", [0, 1, 2, 3, 7, 19], ids=lambda o: f"plane+{o}floats")
+def test_soak_case_of_round_5_neighbour_frames_far_apart(offset):
+    """Found by the 1200-case soak of round 5 (tools/fuzz2.py case 1172, pair 37 of 133: Smith-Waterman, theta x 8, A = 0, 71 x 81):
+    the windowed forward form rescaled a neighbour's value as ua * 2^(Rn - R), and the factor alone underflowed to zero where lane
+    0's frame -- the producer strip's -- lay far below lane 1's: the `up` weight of cell (65, 79) came out 0 instead of 0.975, Vt
+    was off by 0.033 and E by 5e-3.  Which blocks run in the windowed form depends on what lies beside the matrix in memory, so the
+    case needs its plane to start 3 floats off a 16-byte boundary: every offset is run.  (tests/golden/r5_soak_case1172_pair37.npz
+    holds the pair's scores as the fuzz generated them; expected values: the oracle.)"""
+    import torch
+    from deepblast_amd._engine import get_engine
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "r5_soak_case1172_pair37.npz"))
+    theta, A, Et, variant = d["theta"], d["A"], d["Et"], int(d["variant"])
+    ref = parity.oracle_all(theta, A, Et, None, variant, omp=False)
+    lib = get_engine().lib
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(0).cuda_stream
+    B, N, M = theta.shape
+    for waves in (0, 1, 4):
+        buf_t = torch.zeros(theta.size + 64, device=dev)
+        buf_a = torch.zeros(theta.size + 64, device=dev)
+        t = buf_t[offset:offset + theta.size].view(B, N, M)
+        a = buf_a[offset:offset + theta.size].view(B, N, M)
+        t.copy_(torch.from_numpy(theta)), a.copy_(torch.from_numpy(A))
+        et = torch.from_numpy(Et).to(dev)
+        st = torch.empty(lib.sdp_state_bytes(B, N, M) // 4 + 64, device=dev)
+        vt = torch.empty(B, device=dev)
+        E = torch.full((B, N, M), float("nan"), device=dev)
+        assert lib.sdp_forward_f32(t.data_ptr(), a.data_ptr(), st.data_ptr(), vt.data_ptr(), B, N, M, None, variant | (waves << 12), 0, stream) == 0
+        assert lib.sdp_backward_f32(et.data_ptr(), st.data_ptr(), E.data_ptr(), B, N, M, None, variant | (waves << 12), 0, stream) == 0
+        torch.cuda.synchronize()
+        assert parity.rel_err(vt.cpu().numpy(), ref["Vt"]) <= 1e-6, (offset, waves, float(vt[0]), float(ref["Vt"][0]))
+        assert parity.abs_err(E.cpu().numpy(), ref["E"]) <= parity.TOL, (offset, waves)

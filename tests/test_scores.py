@@ -139,7 +139,8 @@ def test_scores_feed_the_dp():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(256, 512, 512, 512), (3, 130, 260, 48), (2, 300, 128, 100), (1, 1, 2048, 8), (5, 257, 516, 20), (4, 600, 36, 64)],
+@pytest.mark.parametrize("shape", [(256, 512, 512, 512), (3, 130, 260, 48), (2, 300, 128, 100), (1, 1, 2048, 8), (5, 257, 516, 20), (4, 600, 36, 64),
+                                   (2, 50, 33, 24), (3, 70, 129, 30), (2, 65, 255, 7), (1, 3, 1, 1)],   # (round 5: ragged M / D, padded on the way in)
                          ids=lambda s: "x".join(map(str, s)))
 def test_native_backward_matches_float64_autograd(shape):
     """sdp_scores_backward_f32 (dS pass + two three-piece products per tensor whose contractions run over the rows of the
@@ -192,17 +193,39 @@ def test_native_backward_matches_float64_autograd(shape):
 
 
 @pytest.mark.gpu
-def test_backward_shapes_the_native_kernels_do_not_take_use_the_library():
+def test_backward_ragged_shapes_and_views_run_native_and_what_is_left_to_the_library():
+    """Round 5: M or D not a multiple of 4 and unaligned views no longer leave the native kernels (padded / copied in
+    `_native_backward`; the C entry point itself still refuses them); the library GEMMs keep a few very large pairs."""
     import torch
+    import torch.nn.functional as F
     from deepblast_amd import scores as sc
     B, N, M, D = 2, 50, 33, 24   # M not a multiple of 4
-    t = [torch.from_numpy((datagen.normal(820 + i, (B, n, D)) / np.sqrt(D)).astype(np.float32)).cuda().requires_grad_() for i, n in enumerate((N, M, N, M))]
-    assert not sc._native_backward_ok(t[0], t[1], None, None)
-    theta, A = sc.alignment_scores(*t)
-    (theta.sum() + A.sum()).backward()
-    assert all(x.grad is not None and torch.isfinite(x.grad).all() for x in t)
+    base = [torch.from_numpy((datagen.normal(820 + i, (B, n + 1, D + 1)) / np.sqrt(D)).astype(np.float32)).cuda() for i, n in enumerate((N, M, N, M))]
+    views = [b[:, 1:, 1:] for b in base]               # neither contiguous nor 16-byte aligned
+    assert all((v.data_ptr() & 15) != 0 and not v.is_contiguous() for v in views)
+    t = [v.detach().requires_grad_() for v in views]
+    assert sc._native_backward_ok(t[0], t[1], None, None)
+    calls = []
+    orig = sc._native_backward
+    sc._native_backward = lambda *a: (calls.append(1), orig(*a))[1]
+    try:
+        theta, A = sc.alignment_scores(*t)
+        (theta.sum() + A.sum()).backward()
+    finally:
+        sc._native_backward = orig
+    assert calls == [1]
+    t64 = [v.detach().double().requires_grad_() for v in views]
+    (F.softplus(torch.einsum("bid,bjd->bij", t64[0], t64[1])).sum() + F.logsigmoid(torch.einsum("bid,bjd->bij", t64[2], t64[3])).sum()).backward()
+    for x, r in zip(t, t64):
+        assert x.grad is not None and x.grad.shape == r.grad.shape
+        assert float((x.grad.double() - r.grad).abs().max()) <= 2e-6 * max(1.0, float(r.grad.abs().max()))
+    # the C entry point takes multiples of 4 only: an error code, not a launch
     eng_lib = sc.get_engine().lib
     ws = torch.empty(8, device="cuda")
-    rc = eng_lib.sdp_scores_backward_f32(theta.data_ptr(), None, theta.data_ptr(), None, t[0].data_ptr(), t[1].data_ptr(), None, None, ws.data_ptr(),
-                                         t[0].data_ptr(), t[1].data_ptr(), None, None, B, N, M, D, 0, None)
-    assert rc != 0   # SDP_E_SHAPE, not a launch
+    tc = [x.detach().contiguous() for x in t]
+    rc = eng_lib.sdp_scores_backward_f32(theta.data_ptr(), None, theta.data_ptr(), None, tc[0].data_ptr(), tc[1].data_ptr(), None, None, ws.data_ptr(),
+                                         tc[0].data_ptr(), tc[1].data_ptr(), None, None, B, N, M, D, 0, None)
+    assert rc != 0   # SDP_E_SHAPE
+    # a few very large pairs: too few tiles for the chip, left to the library GEMMs
+    big = [torch.empty(4, n, 256, device="cuda") for n in (2000, 2000)]
+    assert not sc._native_backward_ok(big[0], big[1], None, None)

@@ -28,14 +28,23 @@ for it in range(n):
         A[rng.random(A.shape) < 0.2] = -np.inf
     Z = datagen.normal(60000 + it, (B, N, M))
     use_lens = bool(rng.integers(0, 2))
+    # (every random draw of the case BEFORE any work: FUZZ_ONLY=<it> then reproduces one case of a long run in seconds)
+    lens = ZA = Et = None
+    if use_lens:
+        lens = np.stack([rng.integers(1, N + 1, B), rng.integers(1, M + 1, B)], axis=1).astype(np.int32)
+    else:
+        # a third of the padded cases also seed the gap scores' direction (ZA) and a random upstream factor Et
+        ZA = datagen.normal(70000 + it, (B, N, M)) if rng.integers(0, 3) == 0 else None
+        Et = rng.normal(size=B).astype(np.float32) if rng.integers(0, 3) == 0 else None
+    if os.environ.get("FUZZ_ONLY") and it != int(os.environ["FUZZ_ONLY"]):
+        continue
+    if os.environ.get("FUZZ_DUMP"):
+        np.savez(os.environ["FUZZ_DUMP"], theta=theta, A=A, Z=Z, variant=variant, lens=lens if lens is not None else np.zeros(0), ZA=ZA if ZA is not None else np.zeros(0),
+                 Et=Et if Et is not None else np.zeros(0))
     try:
         if use_lens:
-            lens = np.stack([rng.integers(1, N + 1, B), rng.integers(1, M + 1, B)], axis=1).astype(np.int32)
             ref = parity.oracle_lens(theta, A, None, Z, variant, lens); got = parity.engine_all(theta, A, None, Z, variant, lens=lens)
         else:
-            # a third of the padded cases also seed the gap scores' direction (ZA) and a random upstream factor Et
-            ZA = datagen.normal(70000 + it, (B, N, M)) if rng.integers(0, 3) == 0 else None
-            Et = rng.normal(size=B).astype(np.float32) if rng.integers(0, 3) == 0 else None
             ref = parity.oracle_all(theta, A, Et, Z, variant, ZA=ZA); got = parity.engine_all(theta, A, Et, Z, variant, ZA=ZA)
         e = parity.compare(got, ref)
     except Exception as ex:
