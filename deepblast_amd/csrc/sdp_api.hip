@@ -381,7 +381,15 @@ struct VariantBits {
 // 1e-4 bound.  Longer problems always use the exact (float2) state, whose largest weight is the complement of the other
 // two (q_sharpen): <= 1e-5 at N = 60000.  sdp_state_bytes covers either layout; forward and backward apply the same rule.
 constexpr int PACKED_MAX_PATH = 4096;
-inline bool exact_for(bool flag, int N, int M) { return flag || N + M > PACKED_MAX_PATH; }
+// Thin problems as well (round 5): with fewer than 32 rows (or columns) the rounding errors of the packed weights along the long
+// axis do not average out over many paths -- flat scores, max |dE| by shape, packed (exact), tools/thin_probe.py / profiles/
+// r05_thin.txt: 2 x 2048 1.0e-4 (4.5e-6), 4 x 2048 7.8e-5, 8 x 2048 6.1e-5, 16 x 1772 5.0e-5, 32 x 2048 3.6e-5, 64 x 2048 1.6e-5;
+// any N x 512 <= 3.0e-5.  The soak of round 5 met 1.17e-4 at 2 x 1772 (positive gap scores).  Such problems are tiny: the exact state.
+inline bool exact_for(bool flag, int N, int M)
+{
+    const int lo = N < M ? N : M, hi = N < M ? M : N;
+    return flag || N + M > PACKED_MAX_PATH || (lo < 32 && hi > 512);
+}
 
 VariantBits split_variant(int variant)
 {
@@ -561,7 +569,7 @@ size_t sdp_state_bytes(int B, int N, int M)
 {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
     // 2 x 23 bits per cell, 3 dwords per 2 cells (a 768-byte record row per pair of steps); + the launch order of a
-    // variable-length batch.  Problems longer than PACKED_MAX_PATH keep the exact state (see exact_for).
+    // variable-length batch.  Problems longer than PACKED_MAX_PATH, and thin long ones, keep the exact state (see exact_for).
     if (exact_for(false, N, M)) return sdp_state_d_bytes(B, N, M);
     return packed_body_bytes(B, N, M) + sdp::state_order_bytes(B) + bridge_bytes(B, N, M) + parts_map_bytes(B, N);
 }

@@ -38,8 +38,10 @@
  *     size of Qd); sdp_backward_f32 reads that format too when given the flag.
  *     Problems with N + M > 4096 always use the float2 form (the packed format's
  *     rounding error is carried along an alignment path like a random walk: measured
- *     <= 4e-5 of E at N = M = 2048 on soft and on steep scores, bound 1e-4):
- *     sdp_state_bytes accounts for it, and forward
+ *     <= 4e-5 of E at N = M = 2048 on soft and on steep scores, bound 1e-4),
+ *     and so do THIN long problems -- min(N, M) < 32 with max(N, M) > 512, where
+ *     those errors do not average out over many paths (2 x 2048, flat scores:
+ *     1.0e-4 packed, 4.5e-6 exact): sdp_state_bytes accounts for both, and forward
  *     and backward apply the same rule, so callers need not care.
  *   - `lens` is NULL (reference semantics: every pair uses the full padded N x M)
  *     or a DEVICE pointer to B x 2 int32 (n_b, m_b): pair b is aligned over its

@@ -107,6 +107,15 @@ def _plan(lib, pass_, B, N, M, lens=0, exact=0, cus=256):
     return kid.value, chunk.value, waves.value, lds.value
 
 
+def test_thin_long_problems_take_the_exact_state(lib):
+    """Round 5: fewer than 32 rows (or columns) with more than 512 on the other axis -- the packed weights' rounding does not
+    average out over many paths there (2 x 2048: 1.0e-4) -- use the float2 state, like problems with N + M > 4096; the sizing
+    function follows (sdp_api.hip: exact_for)."""
+    for (N, M, exact) in [(2, 1772, True), (1772, 2, True), (31, 513, True), (32, 2048, False), (31, 512, False), (64, 960, False), (7, 1361, True),
+                          (2048, 2048, False), (2049, 2048, True), (512, 512, False)]:
+        assert (lib.sdp_state_bytes(3, N, M) == lib.sdp_state_d_bytes(3, N, M)) == exact, (N, M)
+
+
 def test_launch_plan_policy(lib):
     """Which build / how many waves a launch uses, checked without a device."""
     LDS = 160 * 1024

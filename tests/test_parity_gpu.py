@@ -871,3 +871,18 @@ def test_soak_case_of_round_5_neighbour_frames_far_apart(offset):
         torch.cuda.synchronize()
         assert parity.rel_err(vt.cpu().numpy(), ref["Vt"]) <= 1e-6, (offset, waves, float(vt[0]), float(ref["Vt"][0]))
         assert parity.abs_err(E.cpu().numpy(), ref["E"]) <= parity.TOL, (offset, waves)
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 1772), (1, 1772, 3), (2, 16, 2048), (1, 31, 600)], ids=lambda s: "x".join(map(str, s)))
+def test_thin_long_problems_meet_the_bound_with_room(shape):
+    """Round 5: on thin long problems the packed state's rounding does not average out (flat scores, positive gap scores: 1.17e-4
+    at 2 x 1772 in the round's soak, 1.0e-4 at 2 x 2048 in tools/thin_probe.py); they take the exact state now: a fifth of the bound."""
+    B, N, M = shape
+    for variant in (0, 1):
+        theta, A = datagen.theta_A(8800 + N, B, N, M)
+        theta = (theta * 0.01).astype(np.float32)
+        A = (A + 0.5).astype(np.float32)
+        ref = parity.oracle_all(theta, A, None, None, variant, omp=False)
+        got = parity.engine_all(theta, A, None, None, variant)
+        errs = parity.compare(got, ref)
+        assert errs["E"] <= 0.2 * parity.TOL and errs["Vt"] <= 0.2 * parity.TOL, (shape, variant, errs)
