@@ -1837,7 +1837,11 @@ __device__ __forceinline__ void sweep(const Params &p)
                             const float l = __builtin_amdgcn_ldexpf(cy.xa, ey - er);
                             const float d = __builtin_amdgcn_ldexpf(cy.da, ed - er);
                             const float ssum = __builtin_fmaf(ca, u + l, d);  // the operand with the largest exponent is unshifted
-                            const float rinv = __builtin_amdgcn_rcpf(ssum);
+                            // (a cell nothing reaches -- forbidden gaps on every way in, the diagonal predecessor unreachable itself -- has ssum = 0:
+                            //  its weights are then 0, 0 and, by the sharpening, 1 for the diagonal, as the reference's finite -1e10 borders give them;
+                            //  1 / 0 made them NaN in the exact state, which the first-order sweeps never noticed (E is 0 there) and the adjoint sweeps
+                            //  spread over the whole pair: Vtd = NaN in 3 of 4000 cases of round 5's last soak, thin problems with 20 % forbidden gaps)
+                            const float rinv = ssum >= 1.1754944e-38f ? __builtin_amdgcn_rcpf(ssum) : 0.f;
                             const float tq = ca * rinv;
                             {
                                 float2 qq = make_float2(tq * u, tq * l);
@@ -2695,7 +2699,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         const float l = __builtin_amdgcn_ldexpf(cy.xa, ey - er);
                         const float d = __builtin_amdgcn_ldexpf(cy.da, ed - er);
                         const float ssum = __builtin_fmaf(ca, u + l, d);  // the operand with the largest exponent is unshifted
-                        const float rinv = __builtin_amdgcn_rcpf(ssum);
+                        const float rinv = ssum >= 1.1754944e-38f ? __builtin_amdgcn_rcpf(ssum) : 0.f;   // (see norm_block: a cell nothing reaches)
                         const float tq = ca * rinv;
                         {
                             float2 qq = make_float2(tq * u, tq * l);

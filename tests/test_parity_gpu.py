@@ -886,3 +886,23 @@ def test_thin_long_problems_meet_the_bound_with_room(shape):
         got = parity.engine_all(theta, A, None, None, variant)
         errs = parity.compare(got, ref)
         assert errs["E"] <= 0.2 * parity.TOL and errs["Vt"] <= 0.2 * parity.TOL, (shape, variant, errs)
+
+
+@pytest.mark.parametrize("which", ["a", "b"])
+def test_soak_cases_of_round_5_cells_that_nothing_reaches(which):
+    """Found by the last soak of round 5 (tools/fuzz2.py 2000 11 / 12: 3 of 4000 cases): thin problems (3 rows) with a fifth of
+    their gap scores -inf have cells that nothing reaches -- every way in is a forbidden gap and the diagonal predecessor is
+    unreachable itself.  Their sum of three was 0, their weights 0 * (1 / 0) = NaN in the exact state; the first-order sweeps
+    never noticed (E is 0 there), the adjoint sweeps spread the NaN over the whole pair (Vtd = NaN, Ed = NaN).  The reference
+    works with finite -1e10 borders and gets weights (0, 1, 0) there.  Fixture: the two pairs as the fuzz generated them
+    (one with a per-pair Et, one with a ZA seed); expected: the oracle, every output finite and inside the bound."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "r5_soak_unreachable_cells.npz"))
+    theta, A, Z, variant = d[f"theta_{which}"], d[f"A_{which}"], d[f"Z_{which}"], int(d[f"variant_{which}"])
+    Et = d["Et_a"] if which == "a" else None
+    ZA = d["ZA_b"] if which == "b" else None
+    assert np.isneginf(A).sum() > 100
+    ref = parity.oracle_all(theta, A, Et, Z, variant, ZA=ZA, omp=False)
+    got = parity.engine_all(theta, A, Et, Z, variant, ZA=ZA)
+    for k in ("Vt", "E", "Ed", "Vtd"):
+        assert np.isfinite(got[k]).all(), k
+    _assert(parity.compare(got, ref), f"unreachable cells, case {which}")
