@@ -11,8 +11,9 @@ that collects the terminal scores Vt from all ranks (--gather e also gathers E).
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the mode (the one with the longest
 mean launch; sdp_fwd_kernel in the headline mode): algorithmic bytes (12 B per cell-update for the forward
 and backward sweeps, 32 B for each adjoint sweep; flops on the matrix pipe when the scores
-GEMM dominates) over its mean launch duration measured with HIP events on the launch stream inside the
-timed region.  `cpu_baseline` is the CPU oracle (a port of
+GEMM dominates) over its mean launch duration measured with HIP events on the launch stream, in a loop of the
+same step that runs right BEHIND the timed region (round 6: the timed region itself carries no instrument at
+any --steps -- an event record costs the stream ~6 us, tools/gap_probe.py).  `cpu_baseline` is the CPU oracle (a port of
 deepblast/nw.py, oracle/sdp_oracle.c) timed on this box's host cores, rank 0 at N=1 only.
 """
 import argparse
@@ -61,11 +62,12 @@ def parse():
 
 
 class KernelTimer:
-    """Brackets engine launches with a pair of events on the launch stream, inside the timed region.
+    """Brackets engine launches with a pair of events on the launch stream -- in the kernel-time loop BEHIND the timed
+    region (`kernel_loop`), never inside it.
 
     Every `every`-th launch of each kernel is bracketed (default: every fourth one): a pair of event records costs
-    the step ~3 us per kernel (measured: 0.402 vs 0.387 ms per step with all launches bracketed / none), and the
-    mean of a quarter of the launches of the timed region is as good an estimate as the mean of all of them."""
+    the step ~3 us per kernel (measured: 0.402 vs 0.387 ms per step with all launches bracketed / none), so the loop
+    they ride in is not the one the headline is read from."""
 
     def __init__(self, every=4):
         self.spans = []
@@ -290,8 +292,10 @@ def main():
     aligner = ShardedAligner(dec, gather=args.gather if multi else "none", e_chunks=args.e_chunks,
                              idiom="sum_backward" if args.mode == "fwdbwd" else "grad")
     eng = get_engine()
-    timer = KernelTimer(every=max(4, args.steps // 8) if args.steps >= 8 else 1)   # (<= 8 bracketed launches per kernel at the default K: a bracketed step pays ~16 us for its three extra holes; a short run brackets every launch: it must still see each kernel)
-    eng.launch_hook = None if os.environ.get("BENCH_NO_KERNEL_EVENTS") else timer   # (experiment: cost of the event pairs)
+    # kernel launch times: a loop of KSTEPS steps behind the timed region, every fourth launch of each kernel bracketed
+    KSTEPS = max(16, min(args.steps, 64))
+    timer = KernelTimer(every=4)
+    eng.launch_hook = None
 
     emb = None
     if args.mode == "scores+dp":
@@ -365,13 +369,25 @@ def main():
             dt = float(tt.item())
         return dt, m0.elapsed_time(m1) / nsteps
 
-    timer.enabled = True
-    elapsed, ms_per_step_events = timed(args.steps)
-    timer.enabled = False
+    elapsed, ms_per_step_events = timed(args.steps)   # the headline: nothing but the steps between the two fences
+
+    def kernel_loop(tm):
+        """per-kernel mean launch times: KSTEPS more steps of the same loop, right behind the timed region (the GPU never idles in
+        between beyond the fence), with an event pair around every fourth launch of each kernel"""
+        eng.launch_hook = tm
+        tm.enabled = True
+        try:
+            for _ in range(KSTEPS):
+                step()
+            fence()
+        finally:
+            tm.enabled = False
+            eng.launch_hook = None
+        return tm.means_ms()
     cells = B * N * M if args.variant == "nw" else B * (N - 1) * (M - 1)
     per_step_updates = (4 if args.mode.startswith("train") else 2) * cells
     value = world * per_step_updates * args.steps / elapsed
-    ms = timer.means_ms()
+    ms = kernel_loop(timer)
 
     no_skip = clocks = None
 
@@ -440,6 +456,7 @@ def main():
                                              "(bit-identical E; 47 % of E's cells, 29 % of the chunks on this data: DESIGN.md 3.8); the forward sweep "
                                              "-- the kernel the roofline is quoted on -- does all of its work"},
                 "kernel_ms": ms,
+                "kernel_ms_how": f"HIP event pairs on the launch stream around every 4th launch of each kernel, in {KSTEPS} steps of the same loop run right behind the timed region; the timed region itself holds no event record besides the pair around all of it",
                 "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                              "real_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
@@ -570,12 +587,8 @@ def main():
         try:
             eng.zero_skip = False
             step()
-            ns_timer = KernelTimer(every=timer.every)   # (the primary's own step count and bracketing: a like-for-like control)
-            eng.launch_hook = ns_timer
-            ns_timer.enabled = True
-            dt_ns, _ = timed(args.steps)
-            ns_timer.enabled = False
-            nm = ns_timer.means_ms()
+            dt_ns, _ = timed(args.steps)   # (the primary's own step count, no instruments: a like-for-like control)
+            nm = kernel_loop(KernelTimer(every=timer.every))
             no_skip = {"ms_per_step": dt_ns / args.steps * 1e3, "value": per_step_updates * args.steps / dt_ns,
                        "bwd_ms": next((v for k, v in nm.items() if k.startswith("sdp_bwd")), None),
                        "fwd_ms": next((v for k, v in nm.items() if k.startswith("sdp_fwd")), None), "steps": args.steps,
@@ -584,7 +597,7 @@ def main():
             print(f"[bench] no_skip control failed: {ex}", file=sys.stderr, flush=True)
         finally:
             eng.zero_skip = True
-            eng.launch_hook = None if os.environ.get("BENCH_NO_KERNEL_EVENTS") else timer
+            eng.launch_hook = None
     if not os.environ.get("BENCH_NO_CLOCKS") and not os.environ.get("BENCH_NO_SECONDARY"):
         # every rank loops the same number of steps (~1.5 s by the timed region's own figure, the max over ranks); rank 0 samples
         rounds = max(1, min(400, int(1.5 / max(50 * elapsed / args.steps, 1e-4))))

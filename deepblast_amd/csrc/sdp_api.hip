@@ -103,16 +103,6 @@ Variant variant(int id)
     case 26: return {(const void *)sdp_fwd_x_tp_pg_kernel, SDP_K_FWD, SDP_MAXW_FWD, 26};
     case 27: return {(const void *)sdp_bwd_pg_kernel, SDP_K_BWD, SDP_MAXW_BWD, 27};
     case 28: return {(const void *)sdp_bwd_x_pg_kernel, SDP_K_BWD, SDP_MAXW_BWD, 28};
-#if SDP_Q18
-    // 18-bit packed state (sdp_kernels.h: packed_bits): 29 fwd, 30 fwd latency, 31 fwd general pitch, 32 bwd, 33 bwd latency, 34 / 35 their general pitch
-    case 29: return {(const void *)sdp_fwd18_kernel, SDP_K_FWD, SDP_MAXW_FWD, 29};
-    case 30: return {(const void *)sdp_fwd18_lat_kernel, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, 30};
-    case 31: return {(const void *)sdp_fwd18_g_kernel, SDP_K_FWD, SDP_MAXW_FWD, 31};
-    case 32: return {(const void *)sdp_bwd18_kernel, SDP_K_BWD, SDP_MAXW_BWD, 32};
-    case 33: return {(const void *)sdp_bwd18_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 33};
-    case 34: return {(const void *)sdp_bwd18_g_kernel, SDP_K_BWD, SDP_MAXW_BWD, 34};
-    case 35: return {(const void *)sdp_bwd18_lat_g_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 35};
-#endif
     case 36: return {(const void *)sdp_bwd_pipe_kernel, SDP_K_BWD, SDP_MAXW_BWD_Q, 36};   // [1] with the chunk as one software pipeline (long pairs)
     default: return {(const void *)sdp_bwd_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 4};
     }
@@ -176,27 +166,9 @@ int general_id(int id)
 constexpr int PART_STRIPS = 4;
 inline int parts_per_pair(int N) { return (sdp::state_nstrips(N) + PART_STRIPS - 1) / PART_STRIPS; }
 
-// kernel id -> the build of the same sweep for the 18-bit packed state (or itself: builds that do not touch a packed state)
-int q18_id(int id)
-{
-    switch (id) {
-    case 0: return 29;
-    case 6: return 30;
-    case 11: return 31;
-    case 1: return 32;
-    case 4: return 33;
-    case 12: return 34;
-    case 15: return 35;
-    default: return id;
-    }
-}
-
 Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cus, int forced_waves, bool fused_seed = false,
           bool general_pitch = false, int allow_parts = 1 /* 0 never, 1 where it pays, 2 wherever it is possible */)
 {
-    // the packed state of this problem: 18-bit fields never go with parts (the format is a function of the shape alone, so
-    // that forward and backward agree; sdp_kernels.h: packed_bits)
-    const bool q18 = !exact_state && (pass == sdp::PASS_FWD || pass == sdp::PASS_BWD) && sdp::packed_bits(N, M, has_lens) == 18;
     const int nstrips = sdp::state_nstrips(N);
     const int mcap = (M + 63) / 64 * 64;
     // Waves per pair.  A batch that occupies the GPU is bound by HBM/fabric traffic and runs best with one wave
@@ -232,18 +204,13 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
     const int nin = (pass == sdp::PASS_AFWD && fused_seed) ? 3 : 0;   // three staged planes (ref, pred, G)
     if (nin) v = variant(10);
     if (general_pitch) v = variant(general_id(v.id));
-    if (q18) v = variant(q18_id(v.id));
     // The packed backward sweep's pipelined twin (sdp_kernels.hip, sdp_bwd_pipe_kernel) trades instruction issue for memory
     // latency.  Steady-state A/B over 24 shapes (tools/steady.py, +- 0.3 us; profiles/r05_steady_pipe.txt): it pays 2.3 % where
     // every CU holds ONE pair of long rows (256 x 1024^2, 256 x 512 x 1024), is level at 256 x 768 x 640 / 300 x 2000 / 192 x 1024^2, and
     // costs 1.1-3.7 % everywhere else -- shorter rows (the headline 256 x 512^2: 279.0 vs 272.5 us; 256 x 2048 x 256: 2.7 %), fewer
     // pairs than CUs (128 x 1024^2), more (384 x 1024^2, 512 x 768^2), 8 waves per pair (64 x 512^2).  So: only there.
-    // (-DSDP_BWD_PIPE_RULE=0 never, 2 always: the A/B builds of that table)
-#ifndef SDP_BWD_PIPE_RULE
-#define SDP_BWD_PIPE_RULE 1
-#endif
     const bool bwd_pipe_pays = W == 4 && B <= cus && B * 8 >= cus * 7 && M >= 1024 && (long long)N * M >= 450000;
-    if (v.id == 1 && (SDP_BWD_PIPE_RULE == 2 || (SDP_BWD_PIPE_RULE == 1 && bwd_pipe_pays))) v = variant(36);
+    if (v.id == 1 && bwd_pipe_pays) v = variant(36);
     // A pair over several workgroups (sdp_kernels.hip, "PARTS"): parts of four strips, each on a CU of its own, one strip
     // per wave of the 4-wave throughput builds, instead of one CU taking all the pair's strips in rounds.  It pays only
     // where CUs would otherwise idle AND the pair is long enough for the extra lag per bridge (measured, round 3, us
@@ -258,7 +225,7 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
     // only the backward sweep of pairs of four parts.  The adjoint pair (float64
     // carries) keeps one workgroup per pair.
     int parts = 0;
-    const bool parts_fit = sweep12 && forced_waves <= 0 && nstrips > PART_STRIPS && !q18;
+    const bool parts_fit = sweep12 && forced_waves <= 0 && nstrips > PART_STRIPS;
     // Round 5, re-measured after the backward sweep's changes (profiles/r05_parts_table.txt; us, one workgroup per pair -> parts):
     // with per-pair lengths the BACKWARD sweep no longer gains from parts anywhere but at BASELINE configs[2] (540 -> 512-522,
     // and 515 when only the forward sweep uses them) and loses elsewhere (<= 640^2: 213 -> 236, <= 512^2: 146 -> 160, 64 pairs
@@ -289,25 +256,18 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
     return {v, W, lds, off, parts};
 }
 
-// Where the 32-step units of the skewed state live (sdp_kernels.hip, "Skewed state addressing").  Default: every
-// (pair, strip) is one contiguous stream.  -DSDP_STATE_MARCH=1 ("marching"): unit u of every (pair, strip) in one slab,
-// so that a batch whose pairs advance in lockstep sweeps memory front to back; the unit part of an address travels in a
-// 32-bit scalar offset, so states of 2 GiB and more keep the contiguous streams.  Measured equal (round 3, B=256 512^2,
-// interleaved A/B: fwd 228.9 vs 226.1 us, bwd 163.5 vs 164.9), although a bare read/write stream of the same mix runs 4 %
-// faster that way (tools/ubench/mix2.hip): the sweeps are not bound by the order in which memory is visited.
+// Where the 32-step units of the skewed state live (sdp_kernels.hip, "Skewed state addressing"): every (pair, strip) is one
+// contiguous stream of units.  (A "marching" layout -- unit u of every (pair, strip) in one slab, so that a batch whose pairs
+// advance in lockstep sweeps memory front to back -- measured equal in round 3 and was removed in round 6: the sweeps are not
+// bound by the order in which memory is visited.  The two strides stay parameters of the kernels.)
 // All four sweeps of a problem (B, N, M) derive the same layout from the same three numbers.
-#ifndef SDP_STATE_MARCH
-#define SDP_STATE_MARCH 0
-#endif
 void state_layout(sdp::Params &p)
 {
-    const size_t streams = (size_t)p.B * p.nstrips_max, units = (size_t)p.tpad / sdp::STATE_UNIT_STEPS;
-    const bool march = SDP_STATE_MARCH && streams * units * sdp::STATE2_UNIT_BYTES < ((size_t)1 << 31);
-    const unsigned qunit = sdp::stateq_unit_bytes(p.qbits);   // (18-bit fields: 9216 B per 32 steps, else 10240)
-    p.st_ps = march ? qunit : units * qunit;
-    p.st_us = march ? (unsigned)(streams * qunit) : qunit;
-    p.st2_ps = march ? sdp::STATE2_UNIT_BYTES : units * sdp::STATE2_UNIT_BYTES;
-    p.st2_us = march ? (unsigned)(streams * sdp::STATE2_UNIT_BYTES) : sdp::STATE2_UNIT_BYTES;
+    const size_t units = (size_t)p.tpad / sdp::STATE_UNIT_STEPS;
+    p.st_ps = units * sdp::STATEQ_UNIT_BYTES;
+    p.st_us = sdp::STATEQ_UNIT_BYTES;
+    p.st2_ps = units * sdp::STATE2_UNIT_BYTES;
+    p.st2_us = sdp::STATE2_UNIT_BYTES;
 }
 
 // A kernel of an EARLIER call on this device gave up waiting for a strip hand-off: its results are wrong.  Reported
@@ -373,7 +333,7 @@ struct VariantBits {
     bool exact, et_bcast, ref;
     int flags;   // Params::flags: bit 0 SDP_NO_ZERO_SKIP, bit 1 SDP_NO_FILL
 };
-// The packed state keeps two 20-bit weights per cell (absolute error <= 2^-21 per weight, sdp_kernels.hip "SDP_Q20").  Its
+// The packed state keeps two 20-bit weights per cell (absolute error <= 2^-21 per weight, sdp_kernels.hip "The packed state").  Its
 // rounding error travels along an alignment path like a random walk (the 24-bit format of rounds 1-3 instead lost 1.7e-8 of
 // E per step of a SATURATED path, 7.5e-5 at N = M = 2048: the 20-bit fields decode a saturated weight to exactly 1 and do
 // not have that term); tests/test_parity_gpu.py::test_packed_state_at_the_longest_paths_it_serves holds max |dE| at
@@ -423,7 +383,6 @@ int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state 
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
     if (int rc = pending_handoff_error(device)) return rc;
     p.nstrips_max = sdp::state_nstrips(p.N);
-    p.qbits = sdp::packed_bits(p.N, p.M, p.lens != nullptr);
     p.tpad = sdp::state_tpad(p.M);
     p.mcap = (p.M + 63) / 64 * 64;
     state_layout(p);
@@ -715,7 +674,7 @@ size_t sdp_state_pair_stride(int N, int M, int exact_state)
     // the body of the state buffer is B equal records, one per pair: nstrips streams of tpad / 32 units
     // (state_layout); order, bridge rows and dispatch map live behind the LAST pair's record, not between records
     const size_t units = (size_t)sdp::state_nstrips(N) * (sdp::state_tpad(M) / sdp::STATE_UNIT_STEPS);
-    return units * (exact_for(exact_state != 0, N, M) ? sdp::STATE2_UNIT_BYTES : sdp::stateq_unit_bytes(sdp::packed_bits(N, M, false)));
+    return units * (exact_for(exact_state != 0, N, M) ? sdp::STATE2_UNIT_BYTES : sdp::STATEQ_UNIT_BYTES);
 }
 
 int sdp_backward_range_f32(const float *Et, const float *state, float *E, int B, int N, int M, int first, int count,
@@ -734,7 +693,6 @@ int sdp_backward_range_f32(const float *Et, const float *state, float *E, int B,
                            state + (size_t)first * plane * 3, E + (size_t)first * plane, (const int *)nullptr, N, M, variant == SDP_SW, vb.et_bcast ? 1 : 0);
         return ref_launched("sdp_ref_bwd_kernel");
     }
-    if (SDP_STATE_MARCH) return fail(SDP_E_SHAPE, "sdp_backward_range_f32: not available with the marching state layout");
     sdp::Params p = {};
     p.vin = vb.et_bcast ? Et : Et + first;
     p.vin_bcast = vb.et_bcast ? 1 : 0;

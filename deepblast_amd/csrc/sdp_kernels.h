@@ -75,17 +75,8 @@ constexpr int max_waves(int pass)
 constexpr int MAX_COLS = 2048;     // boundary rows live in LDS (4 x MAX_COLS x 8 B = 64 KiB)
 // how a pass represents the values that flow from cell to cell (sdp_kernels.hip, "Carry kinds")
 enum { CK_F64 = 0, CK_F32 = 1, CK_EXP = 2 };
-#ifndef SDP_FWD_KIND
-#define SDP_FWD_KIND 2
-#endif
-#ifndef SDP_BWD_KIND
-#define SDP_BWD_KIND 1
-#endif
-#ifndef SDP_ABWD_KIND
-#define SDP_ABWD_KIND 0
-#endif
 // bytes of one slot of a boundary row in LDS: 4 where the values are single floats (the fp32 backward sweep), else 8
-__host__ __device__ constexpr int boundary_slot_bytes(int pass) { return (pass == PASS_BWD && SDP_BWD_KIND == CK_F32) ? 4 : 8; }
+__host__ __device__ constexpr int boundary_slot_bytes(int pass) { return pass == PASS_BWD ? 4 : 8; }
 constexpr int FRAME_CAP = 136;     // frame words per boundary row: >= 16-step blocks of a strip at MAX_COLS (+ a chunk)
 constexpr int PROG_STRIDE = 4096;  // > MAX_COLS: progress words are (use index)*PROG_STRIDE + columns
 
@@ -110,7 +101,6 @@ struct Params {
     int mcap;            // doubles per boundary row in LDS
     int stage_off;       // byte offset of the per-wave staging area in LDS
     int variant;
-    int qbits;           // field width of the packed state this launch writes / reads (packed_bits): 18 or 20
     int flags;           // bit 0: run every chunk (SDP_NO_ZERO_SKIP), bit 1: no zero fill outside the pairs' blocks (SDP_NO_FILL)
     int dbg;             // experiments build only (sdp_set_debug): bit0 inputs, bit1 outputs, bit2 state: all pairs alias
                          // pair 0; bit3: strips never publish their progress (exercises the hand-off time-out)
@@ -142,32 +132,13 @@ __host__ __device__ constexpr int stage_floats(int pass, int K, int nin_override
 // tail of both state buffers: room for the launch order of a variable-length batch (B ints, 256-byte granules)
 __host__ __device__ inline size_t state_order_bytes(int B) { return ((size_t)B * 4 + 255) / 256 * 256; }
 
-// State layout: the state of a (pair, strip) is a sequence of units of 32 steps (packed Q: 12288 B, float2: 16384 B);
+// State layout: the state of a (pair, strip) is a sequence of units of 32 steps (packed Q: 10240 B, float2: 16384 B);
 // unit u of (pair b, strip s) starts at (b * nstrips + s) * ps + u * us.  See "Skewed state addressing" in sdp_kernels.hip.
-// Packed Q, round 4 (SDP_Q20 = 1): two 20-bit fields per cell, 5 bytes; a 16-step block of a lane is 20 dwords, kept as
-// five rows of 1024 B (row j: dwords 4j .. 4j+3 of every lane) -- every wave access is one dwordx4 over contiguous lines;
-// a unit of 32 steps is two blocks, ten rows.  SDP_Q20 = 0: the 24-bit fields of rounds 1-3 (6 bytes per cell, 16 rows of
-// 768 B).
-#ifndef SDP_Q20
-#define SDP_Q20 1
-#endif
+// Packed Q: two 20-bit fields per cell, 5 bytes; a 16-step block of a lane is 20 dwords, kept as five rows of 1024 B (row j:
+// dwords 4j .. 4j+3 of every lane) -- every wave access is one dwordx4 over contiguous lines; a unit of 32 steps is two blocks,
+// ten rows.  (Rounds 1-3: 24-bit fields, 6 bytes; an 18-bit form was built in round 5 and not adopted: sdp_kernels.hip.)
 constexpr int STATE_UNIT_STEPS = 32;
-constexpr unsigned STATEQ_UNIT_BYTES = SDP_Q20 ? 10 * 1024 : 16 * 768, STATE2_UNIT_BYTES = 32 * 512;
-// Round 5: two 18-bit fields per cell (4.5 bytes; a 32-step unit is two blocks of four dwordx4 rows + one dwordx2 row = 9216 B)
-// for problems whose alignment paths are short enough for the coarser grid to stay ten times inside the parity bound
-// (sdp_kernels.hip, "18-bit fields"): N + M <= 1024, and -- so that the forward and the backward call agree without knowing each
-// other's launch plans -- only problems that can never be spread over several workgroups: no per-pair lengths, N <= 768.
-// sdp_state_bytes keeps sizing the buffer for the 20-bit fields (it is not told about lengths).
-#ifndef SDP_Q18
-#define SDP_Q18 0   // NOT adopted (round 5): the gate holds only barely and only for near-square shapes, the gain is ~1 % -- see sdp_kernels.hip "18-bit fields"
-#endif
-constexpr unsigned STATEQ18_UNIT_BYTES = 2 * (4 * 1024 + 512);
-constexpr int PACKED18_MAX_PATH = 1024;
-__host__ __device__ inline int packed_bits(int N, int M, bool has_lens)
-{
-    return (SDP_Q18 && SDP_Q20 && !has_lens && N + M <= PACKED18_MAX_PATH && N <= 768) ? 18 : (SDP_Q20 ? 20 : 24);
-}
-__host__ __device__ inline unsigned stateq_unit_bytes(int qbits) { return qbits == 18 ? STATEQ18_UNIT_BYTES : STATEQ_UNIT_BYTES; }
+constexpr unsigned STATEQ_UNIT_BYTES = 10 * 1024, STATE2_UNIT_BYTES = 32 * 512;
 // (Sharing the ramp rows of neighbouring strips -- no skew padding -- was implemented in round 2 for both formats, measured
 // slower (partial-line writes) and removed in round 3; see DESIGN.md.)
 __host__ __device__ inline size_t state_rows2(int N, int M) { return (size_t)((N + 63) / 64) * ((M + 63 + 63) / 64 * 64); }
@@ -213,15 +184,6 @@ __global__ void sdp_bwd_lat_g_kernel(const sdp::Params p);
 __global__ void sdp_bwd_x_g_kernel(const sdp::Params p);
 __global__ void sdp_bwd_x_lat_g_kernel(const sdp::Params p);
 __global__ void sdp_adj_bwd_g_kernel(const sdp::Params p);
-#if SDP_Q18
-__global__ void sdp_fwd18_kernel(const sdp::Params p);
-__global__ void sdp_fwd18_lat_kernel(const sdp::Params p);
-__global__ void sdp_fwd18_g_kernel(const sdp::Params p);
-__global__ void sdp_bwd18_kernel(const sdp::Params p);
-__global__ void sdp_bwd18_lat_kernel(const sdp::Params p);
-__global__ void sdp_bwd18_g_kernel(const sdp::Params p);
-__global__ void sdp_bwd18_lat_g_kernel(const sdp::Params p);
-#endif
 __global__ void sdp_ref_fwd_kernel(const float *theta, const float *A, float *Q, float *Vt, const int *lens, int N, int M, int sw);
 __global__ void sdp_ref_bwd_kernel(const float *Et, const float *Q, float *E, const int *lens, int N, int M, int sw, int et_bcast);
 __global__ void sdp_ref_adj_fwd_kernel(const float *Q, const float *Ztheta, const float *ZA, float *Vtd, float *Qd, const int *lens, int N, int M);

@@ -99,105 +99,19 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #else
 #define SDP_EXP_BUILD 0  // default library: Params::dbg is ignored, no wrong-results switch is reachable
 #endif
-#ifndef SDP_ZF_AUX
-#define SDP_ZF_AUX 0   // cache policy of the zero-fill stores
-#endif
 #ifndef SDP_TB_WINDOW
 #define SDP_TB_WINDOW 32  // traceback: edge of the LDS window of E (32 or 64 cells)
 #endif
-#ifndef SDP_PREPASS
-#define SDP_PREPASS 1
-#endif
-#ifndef SDP_LINES
-#define SDP_LINES 1  // throughput forward build: line-aligned input blocks (see "Staged INPUT geometry")
-#endif
-#ifndef SDP_LINES_AUX
-#define SDP_LINES_AUX 2   // policy bits of those loads (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
-#endif
-#ifndef SDP_LINES_NT
-#define SDP_LINES_NT 1  // line-aligned input blocks are touched once: stream them past the caches
-#endif
-#ifndef SDP_WF
-#define SDP_WF 1  // forward sweep: try the windowed form on interior chunks
-#endif
-#ifndef SDP_FLUSH_FAST
-#define SDP_FLUSH_FAST 1  // reverse sweeps: chunks whose outputs are all real cells flush without per-lane tests
-#endif
-#ifndef SDP_VEC_BND
-#define SDP_VEC_BND 1
-#endif
-#ifndef SDP_ZERO_SKIP
-#define SDP_ZERO_SKIP 2  // fp32 backward sweep: a chunk whose carries, boundary values and cotangent are all +0 produces +0 everywhere: 1 = its steps are skipped, 2 = and its state rows not loaded (bit-identical)
-#endif
-#ifndef SDP_STAGE_EARLY
-#define SDP_STAGE_EARLY 0  // forward sweep: the next block set into the LDS ring as soon as the chunk's last block has read its inputs -- measured, no gain, off
-#endif
-#ifndef SDP_TOPLOAD
-#define SDP_TOPLOAD 1  // exact-state sweeps: the next chunk's state rows are loaded in one burst at the top of the iteration (the packed reverse sweep always does)
-#endif
-#ifndef SDP_REFILL_BARRIER
-#define SDP_REFILL_BARRIER 1
-#endif
-#ifndef SDP_PROLOGUE_WAIT
-#define SDP_PROLOGUE_WAIT 1  // reverse sweeps: the prologue's loads are waited for before the chunk loop (see the chunk loop's prologue)
-#endif
-#ifndef SDP_FLUSH2
-#define SDP_FLUSH2 1  // reverse sweeps, aligned K = 32 builds: outputs leave two columns per lane (see FLUSH2)
-#endif
-#ifndef SDP_BWD_PIPE
-#define SDP_BWD_PIPE 1  // fp32 backward sweep, aligned K = 32 builds: the chunk as ONE software pipeline (see PIPE in the chunk loop)
-#endif
-#ifndef SDP_FLUSH4
-#define SDP_FLUSH4 1  // reverse sweeps without the pipelined chunk, plain flush: the same 16 aligned 8-byte LDS reads, but 8 dwordx4 stores (four columns per lane) instead of 16 dwordx2 -- bit-identical; steady state, fwd;bwd us: 256 x 512^2 282.9 -> 282.5, 64 x 512^2 217.3 -> 215.3, 512 x 512^2 544.2 -> 543.1, 256 x 768 x 640 529.0 -> 525.6 (what a chunk's stores cost goes with their BYTES, not their number: profiles/r05_flusher_waves.txt)
-#endif
-#ifndef SDP_BWD_MASKFREE
-#define SDP_BWD_MASKFREE 1  // fp32 backward sweep: the ramps of a full strip run the mask-free step body too (see bwd_mask_free)
-#endif
-#ifndef SDP_ZERO_SKIP_ADJ
-#define SDP_ZERO_SKIP_ADJ 1  // adjoint backward sweep: chunks over which E, the carries and the boundary values are all zero are not run, nor their Q / Qd rows read (see ZSKIP_A)
-#endif
-#ifndef SDP_DEAD_LINES
-#define SDP_DEAD_LINES 0  // (0: off -- built, bit-identical, measured in round 5 and NOT adopted: forward alone 193 -> 185 us, but the forward;backward sequence 312 +- 4 us either way and the backward sweep 124 -> 128 us when it masks its loads; 1: the forward sweep does not write them; 2: the backward sweep does not read them either)  // packed state: 128-byte lines of the skew padding whose eight lanes are all outside the matrix for a whole 16-step block are neither written nor read
-#endif
-#ifndef SDP_PIPE_ST
-#define SDP_PIPE_ST 1  // PIPE: one of the previous chunk's 16 output stores every SDP_PIPE_ST steps (1: all in the first half of the chunk)
-#endif
-#ifndef SDP_PIPE_PUB
-#define SDP_PIPE_PUB 0  // PIPE: this strip's boundary values leave 0 = after the steps, 1 = four at a time inside them, 2 = in two halves
-#endif
-#ifndef SDP_BWD_HALF
-#define SDP_BWD_HALF 0  // fp32 backward sweep: boundary hand-off in halves of a chunk (see HALF) -- measured slower, off
-#endif
-#ifndef SDP_FWD_SUB
-#define SDP_FWD_SUB 1  // forward sweep: compute in WB-step blocks inside a K-step chunk (see fwd_blocks)
-#endif
-// cache policy: bit0 state stores, bit1 state loads, bit2 staged loads, bit3 staged stores use nt (aux=2).
-// The skewed state is read exactly once, so its loads stream past the caches (nt); its stores keep the
-// default policy: in the fwd -> bwd sequence the tail of the state is then still in the Infinity Cache when
-// the backward sweep starts reading it.  Measured on the back-to-back sequence (us): none 472, stores 471,
-// loads 468, both 476.  The row-major tensors are re-touched by neighbouring chunks and keep the default.
-// Round 2, same measurement with the block-wise forward (fwd;bwd back to back, one box): 2 (loads): 380.3, 0: 397.6,
-// 3 (+ state stores): 385.6, 11: 394.2, and 10 = state loads + staged OUTPUT stores (E, Ed -- nobody in this library
-// reads them back): 371.0 -- the outputs no longer push the state out of the Infinity Cache before it is re-read.
-#ifndef SDP_NT
-#define SDP_NT 10
-#endif
-// State stores: sc1.  Once the forward sweep ran at the rate of the memory system (round 4) the store policy began to
-// matter: same box, interleaved, 256 x 512^2 forward 183 -> 176 us (191 -> 182, 212 -> 203 on slower boxes), forward;backward
-// 329 -> 321 (321 -> 315), 256 x 1024^2 1143 -> 1116; nt for the state stores: 177 / 333; sc0 sc1: 175 / 327; sc1 for the E
-// stores as well: forward;backward 341, nt sc1 for them: 314 (noise against 315) -- profiles/r04_store_policy.txt.  (In
-// rounds 2-3, with the sweep bound by its instruction stream, every one of these was inside the box-to-box spread.)
-#ifndef SDP_AUX_ST_STORE   // explicit policy bits of the state stores (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
-#define SDP_AUX_ST_STORE ((SDP_NT & 1) ? 2 : 16)
-#endif
-#ifndef SDP_AUX_ST_LOAD
-#define SDP_AUX_ST_LOAD ((SDP_NT & 2) ? 2 : 0)
-#endif
-constexpr int AUX_ST_STORE = SDP_AUX_ST_STORE, AUX_ST_LOAD = SDP_AUX_ST_LOAD;
-#ifndef SDP_AUX_OUT_STORE   // explicit policy bits of the staged output stores (E, Ed)
-#define SDP_AUX_OUT_STORE ((SDP_NT & 8) ? 18 : 0)   // nt sc1 (round 5, steady state: fwd;bwd 292.0 -> 288.5 us on one box, 272.3 -> 271.0 on another, 512 x 512^2 587.4 -> 581.7; plain nt was round 4's choice; anything without nt: backward -15 us, the next forward +31)
-#endif
-constexpr int AUX_IN_LOAD = (SDP_NT & 4) ? 2 : 0, AUX_OUT_STORE = SDP_AUX_OUT_STORE;
+// Everything below used to be a compile-time switch of its own (31 of them by round 5).  Each was measured, one setting won, and
+// the losing code paths were deleted in round 6 (their measurements: DESIGN_HISTORY.md, "Switches retired in round 6"; the code:
+// git history).  What is left are the constants the winning settings fold to.
+//   * fp32 backward sweep: a chunk whose carries, boundary values and cotangent are all +0 produces +0 everywhere: its steps are
+//     skipped and its state rows not loaded (bit-identical; the control is the run-time flag SDP_NO_ZERO_SKIP);
+//   * adjoint backward sweep: chunks over which E, the carries and the boundary values are all zero are not run (ZSKIP_A);
+//   * cache policies (gfx950 aux bits: 1 = sc0, 2 = nt, 16 = sc1), profiles/r04_store_policy.txt, r05_steady_policies.txt: every
+//     stream is touched once per sweep -- line-aligned input blocks nt, state loads nt, state stores sc1 (what stays in the
+//     Infinity Cache between the forward and the backward sweep matters), E / Ed stores nt sc1, zero-fill stores default.
+constexpr int AUX_ST_STORE = 16, AUX_ST_LOAD = 2, AUX_IN_LOAD = 0, AUX_LINES_LOAD = 2, AUX_OUT_STORE = 18, AUX_ZERO_FILL = 0;
 constexpr bool ABL_NOSTORE = (SDP_ABL & 1) != 0;
 constexpr bool ABL_NOLOAD = (SDP_ABL & 2) != 0;
 constexpr bool ABL_NOSYNC = (SDP_ABL & 4) != 0;
@@ -275,50 +189,21 @@ struct Traits<PASS_ABWD, QX> {  // nw.py:251-267
     static constexpr bool REV = true;
 };
 
-// (The format of rounds 1-3, kept as the SDP_Q20 = 0 build for comparison; the shipped format is SDP_Q20 below: 20-bit fields, 5 bytes per cell.)
-// The saved softmax weights Q (qx, qy; qm = 1 - qx - qy) are kept as two 24-bit fields per cell: the low three
-// bytes of the float f = 1 + q*(1 - 2^-20), i.e. q on a grid of 2^-23 (absolute error <= 2^-24, the precision
-// fp32 itself has for weights in [0.5, 1)); the factor keeps f below 2 for any q <= 1 + 9e-7 -- a weight computed
-// as c/sum*u can exceed 1 by a few ulp -- so no clamp is needed, and the reader undoes it (Q_UNSCALE).  Two cells -- four fields -- fill three dwords: the state costs
-// 6 bytes per cell instead of 8, one dwordx3 access per lane moves two steps, and byte permutes do the packing.
-// (Two unorm16 per cell would halve the state, but their rounding error accumulates along an alignment path like
-// a random walk and passes 1e-4 on E for peaked inputs and for sequences beyond ~1000 residues.)  This format
-// feeds the backward sweep only; see Q_EXACT above.  The derivative state Qd is signed and unbounded and stays
-// float2.
-constexpr float Q_SCALE = 0.99999904632568359375f;   // 1 - 2^-20
-constexpr float Q_UNSCALE = 1.00000095367522590f;     // 1 / (1 - 2^-20)
-// group w[0..2] = bytes x0.0 x0.1 x0.2 y0.0 | y0.1 y0.2 x1.0 x1.1 | x1.2 y1.0 y1.1 y1.2
-__device__ __forceinline__ void q_pack2(float2 a, float2 b, unsigned *w)
-{
-    const unsigned x0 = __float_as_uint(__builtin_fmaf(a.x, Q_SCALE, 1.0f)), y0 = __float_as_uint(__builtin_fmaf(a.y, Q_SCALE, 1.0f));
-    const unsigned x1 = __float_as_uint(__builtin_fmaf(b.x, Q_SCALE, 1.0f)), y1 = __float_as_uint(__builtin_fmaf(b.y, Q_SCALE, 1.0f));
-    w[0] = __builtin_amdgcn_perm(y0, x0, 0x04020100u);
-    w[1] = __builtin_amdgcn_perm(x1, y0, 0x05040201u);
-    w[2] = __builtin_amdgcn_perm(y1, x1, 0x06050402u);
-}
-__device__ __forceinline__ float q_field(unsigned u)  // field in the low 23 bits of u, anything above -> f - 1
-{
-    return __uint_as_float((u & 0x7fffffu) | 0x3f800000u) - 1.0f;
-}
-// (f - 1) of both weights of a cell; the caller multiplies by Q_UNSCALE (or folds it into another factor)
-__device__ __forceinline__ float2 q_unpack(const unsigned *w, int second)
-{
-    if (second) return make_float2(q_field(__builtin_amdgcn_perm(w[2], w[1], 0x0c040302u)), q_field(w[2] >> 8));
-    return make_float2(q_field(w[0]), q_field(__builtin_amdgcn_perm(w[1], w[0], 0x0c050403u)));
-}
-
-// Round 4, SDP_Q20: two 20-bit fields per cell (5 bytes).  A field is the low 20 bits of the float f = 8 + q * (1 - 2^-19):
-// in [8, 16) one ulp is 2^-20, so the fma's own rounding puts q on a grid of 2^-20 (absolute error <= 2^-21 = 4.8e-7 per
-// weight; emulated on the float64 oracle's weights, tools/emu_state_formats.py: max |dE| 9e-7 on the benchmark's scores,
-// 3.4e-6 on peaked ones at 512 x 512 -- the 1e-4 bound is 30x away, and problems with N + M > 4096 take the exact state
-// as before).  The factor keeps the field below 2^20 for q <= 1 + 9e-7; a saturated weight (anything within 2^-21 of 1)
-// decodes to exactly 1, a weight below 2^-21 to exactly 0, so a saturated path loses nothing -- the 24-bit format kept 1 -
-// 2^-23 as it was and lost 1.7e-8 of E per step.  Four cells -- eight fields, x0 y0 x1 y1 x2 y2 x3 y3 from bit 0 up -- fill
-// five dwords; the 20 dwords of a 16-step block are stored as five rows of one dwordx4 per lane (sdp_kernels.h).
-constexpr bool Q20 = SDP_Q20 != 0;
-constexpr float Q20_SCALE = 0.99999809265136718750f;    // 1 - 2^-19
-constexpr float Q20_UNSCALE = 1.0000019073486328125f;   // 1 + 2^-19 = 1 / (1 - 2^-19) to fp32
-constexpr float QF_SCALE = Q20 ? Q20_SCALE : Q_SCALE, QF_UNSCALE = Q20 ? Q20_UNSCALE : Q_UNSCALE, QF_BASE = Q20 ? 8.0f : 1.0f;
+// The packed state (read by the backward sweep only; see Q_EXACT above): two 20-bit fields per cell, 5 bytes (round 4; rounds
+// 1-3 kept two 24-bit fields, 6 bytes; 18-bit fields were built in round 5, gated by emulation and NOT adopted -- one per cent of
+// time for three quarters of the margin; two unorm16 per cell were rejected in round 1: their rounding error is carried along an
+// alignment path like a random walk and passes 1e-4 on E beyond ~1000 residues.  DESIGN.md section 2, DESIGN_HISTORY.md).
+// A field is the low 20 bits of the float f = 8 + q * (1 - 2^-19): in [8, 16) one ulp is 2^-20, so the fma's own rounding puts q on
+// a grid of 2^-20 (absolute error <= 2^-21 = 4.8e-7 per weight; emulated on the float64 oracle's weights,
+// tools/emu_state_formats.py: max |dE| 9e-7 on the benchmark's scores, 3.4e-6 on peaked ones at 512 x 512 -- the 1e-4 bound is 30x
+// away, and problems with N + M > 4096 take the exact state).  The factor keeps the field below 2^20 for q <= 1 + 9e-7 -- a weight
+// computed as c / sum * u can exceed 1 by a few ulp -- so no clamp is needed; a saturated weight (anything within 2^-21 of 1)
+// decodes to exactly 1, a weight below 2^-21 to exactly 0, so a saturated path loses nothing.  Four cells -- eight fields, x0 y0 x1
+// y1 x2 y2 x3 y3 from bit 0 up -- fill five dwords; the 20 dwords of a 16-step block are stored as five rows of one dwordx4 per
+// lane (sdp_kernels.h).  The derivative state Qd is signed and unbounded and stays float2.
+constexpr float QF_SCALE = 0.99999809265136718750f;    // 1 - 2^-19
+constexpr float QF_UNSCALE = 1.0000019073486328125f;   // 1 + 2^-19 = 1 / (1 - 2^-19) to fp32
+constexpr float QF_BASE = 8.0f;
 // raw bits fx[k], fy[k] of the four cells' biased floats (0x41000000 | field) -> five dwords
 __device__ __forceinline__ void q20_pack4(const unsigned *fx, const unsigned *fy, unsigned *w)
 {
@@ -330,22 +215,15 @@ __device__ __forceinline__ void q20_pack4(const unsigned *fx, const unsigned *fy
     w[3] = __builtin_amdgcn_ubfe(fx[2], 16, 4) | ((fy[2] & 0xfffffu) << 4) | (fx[3] << 24);
     w[4] = __builtin_amdgcn_ubfe(fx[3], 8, 12) | (fy[3] << 12);
 }
-#ifndef SDP_Q20_BFI
-#define SDP_Q20_BFI 1  // the field goes under the exponent of 8.0 with ONE v_bfi_b32 (mask in an SGPR, 0x41000000 in a VGPR) instead of v_and + v_or
-#endif
 __device__ __forceinline__ float q20_field(unsigned u)  // field in the low 20 bits of u, anything above -> f - 8
 {
-#if SDP_Q20_BFI
-    // gfx9 allows one constant-bus operand per VALU instruction, so the compiler, given two literals, emits two
-    // instructions; with the bias in a register the bit-field insert does it in one.  Same bits.
+    // gfx9 allows one constant-bus operand per VALU instruction, so the compiler, given two literals ((u & mask) | bias), emits
+    // two instructions; with the bias in a register the bit-field insert does it in one (15.5 -> 13.75 VALU per step).  Same bits.
     unsigned r;
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(0xfffffu), "v"(u), "v"(0x41000000u));
     return __uint_as_float(r) - 8.0f;
-#else
-    return __uint_as_float((u & 0xfffffu) | 0x41000000u) - 8.0f;
-#endif
 }
-// (f - 8) of both weights of cell `sub` (0..3) of a five-dword record; the caller multiplies by Q20_UNSCALE
+// (f - 8) of both weights of cell `sub` (0..3) of a five-dword record; the caller multiplies by QF_UNSCALE
 __device__ __forceinline__ float2 q20_unpack(const unsigned *w, int sub)
 {
     switch (sub) {
@@ -353,74 +231,6 @@ __device__ __forceinline__ float2 q20_unpack(const unsigned *w, int sub)
     case 1: return make_float2(q20_field(w[1] >> 8), q20_field(__builtin_amdgcn_alignbit(w[2], w[1], 28)));
     case 2: return make_float2(q20_field(__builtin_amdgcn_alignbit(w[3], w[2], 16)), q20_field(w[3] >> 4));
     default: return make_float2(q20_field(__builtin_amdgcn_alignbit(w[4], w[3], 24)), q20_field(w[4] >> 12));
-    }
-}
-
-// Round 5, -DSDP_Q18=1 (built, bit-checked, measured, NOT adopted): two 18-bit fields per cell (4.5 bytes) for problems with
-// N + M <= 1024 (sdp_kernels.h: packed_bits).  A field is the low 18 bits of the float f = 32 + q * (1 - 2^-17): in [32, 64) one
-// ulp is 2^-18 (absolute error <= 2^-19 = 1.9e-6 per weight).  Eight cells -- sixteen fields -- fill nine dwords; the 18 dwords
-// of a 16-step block are four rows of one dwordx4 per lane and one row of a dwordx2 (4608 bytes per block instead of 5120).
-// Gate (ten times inside the bound at every shape the format serves; tools/emu_field_bits.py, float64 oracle
-// weights rounded to the grid, backward recurrence in float64, max |dE| over three seeds and five score families;
-// profiles/r05_emu_state_formats.txt): 512 x 512 <= 7.5e-6, 400 x 400 9.6e-6, 384 x 512 1.0e-5 -- AT the gate -- and thin shapes
-// beyond it: 300 x 724 1.2e-5, 512 x 128 1.0e-5, 128 x 896 1.6e-5, 64 x 512 2.1e-5 (a row of gap steps carries the rounding of
-// every weight along).  On the GPU, against the oracle: 1.0e-5 at 512 x 512 (theta x 30, A x 10), 1.3e-5 at 300 x 724 -- a
-// factor 8, where the 20-bit fields keep 30.  The gain: forward 923 -> 887 MB, backward 562 -> 527 MB per launch at
-// 256 x 512^2, the two sweeps back to back 317 -> 314 us (+- 4).  One per cent of time is not worth three quarters of the
-// margin: the shipped library keeps the 20-bit fields for every shape.
-constexpr float Q18_SCALE = 0.99999237060546875f;       // 1 - 2^-17
-constexpr float Q18_UNSCALE = 1.00000762939453125f;     // 1 + 2^-17 = 1 / (1 - 2^-17) to fp32
-template <int QB>
-struct QFmt;
-template <>
-struct QFmt<20> {
-    static constexpr int REC_STEPS = 4, REC_DW = 5, BLK_DW = 20, BLK_ROWS = 5;   // rows: dwordx4 per lane (the last may be a half row)
-    static constexpr bool TAIL_X2 = false;
-    static constexpr unsigned BLK_BYTES = 5 * 1024;
-    static constexpr float BASE = 8.0f;
-};
-template <>
-struct QFmt<18> {
-    static constexpr int REC_STEPS = 8, REC_DW = 9, BLK_DW = 18, BLK_ROWS = 5;
-    static constexpr bool TAIL_X2 = true;   // row 4 of a block holds two dwords per lane (512 bytes)
-    static constexpr unsigned BLK_BYTES = 4 * 1024 + 512;
-    static constexpr float BASE = 32.0f;
-};
-template <int QB> __device__ __forceinline__ constexpr float qf_scale() { return QB == 18 ? Q18_SCALE : (Q20 ? Q20_SCALE : Q_SCALE); }
-template <int QB> __device__ __forceinline__ constexpr float qf_unscale() { return QB == 18 ? Q18_UNSCALE : (Q20 ? Q20_UNSCALE : Q_UNSCALE); }
-template <int QB> __device__ __forceinline__ constexpr float qf_base() { return QB == 18 ? 32.0f : (Q20 ? 8.0f : 1.0f); }
-// raw bits fx[k], fy[k] of eight cells' biased floats (0x42000000 | field) -> nine dwords (generated and checked by a script:
-// a left shift by >= 7 pushes the exponent bits 25 and 30 out of the dword, bits 18-23 of a biased float are zero)
-__device__ __forceinline__ void q18_pack8(const unsigned *fx, const unsigned *fy, unsigned *w)
-{
-    w[0] = (fx[0] & 0x3ffffu) | (fy[0] << 18);
-    w[1] = __builtin_amdgcn_ubfe(fy[0], 14, 4) | ((fx[1] & 0x3ffffu) << 4) | (fy[1] << 22);
-    w[2] = __builtin_amdgcn_ubfe(fy[1], 10, 8) | (fx[2] << 8) | (fy[2] << 26);
-    w[3] = __builtin_amdgcn_ubfe(fy[2], 6, 12) | (fx[3] << 12) | (fy[3] << 30);
-    w[4] = __builtin_amdgcn_ubfe(fy[3], 2, 16) | (fx[4] << 16);
-    w[5] = __builtin_amdgcn_ubfe(fx[4], 16, 2) | ((fy[4] & 0x3ffffu) << 2) | (fx[5] << 20);
-    w[6] = __builtin_amdgcn_ubfe(fx[5], 12, 6) | ((fy[5] & 0x3ffffu) << 6) | (fx[6] << 24);
-    w[7] = __builtin_amdgcn_ubfe(fx[6], 8, 10) | (fy[6] << 10) | (fx[7] << 28);
-    w[8] = __builtin_amdgcn_ubfe(fx[7], 4, 14) | (fy[7] << 14);
-}
-__device__ __forceinline__ float q18_field(unsigned u)  // field in the low 18 bits of u, anything above -> f - 32
-{
-    unsigned r;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(0x3ffffu), "v"(u), "v"(0x42000000u));
-    return __uint_as_float(r) - 32.0f;
-}
-// (f - 32) of both weights of cell `sub` (0..7) of a nine-dword record; the caller multiplies by Q18_UNSCALE
-__device__ __forceinline__ float2 q18_unpack(const unsigned *w, int sub)
-{
-    switch (sub) {
-    case 0: return make_float2(q18_field(w[0]), q18_field(__builtin_amdgcn_alignbit(w[1], w[0], 18)));
-    case 1: return make_float2(q18_field(w[1] >> 4), q18_field(__builtin_amdgcn_alignbit(w[2], w[1], 22)));
-    case 2: return make_float2(q18_field(w[2] >> 8), q18_field(__builtin_amdgcn_alignbit(w[3], w[2], 26)));
-    case 3: return make_float2(q18_field(w[3] >> 12), q18_field(__builtin_amdgcn_alignbit(w[4], w[3], 30)));
-    case 4: return make_float2(q18_field(__builtin_amdgcn_alignbit(w[5], w[4], 16)), q18_field(w[5] >> 2));
-    case 5: return make_float2(q18_field(__builtin_amdgcn_alignbit(w[6], w[5], 20)), q18_field(w[6] >> 6));
-    case 6: return make_float2(q18_field(__builtin_amdgcn_alignbit(w[7], w[6], 24)), q18_field(w[7] >> 10));
-    default: return make_float2(q18_field(__builtin_amdgcn_alignbit(w[8], w[7], 28)), q18_field(w[8] >> 14));
     }
 }
 
@@ -468,12 +278,13 @@ __device__ __forceinline__ void q_sharpen(float &wx, float &wy, float wm)
 //            power of two (added to the exponent) and a factor in [1,2), and the three operands are
 //            aligned to their largest exponent, so no finite input can overflow or cancel; every
 //            rescale is an exact power of two, so the only rounding is the fp32 fma chain itself.
-// (the enum, the SDP_*_KIND macros and boundary_slot_bytes live in sdp_kernels.h: the host sizes the LDS rows by them)
+// (the enum and boundary_slot_bytes live in sdp_kernels.h: the host sizes the LDS rows by them.  Which pass uses which kind was a
+// build-time choice until round 6; the alternatives -- a float64 forward, a float64 backward, an fp32 adjoint backward -- lost by
+// measurement or by parity in rounds 1-2 and are gone.)
 
 template <int PASS>
 struct Kind {
-    static constexpr int value = PASS == PASS_FWD ? SDP_FWD_KIND
-                                 : (PASS == PASS_BWD ? SDP_BWD_KIND : (PASS == PASS_ABWD ? SDP_ABWD_KIND : CK_F64));
+    static constexpr int value = PASS == PASS_FWD ? CK_EXP : (PASS == PASS_BWD ? CK_F32 : CK_F64);
 };
 
 typedef unsigned long long u64;  // one boundary slot (LDS) / one edge value in registers
@@ -571,7 +382,7 @@ __device__ __forceinline__ float loss_dterm(float r, float y, float sc, int kind
 // start on K-float boundaries (M a multiple of 32, 128-byte aligned tensors): the same formulas with the offsets
 // folded to constants -- the host picks per launch (sdp_api.hip), and the headline shape pays nothing for generality
 // (with one instantiation for both, the forward kernel measured +5 % and the backward +3 % at M = 512).
-template <int PASS, int K, bool QX = false, bool LINES = false, bool GEN = false, bool PARTS = false, int QB = 20, bool NOPIPE = false>
+template <int PASS, int K, bool QX = false, bool LINES = false, bool GEN = false, bool PARTS = false, bool NOPIPE = false>
 __device__ __forceinline__ void sweep(const Params &p)
 {
     using T = Traits<PASS, QX>;
@@ -590,7 +401,6 @@ __device__ __forceinline__ void sweep(const Params &p)
     constexpr int NS = T::SIN > 0 ? T::SIN : 1;
     constexpr int PUB_LANE = REV ? 0 : 63;    // lane that produces this strip's boundary row
     constexpr int DPP_IN = REV ? DPP_WAVE_SHL1 : DPP_WAVE_SHR1;  // pull from the lane that owns the previous row
-    static_assert(!(KIND == CK_EXP && PASS != PASS_FWD) && !(KIND == CK_F32 && !REV), "unsupported carry kind");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -696,7 +506,7 @@ __device__ __forceinline__ void sweep(const Params &p)
             const int part = absent ? wave : (idle > 0 ? wave - nstrips_wg : wave);          // this one's index among them
             if (part < 0) return;
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            constexpr int ZF_AUX = SDP_ZF_AUX;
+            constexpr int ZF_AUX = AUX_ZERO_FILL;
             const u32x4 z4 = {0u, 0u, 0u, 0u};
             __amdgpu_buffer_rsrc_t rz = make_rsrc(p.sout + ((SDP_EXP_BUILD && (p.dbg & 2)) ? 0 : (size_t)b) * plane_elems, plane_bytes);
             // rows [n, N): one contiguous run; stores past the end of the plane are dropped dword by dword
@@ -778,124 +588,67 @@ __device__ __forceinline__ void sweep(const Params &p)
         const int t_final = (s == nstrips - 1 && lane == rows - 1) ? (m - 1 + lane) : -1;
 
         // Skewed state addressing.  The state of a (pair, strip) is a sequence of UNITS of 32 steps; a unit is contiguous
-        // (packed Q: 16 record rows of 768 B -- a record row holds two steps of every lane, 12 B per lane, so one
-        // dwordx3 per lane moves two steps; float2 states: 32 rows of 512 B, step t, lane l at t*512 + l*8).  Where
+        // (packed Q: ten rows of 1024 B, see q20_soff below; float2 states: 32 rows of 512 B, step t, lane l at t*512 + l*8).  Where
         // unit u of (pair b, strip s) lives is given by two strides the host picks (sdp_api.hip::state_layout):
         //     byte offset = (b * nstrips + s) * ps + u * us + (offset inside the unit)
-        //   * contiguous strips (default): ps = units per strip * unit bytes, us = unit bytes -- every strip is one stream;
-        //   * "marching" (-DSDP_STATE_MARCH=1): ps = unit bytes, us = B * nstrips * unit bytes -- unit u of ALL strips of
-        //     ALL pairs is one contiguous slab.  The pairs of a full batch advance in lockstep, so the chip as a whole
-        //     then writes (forward) or reads (reverse) one region of memory at a time instead of B * nstrips distant
-        //     streams.  A bare stream of the same read/write mix runs 4 % faster that way (tools/ubench/mix2.hip); the
-        //     sweeps measured no different (sdp_api.hip::state_layout), so it is not the default.
+        // with ps = units per strip * unit bytes, us = unit bytes: every strip is one stream.  (A "marching" layout, unit u of all
+        // strips of all pairs in one slab, measured no different in round 3 and is gone; the strides stay parameters.)
         // One buffer descriptor per (pair, strip); the unit part of the offset is uniform and rides in the scalar
         // offset operand (which the hardware does not range-check), the lane offset is a per-lane constant.
         // (The descriptors' size is the largest one for which the out-of-range offset OOB still is out of range: whether or
-        // not the hardware adds the scalar offset before its range check, every state access below is accepted -- the
-        // host keeps a marching state below 2^31 bytes -- and nothing here relies on the check.)
+        // not the hardware adds the scalar offset before its range check, every state access below is accepted -- and
+        // nothing here relies on the check.)
         constexpr unsigned ST_RECORDS = 0x7fffffffu;
         const size_t ps_idx = b_st * p.nstrips_max + s;
-        const unsigned q_lane = lane * (Q20 ? 16 : 12);
-        // Dead lines (round 5).  The skewed state has a record for every (step, lane), also where the lane's cell lies outside
-        // the matrix: 64 of a strip's M + 64 step rows are such padding (11 % at M = 512).  Round 4 tried to skip the records of
-        // dead LANES and lost (partial 128-byte lines at the edge of a ramp).  Here whole lines only: a row of a 16-step block is
-        // eight lines of eight lanes (16 bytes each); a line is skipped when ALL eight lanes are outside the matrix for ALL 16
-        // steps of the block -- not started yet (8g > tb + 15, g = lane / 8) or done (tb > m + 8g + 6), or below a partial strip's
-        // last row.  Three quarters of the padding are such lines: 8.3 % of the state at M = 512.  Nothing depends on what a
-        // skipped line would have held: every field decodes to a finite weight, and cells outside the matrix hand on e = 0 (or,
-        // left of the matrix, only to each other).  The half rows of the 18-bit format are four lines of sixteen lanes.
-        auto q_lane_blk = [&](int tb, int lanes_per_line) -> unsigned {   // this lane's offset in a row of the block at step tb, or OOB
-            const int g0 = lane & ~(lanes_per_line - 1), g1 = g0 + lanes_per_line - 1;   // the line's first and last lane
-            const bool dead = (REV ? SDP_DEAD_LINES > 1 : SDP_DEAD_LINES > 0) && Q20 && (g0 > tb + 15 || tb > m - 1 + g1 || g0 >= rows);
-            return dead ? OOB : (lanes_per_line == 8 ? lane * 16u : lane * 8u);
-        };
-        unsigned q_lane_st = q_lane, q_lane_st2 = lane * 8;   // forward sweep: offsets of the block being stored (dwordx4 rows / the 18-bit half row)
+        const unsigned q_lane = lane * 16;
+        // (Two ways of not moving the skew padding -- the records of lanes that lie outside the matrix -- were built and dropped:
+        //  per-lane skipping in round 4 (partial 128-byte lines at the edge of a ramp: forward 210 -> 215 us), whole dead lines in
+        //  round 5 (bit-identical; forward alone 193 -> 185 us, nothing in the forward;backward sequence).  DESIGN_HISTORY.md.)
         __amdgpu_buffer_rsrc_t rs_q = make_rsrc(T::QIN == Q_PACKED ? (const void *)(reinterpret_cast<const char *>(p.qin) + ps_idx * p.st_ps)
                                                 : (T::QOUT == Q_PACKED ? (const void *)(static_cast<char *>(p.dout) + ps_idx * p.st_ps) : (const void *)p.vout),
                                                 (T::QIN == Q_PACKED || T::QOUT == Q_PACKED) ? ST_RECORDS : 0u);
-        // 24-bit fields: scalar offset of record row t_base/2 + g4 (g4 = 0, 4, 8, 12; t_base a multiple of the chunk length)
-        auto q_soff = [&](int t_base, int g4) { return (unsigned)(t_base >> 5) * p.st_us + (unsigned)((((t_base >> 1) & 15) + g4) * 768); };
-        // 20-bit fields: a 16-step BLOCK of a lane is 20 dwords (four records of five), kept as five rows of 1024 B -- row j holds
+        // Packed state: a 16-step BLOCK of a lane is 20 dwords (four records of five), kept as five rows of 1024 B -- row j holds
         // dwords 4j .. 4j+3 of every lane -- so that every access is a whole dwordx4 of contiguous 1 KB per wave: five memory
-        // instructions per 16 steps (the first layout of round 4, dwordx4 + dword per record, took eight; rounds 1-3 eight
-        // dwordx3).  A 32-step unit is two blocks, ten rows.  Scalar offset of row jr (0..4) of the block that holds step t:
-        // (18-bit fields, round 5: a block is 18 dwords -- four such rows and a fifth of one dwordx2 per lane, 512 B)
-        using QF_ = QFmt<QB>;
-        static_assert(QB == 20 || (QB == 18 && Q20 && !PARTS), "18-bit fields: the modern row layout, one workgroup per pair");
-        auto q20_soff = [&](int t, int jr) { return (unsigned)(t >> 5) * p.st_us + (unsigned)(((t >> 4) & 1) * QF_::BLK_BYTES + jr * 1024); };
-        typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+        // instructions per 16 steps.  A 32-step unit is two blocks, ten rows.  Scalar offset of row jr (0..4) of the block that
+        // holds step t:
+        auto q20_soff = [&](int t, int jr) { return (unsigned)(t >> 5) * p.st_us + (unsigned)(((t >> 4) & 1) * 5120 + jr * 1024); };
         typedef unsigned u32x4q __attribute__((ext_vector_type(4)));
-        // (an earlier variant sent the records of lanes that lie outside the matrix for all their steps out of range -- neither
-        //  written nor read, -DSDP_SKIP_DEAD of round 4 -- so that whole lines of the skew padding never crossed the fabric:
-        //  forward 210 -> 215 us, backward 161 -> 168 us; the lines at the edge of a ramp become partial accesses.  Removed.)
         // The ring of prefetched rows keeps every dwordx4 AS THE VECTOR it was loaded as.  Kept as scalars (rounds 1-3 did
         // that for the dwordx3 records) each dword is a loop-carried value of its own, the load needs consecutive registers
         // for them, and the compiler resolved that by loading elsewhere and COPYING all rows of the next chunk into place at
         // the end of every iteration -- behind an `s_waitcnt vmcnt(0)`.
         constexpr int QROWS = 5 * K / 16;   // rows (dwordx4 per lane) of a chunk
-        u32x4q rq2[2][Q20 ? QROWS : 1];   // two sets: the current chunk's rows and the next chunk's (roles swap every chunk, see ROT)
+        u32x4q rq2[2][QROWS];   // two sets: the current chunk's rows and the next chunk's (roles swap every chunk, see ROT)
         // ... and the rows of the NEXT chunk are a second set, loaded in one burst at the top of the iteration (TOPLOAD) and
         // moved over at its end: the wait for them then sits a whole iteration behind their issue.  (Refilling a slot of the
         // first set right after its last use -- the scheme of rounds 1-3 -- reads as the same thing, but the compiler gave the
         // refills registers of their own anyway and moved them over at the end of the iteration, behind a vmcnt(0) that the
         // loads issued during the last steps had had a few hundred cycles to meet: the reverse sweeps ran at memory latency.)
-        constexpr bool TOPLOAD = Q20 && REV && T::QIN == Q_PACKED;
+        constexpr bool TOPLOAD = REV && T::QIN == Q_PACKED;
         auto load_row = [&](__amdgpu_buffer_rsrc_t rs, int t_base, int jj, u32x4q &dst) {   // row jj of the chunk (five per 16-step block)
-            if constexpr (QF_::TAIL_X2) {
-                if (jj % 5 == 4) {   // the block's two last dwords: one dwordx2 per lane
-                    const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, q_lane_blk(t_base + 16 * (jj / 5), 16), q20_soff(t_base + 16 * (jj / 5), 4), AUX_ST_LOAD);
-                    const unsigned v0 = v[0], v1 = v[1];
-                    dst[0] = v0, dst[1] = v1;
-                    return;
-                }
-            }
-            dst = __builtin_amdgcn_raw_buffer_load_b128(rs, q_lane_blk(t_base + 16 * (jj / 5), 8), q20_soff(t_base + 16 * (jj / 5), jj % 5), AUX_ST_LOAD);
+            dst = __builtin_amdgcn_raw_buffer_load_b128(rs, q_lane, q20_soff(t_base + 16 * (jj / 5), jj % 5), AUX_ST_LOAD);
         };
         auto load_q20 = [&](int t_base, int jj, auto set_tag) {   // row jj (0 .. QROWS-1) of the chunk that starts at step t_base -> set S
             load_row(rs_q, t_base, jj, rq2[decltype(set_tag)::value][jj]);
         };
         // the five dwords of the record of steps 4g .. 4g+3 of the chunk, out of the rows of set S
-        auto q20_record = [&](int g, unsigned *w, auto set_tag) {   // (QB = 18: the nine dwords of the record of steps 8g .. 8g+7)
-            constexpr int RPB = 16 / QF_::REC_STEPS;   // records per block
+        auto q20_record = [&](int g, unsigned *w, auto set_tag) {
 #pragma unroll
-            for (int e = 0; e < QF_::REC_DW; ++e) {
-                const int d = QF_::REC_DW * (g % RPB) + e;           // dword of the block
-                w[e] = rq2[decltype(set_tag)::value][5 * (g / RPB) + (d >> 2)][d & 3];
+            for (int e = 0; e < 5; ++e) {
+                const int d = 5 * (g % 4) + e;           // dword of the block
+                w[e] = rq2[decltype(set_tag)::value][5 * (g / 4) + (d >> 2)][d & 3];
             }
         };
-        auto load_q = [&](int t_base, int g, unsigned *dst) {  // 24-bit: steps t_base + 2g, + 1 (3 dwords)
-            if constexpr (!Q20) {
-                const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs_q, q_lane + (g & 3) * 768, q_soff(t_base, g & ~3), AUX_ST_LOAD);
-                const unsigned v0 = v[0], v1 = v[1], v2 = v[2];
-                dst[0] = v0, dst[1] = v1, dst[2] = v2;
-            }
-        };
-        auto store_q = [&](int t_base, int g, const unsigned *src) {
+        auto store_q = [&](int t_base, int g, const unsigned *src) {   // g: row of the block that holds step t_base (src: its four dwords)
             // A VALU instruction that overwrites a data register of a store wider than 64 bits in the very next
             // issue slot corrupts the stored value for part of the wave on gfx950 (seen: lanes 12-15 of every
             // 16).  The compiler only inserts the wait state for stores without a scalar offset register, so it
             // is forced here: the no-op "reads" the data registers (nothing that overwrites them can move above
             // it) and is ordered after the store as a memory operation.
-            if constexpr (Q20) {   // g: row of the block that holds step t_base (src: its four dwords)
-                if constexpr (QF_::TAIL_X2) {
-                    if (g == 4) {   // (18-bit fields) the block's two last dwords
-                        typedef unsigned u32x2q __attribute__((ext_vector_type(2)));
-                        u32x2q v2;
-                        v2[0] = src[0], v2[1] = src[1];
-                        __builtin_amdgcn_raw_buffer_store_b64(v2, rs_q, q_lane_st2, q20_soff(t_base, 4), AUX_ST_STORE);
-                        return;
-                    }
-                }
-                u32x4q v;
-                v[0] = src[0], v[1] = src[1], v[2] = src[2], v[3] = src[3];
-                __builtin_amdgcn_raw_buffer_store_b128(v, rs_q, q_lane_st, q20_soff(t_base, g), AUX_ST_STORE);
-                asm volatile("s_nop 1" : : "v"(v) : "memory");
-            } else {
-                u32x3 v;
-                v[0] = src[0], v[1] = src[1], v[2] = src[2];
-                __builtin_amdgcn_raw_buffer_store_b96(v, rs_q, q_lane + (g & 3) * 768, q_soff(t_base, g & ~3), AUX_ST_STORE);
-                asm volatile("s_nop 1" : : "v"(v) : "memory");
-            }
+            u32x4q v;
+            v[0] = src[0], v[1] = src[1], v[2] = src[2], v[3] = src[3];
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs_q, q_lane, q20_soff(t_base, g), AUX_ST_STORE);
+            asm volatile("s_nop 1" : : "v"(v) : "memory");
         };
         // float2 states (Qd, and Q in its exact form).  Cells outside the matrix are stored like any other (their
         // values are never used: every reader masks them).
@@ -923,67 +676,30 @@ __device__ __forceinline__ void sweep(const Params &p)
             __builtin_amdgcn_raw_buffer_store_b64(v, rs, st_lane + (k & 7) * 512, f2_soff(t_base, k & ~7), AUX_ST_STORE);
         };
         auto load_d = [&](int t_base, int k) { return load_f2(rs_d, t_base, k); };
-        // packed state, forward: the two biased fields of a cell (bits of QF_BASE + q * QF_SCALE) arrive per step.  24-bit
-        // fields: every second step three byte-permutes assemble the 12-byte record of the pair and one dwordx3 store moves
-        // it.  20-bit fields: every fourth step 13 shift / mask / or instructions assemble the 20-byte record of four cells,
-        // stored as dwordx4 + dword.
-        unsigned qbits_x = 0, qbits_y = 0;
-        unsigned qb_x[QB == 18 ? 7 : 3] = {0, 0, 0}, qb_y[QB == 18 ? 7 : 3] = {0, 0, 0};
-        unsigned qblk[20];   // 20-bit fields: the dwords of the current 16-step block; a row leaves as soon as it is complete
+        // packed state, forward: the two biased fields of a cell (bits of QF_BASE + q * QF_SCALE) arrive per step; every fourth
+        // step 13 shift / mask / or instructions assemble the 20-byte record of four cells, and a row of the block (four dwords per
+        // lane) leaves as soon as it is complete
+        unsigned qb_x[3] = {0, 0, 0}, qb_y[3] = {0, 0, 0};
+        unsigned qblk[20];   // the dwords of the current 16-step block
         auto store_state_bits = [&](int t_base, int k, unsigned fx, unsigned fy) {
-            if constexpr (QB == 18) {
-                // eight cells to a record of nine dwords; a block's rows 0, 1 are complete after its first record, rows 2, 3 and
-                // the half row after its second
-                if ((k & 7) != 7) {
-#pragma unroll
-                    for (int j = 0; j < 7; ++j)
-                        if ((k & 7) == j) qb_x[j] = fx, qb_y[j] = fy;
-                } else {
-                    const unsigned ax[8] = {qb_x[0], qb_x[1], qb_x[2], qb_x[3], qb_x[4], qb_x[5], qb_x[6], fx};
-                    const unsigned ay[8] = {qb_y[0], qb_y[1], qb_y[2], qb_y[3], qb_y[4], qb_y[5], qb_y[6], fy};
-                    const int g = (k >> 3) & 1;   // record of the block
-                    q18_pack8(ax, ay, qblk + 9 * g);
-                    const int tb16 = t_base + (k & ~15);
-                    if (g == 0) store_q(tb16, 0, qblk), store_q(tb16, 1, qblk + 4);
-                    else store_q(tb16, 2, qblk + 8), store_q(tb16, 3, qblk + 12), store_q(tb16, 4, qblk + 16);
-                }
-            } else if constexpr (Q20) {
-                if ((k & 3) == 0) qb_x[0] = fx, qb_y[0] = fy;
-                else if ((k & 3) == 1) qb_x[1] = fx, qb_y[1] = fy;
-                else if ((k & 3) == 2) qb_x[2] = fx, qb_y[2] = fy;
-                else {
-                    const unsigned ax[4] = {qb_x[0], qb_x[1], qb_x[2], fx}, ay[4] = {qb_y[0], qb_y[1], qb_y[2], fy};
-                    const int g = (k >> 2) & 3;   // record of the block
-                    q20_pack4(ax, ay, qblk + 5 * g);
-                    const int tb16 = t_base + (k & ~15);
-                    if (g == 0) store_q(tb16, 0, qblk);
-                    else if (g == 1) store_q(tb16, 1, qblk + 4);
-                    else if (g == 2) store_q(tb16, 2, qblk + 8);
-                    else store_q(tb16, 3, qblk + 12), store_q(tb16, 4, qblk + 16);
-                }
-            } else if ((k & 1) == 0) {
-                qbits_x = fx, qbits_y = fy;
-            } else {
-                unsigned w[3];
-                w[0] = __builtin_amdgcn_perm(qbits_y, qbits_x, 0x04020100u);
-                w[1] = __builtin_amdgcn_perm(fx, qbits_y, 0x05040201u);
-                w[2] = __builtin_amdgcn_perm(fy, fx, 0x06050402u);
-                store_q(t_base, k >> 1, w);
+            if ((k & 3) == 0) qb_x[0] = fx, qb_y[0] = fy;
+            else if ((k & 3) == 1) qb_x[1] = fx, qb_y[1] = fy;
+            else if ((k & 3) == 2) qb_x[2] = fx, qb_y[2] = fy;
+            else {
+                const unsigned ax[4] = {qb_x[0], qb_x[1], qb_x[2], fx}, ay[4] = {qb_y[0], qb_y[1], qb_y[2], fy};
+                const int g = (k >> 2) & 3;   // record of the block
+                q20_pack4(ax, ay, qblk + 5 * g);
+                const int tb16 = t_base + (k & ~15);
+                if (g == 0) store_q(tb16, 0, qblk);
+                else if (g == 1) store_q(tb16, 1, qblk + 4);
+                else if (g == 2) store_q(tb16, 2, qblk + 8);
+                else store_q(tb16, 3, qblk + 12), store_q(tb16, 4, qblk + 16);
             }
         };
-        float2 qhold;  // forward: weights of the even step of the current pair of steps
         // the state this pass produces, step t_base + k
         auto store_state = [&](int t_base, int k, float2 qq) {
-            if constexpr (T::QOUT == Q_PACKED && Q20) {
-                store_state_bits(t_base, k, __float_as_uint(__builtin_fmaf(qq.x, qf_scale<QB>(), qf_base<QB>())), __float_as_uint(__builtin_fmaf(qq.y, qf_scale<QB>(), qf_base<QB>())));
-            } else if constexpr (T::QOUT == Q_PACKED) {
-                if ((k & 1) == 0) {
-                    qhold = qq;
-                } else {
-                    unsigned w[3];
-                    q_pack2(qhold, qq, w);
-                    store_q(t_base, k >> 1, w);
-                }
+            if constexpr (T::QOUT == Q_PACKED) {
+                store_state_bits(t_base, k, __float_as_uint(__builtin_fmaf(qq.x, QF_SCALE, QF_BASE)), __float_as_uint(__builtin_fmaf(qq.y, QF_SCALE, QF_BASE)));
             } else if constexpr (T::QOUT == Q_EXACT) {
                 store_f2(rs_qx, t_base, k, qq);
             } else {
@@ -1007,28 +723,24 @@ __device__ __forceinline__ void sweep(const Params &p)
         // chunk's E is zero if the two block sets that cover it are.  Zeros with a sign: a computed zero chunk leaves +0 in
         // a and b but may leave -0 in c (qm < 0 by a rounding, times +0); the skipped one leaves +0.  The difference can only
         // ever surface as the SIGN of a zero in Ed, so Ed is stored as (float)ed + 0.0f in both paths: bit-identical results.
-        constexpr bool ZSKIP_A = PASS == PASS_ABWD && KIND == CK_F64 && SDP_ZERO_SKIP_ADJ && !ABL_NOMATH && !ABL_NOLOAD && SDP_TOPLOAD != 0;
+        constexpr bool ZSKIP_A = PASS == PASS_ABWD && !ABL_NOMATH && !ABL_NOLOAD;
         float rs[ZSKIP_A ? 2 : 1][NS][K];   // staged inputs of the NEXT chunk (registers); ZSKIP_A: of the next two chunks
-        constexpr int QREC_STEPS = Q20 ? 4 : 2, QREC_DW = Q20 ? 5 : 3;   // steps and dwords of one packed record
-        unsigned rq[Q20 ? 1 : QREC_DW * K / QREC_STEPS];  // 24-bit fields: packed Q of the current chunk, one record per 2 steps; a record is refilled
-                                 // with the same steps of the next chunk as soon as both have been consumed
         // exact Q rows / Qd rows: slot k of a set holds step t0+k of a chunk; two sets whose roles (current chunk / next chunk)
-        // swap every chunk (ROT) -- or one set whose slots are refilled right after use (-DSDP_TOPLOAD=0)
+        // swap every chunk (ROT)
         float2 rqx2[2][K];
         float2 rdd2[2][K];
-        // TOPLOAD_X: the rows of the next chunk are a second set, loaded in one burst at the top of the iteration and moved over
-        // at its end (see TOPLOAD); otherwise a slot is refilled right after it has been consumed
-        constexpr bool TOPLOAD_X = SDP_TOPLOAD != 0 && (T::QIN == Q_EXACT || T::DIN);
+        // TOPLOAD_X: the rows of the next chunk are a second set, loaded in one burst at the top of the iteration (see TOPLOAD)
+        constexpr bool TOPLOAD_X = T::QIN == Q_EXACT || T::DIN;
         // fp32 reverse sweep: the K boundary values of a chunk travel through LDS as 16-byte accesses (K / 4 instead of K instructions each way)
-        constexpr bool VEC_BND = REV && PASS == PASS_BWD && KIND == CK_F32 && sizeof(slot_t) == 4 && K % 4 == 0 && SDP_VEC_BND;
+        constexpr bool VEC_BND = PASS == PASS_BWD && sizeof(slot_t) == 4 && K % 4 == 0;
         // Exact zeros (see the chunk loop): the fp32 backward sweep skips the steps of chunks that can only produce +0, and (LAZY)
         // does not fetch the state rows of a chunk it already knows to be one.  There is ONE place per iteration where the next
         // chunk's rows are requested, and the request is always issued: a fetch that is not wanted goes through a buffer
         // descriptor of zero records, which returns zeros without touching memory.  (Loads under a branch, or at a second site
         // for the rare case, make the loaded registers phi nodes: copies behind waits, and a conservative wait in front of the
         // rows' first use -- measured, both.)
-        constexpr bool ZSKIP = REV && PASS == PASS_BWD && KIND == CK_F32 && !SDP_BWD_HALF && !ABL_NOMATH && SDP_ZERO_SKIP;
-        constexpr bool LAZY = ZSKIP && !ABL_NOLOAD && (TOPLOAD || TOPLOAD_X) && SDP_ZERO_SKIP > 1;
+        constexpr bool ZSKIP = PASS == PASS_BWD && !ABL_NOMATH;
+        constexpr bool LAZY = ZSKIP && !ABL_NOLOAD;
         bool known_zero = false;   // the chunk about to be processed is a zero chunk (found out an iteration ahead): its rows were not fetched
         bool za_b1 = false, za_b2 = false;   // (ZSKIP_A) the staged E block sets c and c + 1 -- the two that cover the chunk about to be processed -- are all zero
         int zring = 0;             // bit h: half h of the output ring is known to hold +0 everywhere (written by a zero chunk)
@@ -1166,7 +878,7 @@ __device__ __forceinline__ void sweep(const Params &p)
         // only, a row pitch that is not a multiple of 32 floats made every 128-byte store straddle two lines: the
         // backward sweep ran 2.1-2.4x slower at M = 516 than at M = 512.)  fo_off0 is the LDS index when the current
         // chunk has parity 0, fo_dk the change when it has parity 1, fo_voff the global byte offset (row i0, t0 = 0).
-        constexpr bool FLUSH2 = T::SOUT > 0 && !GEN && K == 32 && SDP_FLUSH2;   // (see below)
+        constexpr bool FLUSH2 = T::SOUT > 0 && !GEN && K == 32;   // (see below)
         int fo_off0[FLUSH2 ? 1 : K], fo_dk[FLUSH2 ? 1 : K];
         unsigned fo_voff[FLUSH2 ? 1 : K];
         bool fo_need_tail = false;
@@ -1207,7 +919,7 @@ __device__ __forceinline__ void sweep(const Params &p)
         const int f2_rl = 8 * ((lane >> 4) >> 1) + 16 * ((lane >> 4) & 1), f2_el = 2 * (lane & 15);
         const int f2_l = f2_rl * PO + f2_rl + f2_el, f2_g = f2_rl * ld + f2_el;
         const int f2_rl_c = f2_rl, f2_el_c = f2_el, f2_l_c = f2_l, f2_g_c = f2_g, r_l_c = r_l, s_l_c = s_l;   // (for the opaque copies in flush_out's rare paths)
-        // FLUSH4 (-DSDP_FLUSH4=1): four columns per lane and store.  Instruction k4 (0..7), lane -> row r = c + rl, c = 4 (k4 & 3) + 32 (k4 >> 2),
+        // Plain flushes of the builds without the pipelined chunk: four columns per lane and store (the same 16 aligned 8-byte LDS reads, but 8 dwordx4 stores instead of 16 dwordx2).  Instruction k4 (0..7), lane -> row r = c + rl, c = 4 (k4 & 3) + 32 (k4 >> 2),
         //   rl = (a & 1) + 16 ((a >> 1) & 1) + 2 (a >> 2), a = lane >> 3 -- the four rows of a 32-lane LDS group are r, r + 1 (bank bases two
         //   floats apart: their 8-byte reads at columns 4 g interleave) and r + 16, r + 17 (32 banks further); columns e_l .. e_l + 3, e_l = 4 (lane & 7)
         //   LDS index (parity 0) of pair j = [c PO + 4 (k4 & 3)] + f4_l + 2 j;  global float offset = [c ld - 32 (k4 >> 2)] + f4_g
@@ -1244,7 +956,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                     } else {
                         // each dword is range-checked on its own (tools/ubench/bufx4.hip), and only dword
                         // alignment is needed, so M need not be a multiple of 4
-                        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_in[q], off, plain ? ubase - bias : 0, (LINES && SDP_LINES_NT) ? SDP_LINES_AUX : AUX_IN_LOAD);
+                        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_in[q], off, plain ? ubase - bias : 0, LINES ? AUX_LINES_LOAD : AUX_IN_LOAD);
                         const unsigned v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
                         rs[RS][q][4 * i] = __uint_as_float(v0);
                         rs[RS][q][4 * i + 1] = __uint_as_float(v1);
@@ -1320,19 +1032,9 @@ __device__ __forceinline__ void sweep(const Params &p)
         }
         if constexpr (T::QIN == Q_PACKED) {
 #pragma unroll
-            for (int g = 0; g < K / QREC_STEPS; ++g) {
-                if constexpr (ABL_NOLOAD) {
-                    if constexpr (!Q20) for (int j = 0; j < QREC_DW; ++j) rq[QREC_DW * g + j] = 0x20003000u + 64 * g + lane;
-                } else {
-                    if constexpr (!Q20) load_q(c_first * K, g, rq + QREC_DW * g);
-                }
-            }
-            if constexpr (Q20) {
-#pragma unroll
-                for (int jj = 0; jj < QROWS; ++jj) {
-                    if constexpr (ABL_NOLOAD) rq2[0][jj] = rq2[1][jj] = (u32x4q){0x20003000u + 64 * jj + lane, 0x20003000u, 0x20003000u, 0x20003000u};
-                    else if constexpr (!LAZY) load_q20(c_first * K, jj, std::integral_constant<int, 0>{});
-                }
+            for (int jj = 0; jj < QROWS; ++jj) {
+                if constexpr (ABL_NOLOAD) rq2[0][jj] = rq2[1][jj] = (u32x4q){0x20003000u + 64 * jj + lane, 0x20003000u, 0x20003000u, 0x20003000u};
+                else if constexpr (!LAZY) load_q20(c_first * K, jj, std::integral_constant<int, 0>{});
             }
         }
         if constexpr (T::DIN) {
@@ -1369,7 +1071,7 @@ __device__ __forceinline__ void sweep(const Params &p)
         // all but one of the loads it had just issued for the NEXT chunk were back: the prefetch distance was not a chunk but
         // the few hundred cycles up to that point, and the reverse sweeps ran at memory latency (round 4, cycle stamps:
         // 900-2200 cycles per chunk in a phase that issues eight LDS writes).  The price: one exposed latency per strip.
-        if constexpr ((REV || T::QIN == Q_EXACT) && SDP_PROLOGUE_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);
+        if constexpr (REV || T::QIN == Q_EXACT) __builtin_amdgcn_s_waitcnt(0x0F70);
 
         // ---- forward sweep, exp domain: the K steps of a chunk are computed in blocks of WB = 16 ----
         // The chunk (K steps) stays the unit of the memory pipeline -- staged input blocks, state prefetch distance --
@@ -1382,7 +1084,7 @@ __device__ __forceinline__ void sweep(const Params &p)
         // value leaves the safe range nothing was committed and the block is redone in the per-step-normalised form.
         // Both forms produce identical bits (same 2^theta, exact power-of-two rescaling), so results do not depend on
         // which form a block ran in, on K, or on the batch.
-        constexpr bool FWD_SUB = PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_WF && SDP_FWD_SUB;
+        constexpr bool FWD_SUB = PASS == PASS_FWD && !ABL_NOMATH;
         auto read_inputs = [&](int tb, float *d0, float *d1) {
             const int pr = (tb & (RING - 1)) + 4 * ring_pi(lane & 7);
 #pragma unroll
@@ -1513,7 +1215,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                 for (int j = 0; j < WB; ++j) bcv[j] = edge_zero<KIND>();
             }
         };
-        auto fwd_blocks = [&](int c, int t0, auto &&stage_next) {
+        auto fwd_blocks = [&](int c, int t0) {
             if constexpr (FWD_SUB) {
                 int thr = lane + (sw ? 1 : 0);  // EDGE: the lane's cell is live at step t iff t >= thr
                 if (sw && i0 + lane == 0) thr = 0x7fffffff;  // padded row 1 of Smith-Waterman never is
@@ -1521,10 +1223,6 @@ __device__ __forceinline__ void sweep(const Params &p)
                     constexpr int sb = decltype(sb_tag)::value;
                     const int tb = t0 + sb * WB;
                     const bool blk_interior = plain_strip && tb >= 63 && tb + WB < m;
-                    if constexpr (T::QOUT == Q_PACKED) {   // dead lines of the skew padding are not stored (q_lane_blk)
-                        q_lane_st = blk_interior ? q_lane : q_lane_blk(tb, 8);
-                        if constexpr (QF_::TAIL_X2) q_lane_st2 = blk_interior ? lane * 8u : q_lane_blk(tb, 16);
-                    }
                     // experiments build, sdp_set_trace: shader-cycle stamps of this block -- [pair / 64][wave][strip round][block][4]
                     auto stamp = [&](int k) {
                         if constexpr (SDP_EXP_BUILD != 0) {
@@ -1600,12 +1298,6 @@ __device__ __forceinline__ void sweep(const Params &p)
                             read_boundary(tb, bcf0, fa0, fb0);
                         }
                     }
-                    // (-DSDP_STAGE_EARLY=1) The chunk's LAST block has read its inputs: the ring half of the oldest block set is dead,
-                    // and the block set loaded at the top of this chunk could go into it NOW rather than after the block, where
-                    // its loads are waited for behind the block's own state stores (`s_waitcnt vmcnt(0)`: the compiler counts only
-                    // what every path is sure to have issued).  Built and measured in round 4: forward 214 -> 217 us at 256 x 512^2,
-                    // 791 -> 801 at 256 x 1024^2 -- the store acknowledgements are not what the forward sweep waits for.  Off.
-                    if constexpr (SDP_STAGE_EARLY && sb == K / WB - 1) stage_next();
                     u64 hist[WB];
                     int frame_pub = FRAME_NONE;
                     stamp(1);
@@ -1751,7 +1443,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                             } else {
                                 // both weights with one packed multiply, their biased fields with one packed fma
                                 const f32x2 w = (f32x2){u, x} * (f32x2){tq, tq};
-                                const f32x2 f = __builtin_elementwise_fma(w, (f32x2){qf_scale<QB>(), qf_scale<QB>()}, (f32x2){qf_base<QB>(), qf_base<QB>()});
+                                const f32x2 f = __builtin_elementwise_fma(w, (f32x2){QF_SCALE, QF_SCALE}, (f32x2){QF_BASE, QF_BASE});
                                 if constexpr (ABL_NOSTORE) { float fx = f[0], fy = f[1]; keep(fx); keep(fy); }
                                 else store_state_bits(tb, j, __float_as_uint(f[0]), __float_as_uint(f[1]));
                             }
@@ -1853,8 +1545,8 @@ __device__ __forceinline__ void sweep(const Params &p)
                                 q_sharpen(qq.x, qq.y, d * rinv);
                                 if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); }
                                 else if constexpr (QX) store_state(tb, j, qq);
-                                else store_state_bits(tb, j, __float_as_uint(__builtin_fmaf(qq.x, qf_scale<QB>(), qf_base<QB>())),
-                                                      __float_as_uint(__builtin_fmaf(qq.y, qf_scale<QB>(), qf_base<QB>())));
+                                else store_state_bits(tb, j, __float_as_uint(__builtin_fmaf(qq.x, QF_SCALE, QF_BASE)),
+                                                      __float_as_uint(__builtin_fmaf(qq.y, QF_SCALE, QF_BASE)));
                             }
                             const float an = ct * ssum;
                             float na = __builtin_amdgcn_frexp_mantf(an);
@@ -1943,7 +1635,7 @@ __device__ __forceinline__ void sweep(const Params &p)
         //     the progress word is left for the end of the chunk.
         // The wait for the state rows (requested an iteration ago) sits at the top of the iteration and counts the stores a
         // pipelined chunk issued behind that request (tail_st).
-        constexpr bool PIPE = FLUSH2 && LAZY && SDP_BWD_PIPE && !NOPIPE;   // (NOPIPE: the twin build for short pairs, see sdp_bwd_kernel below)
+        constexpr bool PIPE = FLUSH2 && LAZY && !NOPIPE;   // (NOPIPE: the twin build for short pairs, see sdp_bwd_kernel below)
         static_assert(!FLUSH2 || T::SIN == 0 || K <= 16, "FLUSH2 writes one float in front of lds_out: there must be no staged input plane before it");
         // the plain flush in two halves: LDS -> registers, registers -> memory (all 64 x 32 elements are real cells)
         auto flush_read = [&](int par, bool zero, float2 *vals) {
@@ -1988,7 +1680,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                     // per-lane tests, the global offset is one per-lane base plus a scalar, the LDS index one per-lane base plus a
                     // constant -- no vector arithmetic at all when the chunk has parity 0, a compare-and-select per row class when 1
                     const bool flush_plain = active && rows == 64 && t0 >= K && t0 + K <= m;
-                    if (flush_plain && SDP_FLUSH_FAST && SDP_FLUSH4 && !PIPE) {
+                    if (flush_plain && !PIPE) {   // (PIPE: plain flushes are deferred -- flush_read / flush_store1 -- and never get here)
                         if (zero) flush_zero8(t0);
                         else {
                             float2 vals[K / 2];
@@ -2012,32 +1704,6 @@ __device__ __forceinline__ void sweep(const Params &p)
                             }
                         }
                         if constexpr (LAZY && !PIPE) __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8): everything older than these K / 4 stores
-                    } else if (flush_plain && SDP_FLUSH_FAST) {
-                        float2 vals[K / 2];
-                        const int thr_l = K - 1 - f2_rl - f2_el;   // (k2 & 7) < thr_l  <=>  sfull < K - 1
-                        if (zero) {
-#pragma unroll
-                            for (int k2 = 0; k2 < K / 2; ++k2) vals[k2] = make_float2(0.f, 0.f);
-                        } else if (par) {
-#pragma unroll
-                            for (int k2 = 0; k2 < K / 2; ++k2) {
-                                const int idx = ((k2 & 7) + 32 * (k2 >> 3)) * PO + (k2 & 7) + f2_l + ((k2 & 7) < thr_l ? K : -K);
-                                vals[k2] = *reinterpret_cast<const float2 *>(__builtin_assume_aligned(lds_out + idx, 8));
-                            }
-                        } else {
-#pragma unroll
-                            for (int k2 = 0; k2 < K / 2; ++k2)
-                                vals[k2] = *reinterpret_cast<const float2 *>(__builtin_assume_aligned(lds_out + f2_l + ((k2 & 7) + 32 * (k2 >> 3)) * PO + (k2 & 7), 8));
-                        }
-#pragma unroll
-                        for (int k2 = 0; k2 < K / 2; ++k2) {
-                            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                            const int c_r = (k2 & 7) + 32 * (k2 >> 3);
-                            if constexpr (ABL_NOSTORE) { keep(vals[k2].x); keep(vals[k2].y); }
-                            else __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(vals[k2].x), __float_as_uint(vals[k2].y)}, rs_out, (unsigned)(f2_g * 4),
-                                                                       ubase + (c_r * ld - 32 * (k2 >> 3)) * 4, AUX_OUT_STORE);
-                        }
-                        if constexpr (LAZY && !PIPE) __builtin_amdgcn_s_waitcnt(0x4F70);   // vmcnt(16): everything older than these K / 2 stores
                     } else if ((m & 1) == 0) {   // (uniform)
                         float2 vals[K / 2];
                         // (the per-lane constants pass through an opaque copy: the compiler otherwise hoists the 16 + 32 index /
@@ -2135,19 +1801,11 @@ __device__ __forceinline__ void sweep(const Params &p)
             // (the last chunk re-reads its own set: harmless, keeps the step body branch-free)
             const int bb_new = more ? (REV ? c - 1 : c + 2) : c;
             // ---- boundary values for the edge lane: broadcast LDS reads, off the dependency chain ----
-            // HALF (fp32 backward sweep, one workgroup per pair; -DSDP_BWD_HALF=1): the chunk's 32 steps take their boundary
-            // values in two halves of 16 and hand their own down in two halves, each with its progress word -- the strip below
-            // then trails by 63 + 16 steps instead of 63 + 32 (three lags per pair at the headline shape: 1387 instead of 1435
-            // steps).  Built, bit-identical, measured in round 4 and NOT adopted: backward 164 -> 179 us at 256 x 512^2,
-            // 491 -> 532 at 256 x 1024^2 (same box, interleaved) -- the second wait in the middle of a chunk exposes an LDS
-            // round trip and a poll on a sweep that is waiting for memory most of the time, and that costs more than 48
-            // steps of lag return.
-            constexpr bool HALF = REV && PASS == PASS_BWD && KIND == CK_F32 && !PARTS && K == 32 && SDP_BWD_HALF;
             u64 bcv[K];
             // fwd: lane 0 at step t0+k needs column t0+k; rev: lane 63 needs column t0+k-63
             const int c_lo = REV ? t0 - 63 : t0;
-            auto acquire = [&](auto k0_tag, auto k1_tag) {   // boundary values of steps t0 + k, k in [K0, K1)
-                constexpr int K0 = decltype(k0_tag)::value, K1 = decltype(k1_tag)::value;
+            auto acquire = [&]() {   // boundary values of the chunk's steps t0 + k, k in [0, K)
+                constexpr int K0 = 0, K1 = K;
                 int need = 0;  // progress value that guarantees those columns are published
                 if (has_pred) {
                     if (REV) {   // (published from the right: the lowest column decides)
@@ -2158,7 +1816,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         need = (c_lo + K0 < m) ? hi : 0;
                     }
                 }
-                if constexpr (REV && KIND == CK_F32) {
+                if constexpr (PASS == PASS_BWD) {
                     if (need > 0 && imported) {
                         // replay the producer's chunks (it works through the columns from the right, K at a time, and leaves the
                         // progress word at m - first column) down to the one that holds the lowest column needed here
@@ -2246,23 +1904,19 @@ __device__ __forceinline__ void sweep(const Params &p)
                     for (int k = K0; k < K1; ++k) bcv[k] = edge_zero<KIND>();
                 }
             };
-            using kc0 = std::integral_constant<int, 0>;
-            using kch = std::integral_constant<int, K / 2>;
-            using kc1 = std::integral_constant<int, K>;
             u64 hist[K];  // the edge-facing carry after each step (published below by one lane)
             const int par = c & 1;
             float *lo = lds_out + lane * PO + par * K;  // this lane's row, this chunk's half of the ring
-            bool pub_vals_done = false;   // (PIPE) the pipelined steps have written this chunk's boundary values already
             // ---- publish boundary values for the next strip (one lane), then the progress word ----
-            auto publish_range = [&](auto k0_tag, auto k1_tag, int *wf_frames_) {   // values of steps t0 + k, k in [K0, K1)
-                constexpr int K0 = decltype(k0_tag)::value, K1 = decltype(k1_tag)::value;
+            auto publish_range = [&]() {   // values of the chunk's steps t0 + k, k in [0, K)
+                constexpr int K0 = 0, K1 = K;
                 if (!has_succ) return;
                 // fwd: lane 63 produced column t0+k-63 at step k; rev: lane 0 produced column t0+k
                 const int p_lo = REV ? t0 : t0 - 63;
                 // (reverse sweeps: a chunk that lies right of the matrix for the publishing lane -- the first one or two of every
                 //  strip -- has no value to hand on, only its progress word; the column-by-column path below took ~3000 cycles
                 //  to find that out, on the strip above's way to its first chunk)
-                if (lane == PUB_LANE && !pub_vals_done && !(REV && p_lo + K0 >= m)) {
+                if (lane == PUB_LANE && !(REV && p_lo + K0 >= m)) {
                     if constexpr (VEC_BND && K0 == 0 && K1 == K) {
                         if (p_lo + K <= m) {   // (p_lo = t0: a multiple of K slots of four bytes)
                             uint4 *dst = reinterpret_cast<uint4 *>(bnd_out + p_lo);
@@ -2296,14 +1950,14 @@ __device__ __forceinline__ void sweep(const Params &p)
                 }
                 // LDS executes a wave's DS instructions in order, so the data written above is visible to
                 // any wave that observes this word (the asm statements also stop compiler reordering)
-                if constexpr (PASS == PASS_FWD && KIND == CK_EXP) {
+                if constexpr (PASS == PASS_FWD) {   // (only the ablation build without the recurrence publishes a forward chunk from here)
                     if (lane == PUB_LANE) {
 #pragma unroll
-                        for (int sb = 0; sb < K / WB; ++sb) frm_out[c * (K / WB) + sb] = wf_frames_[sb];
+                        for (int sb = 0; sb < K / WB; ++sb) frm_out[c * (K / WB) + sb] = FRAME_NONE;
                     }
                 }
                 if (lane == PUB_LANE && !(SDP_EXP_BUILD && (p.dbg & 8))) lds_store_i32(prog + 4 * oword, obase + done);
-                if constexpr (REV && KIND == CK_F32) {
+                if constexpr (PASS == PASS_BWD) {
                     if (exported && t0 < m) {
                         // the chunk's columns to the bridge row, one granule per lane (tag 0; columns past the matrix: dummies)
                         const int col = t0 + lane;
@@ -2352,7 +2006,7 @@ __device__ __forceinline__ void sweep(const Params &p)
             // the 16 output stores issued behind those loads, the counter retires in order, and so the ten youngest operations
             // are stores and the wait takes the rows just requested for the NEXT chunk along: the prefetch distance shrinks to
             // the few hundred cycles of the flush.
-            if constexpr (ROT && SDP_PROLOGUE_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);
+            if constexpr (ROT) __builtin_amdgcn_s_waitcnt(0x0F70);
             if constexpr (TOPLOAD_X && !ABL_NOLOAD && !ZSKIP_A) {   // (ZSKIP_A: requested further down, once the kind of the next chunk is known)
                 if (ci < nchunks) {   // (uniform; the extra flush iterations load nothing)
                     const int c_ = REV ? nchunks - 1 - ci : ci;
@@ -2378,7 +2032,7 @@ __device__ __forceinline__ void sweep(const Params &p)
             const bool fl_zero = ZSKIP && zring == 3;   // ... and they are all +0 (the last two chunks were zero chunks)
             if constexpr (T::SOUT > 0) {
                 if constexpr (PIPE) {
-                    fl_defer = ci > 0 && rows == 64 && pf_t0 >= K && pf_t0 + K <= m && SDP_FLUSH_FAST;   // the plain flush: every element a real cell
+                    fl_defer = ci > 0 && rows == 64 && pf_t0 >= K && pf_t0 + K <= m;   // the plain flush: every element a real cell
                     if (fl_defer) flush_read(pf_par, fl_zero, fv);
                     else {
                         flush_out(pf_t0, pf_par, ci > 0, ZSKIP && zring == 3);
@@ -2420,7 +2074,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                 auto mag64 = [](u64 v) -> unsigned { return hi32(v) & 0x7fffffffu; };   // < TINY iff |v| < 2^-170
                 bool zc = known_zero;
                 if (!zc) {
-                    acquire(kc0{}, kc1{});
+                    acquire();
                     za_acquired = true;
                     unsigned big = max(max(mag64((u64)__double_as_longlong(cy.a)), mag64((u64)__double_as_longlong(cy.b))), mag64((u64)__double_as_longlong(cy.c)));
 #pragma unroll
@@ -2471,7 +2125,7 @@ __device__ __forceinline__ void sweep(const Params &p)
 #pragma unroll
                     for (int k = 0; k < K; ++k) hist[k] = 0, lo[k] = 0.f;
                     cy.a = cy.b = cy.c = 0.0;
-                    publish_range(kc0{}, kc1{}, nullptr);
+                    publish_range();
                     pf_t0 = t0, pf_par = par;
                     if (more) write_block_s(bb_new, ecur_t{});
                     return;
@@ -2491,7 +2145,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                 if (known_zero) {
                     zero_chunk = true;
                 } else {
-                    acquire(kc0{}, kc1{});
+                    acquire();
                     zero_chunk = zero_test();
                 }
                 stamp_rev(2);
@@ -2516,7 +2170,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                 if (zero_chunk) {
                     zero_fill_ring();
                     stamp_rev(3);
-                    publish_range(kc0{}, kc1{}, nullptr);
+                    publish_range();
                     stamp_rev(4);
                     pf_t0 = t0, pf_par = par;
                     return;
@@ -2534,16 +2188,15 @@ __device__ __forceinline__ void sweep(const Params &p)
             stamp_chunk(t0 / WB, 5);
 
             if constexpr (FWD_SUB) {
-                fwd_blocks(c, t0, [&]() { if (more) write_block(bb_new); });
+                fwd_blocks(c, t0);
                 stamp_chunk(t0 / WB + 1, 4);
-                if constexpr (!SDP_STAGE_EARLY) { if (more) write_block(bb_new); }
+                if (more) write_block(bb_new);
                 stamp_chunk(t0 / WB + 1, 5);
                 return;
             }
 
-            if constexpr (HALF) acquire(kch{}, kc1{});   // the reverse sweep starts with the chunk's upper steps
-            else if constexpr (ZSKIP_A) { if (!za_acquired) acquire(kc0{}, kc1{}); }
-            else if constexpr (!LAZY) acquire(kc0{}, kc1{});   // (LAZY: further up, in front of the decision what kind of chunk this is)
+            if constexpr (ZSKIP_A) { if (!za_acquired) acquire(); }
+            else if constexpr (!LAZY) acquire();   // (LAZY: further up, in front of the decision what kind of chunk this is)
             if constexpr (!LAZY) stamp_rev(2);
 
             // ---- staged inputs of this chunk: one burst of LDS reads, off the dependency chain ----
@@ -2575,12 +2228,6 @@ __device__ __forceinline__ void sweep(const Params &p)
                 }
             }
 
-            // ---- exp-domain forward: everything that does not depend on the recurrence is computed for the
-            // whole chunk up front (K independent instruction streams the scheduler can interleave), so that
-            // the serial per-step chain below carries only the alignment, one fma and the renormalisation.
-            // theta = (kt + ft) ln2, A = (ka + fa) ln2 with integer kt, ka: c* = 2^f* in [0.5,2)
-            float ctv[K], cav[K];
-            int ktv[K], kav[K];
             const bool interior = chunk_interior(c);
             // The fp32 backward sweep needs no masks in the RAMPS of a full strip either (round 5; the masked body costs ~20
             // instead of ~14 instructions per step, and a strip's first three chunks -- all ramp -- are what the strip above
@@ -2595,40 +2242,16 @@ __device__ __forceinline__ void sweep(const Params &p)
             // Not for: the chunk that holds the terminal cell (its cotangent is injected under the mask), partial strips (rows
             // below the matrix do hand upwards), Smith-Waterman's border row and column, float2 states (records of cells outside
             // may hold NaN).
-            const bool mask_free = interior || (SDP_BWD_MASKFREE && REV && PASS == PASS_BWD && KIND == CK_F32 && T::QIN == Q_PACKED && rows == 64 && !sw &&
+            const bool mask_free = interior || (PASS == PASS_BWD && T::QIN == Q_PACKED && rows == 64 && !sw &&
                                                 !(s == nstrips - 1 && m - 1 + 63 >= t0 && m - 1 + 63 < t0 + K));
-            auto prepass = [&]() {
-                if constexpr (PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_PREPASS) {
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        // clamped to +-2^20 bits so that A = -inf (a forbidden gap) behaves like the reference's
-                        // exp(-inf) = 0 instead of producing inf - inf
-                        const float tt = __builtin_amdgcn_fmed3f(in0[k] * 1.44269504088896340736f, -1048576.f, 1048576.f);
-                        const float ta = __builtin_amdgcn_fmed3f(in1[k] * 1.44269504088896340736f, -1048576.f, 1048576.f);
-                        // Moderate exponents take mantissa and exponent of the SAME 2^tt the windowed form multiplies
-                        // with, so that both forms produce identical bits and a cell's result does not depend on
-                        // which of them a chunk happened to run (the builds cut a strip into different chunks).
-                        const float et = __builtin_amdgcn_exp2f(tt), ea = __builtin_amdgcn_exp2f(ta);
-                        const float kt = __builtin_floorf(tt), ka = __builtin_floorf(ta);
-                        const float st = __builtin_amdgcn_exp2f(tt - kt), sa = __builtin_amdgcn_exp2f(ta - ka);
-                        const bool mt = __builtin_fabsf(tt) <= 120.f, ma = __builtin_fabsf(ta) <= 120.f;
-                        ctv[k] = mt ? __builtin_amdgcn_frexp_mantf(et) : st;
-                        ktv[k] = mt ? __builtin_amdgcn_frexp_expf(et) : (int)kt;
-                        cav[k] = ma ? __builtin_amdgcn_frexp_mantf(ea) : sa;
-                        kav[k] = ma ? __builtin_amdgcn_frexp_expf(ea) : (int)ka;
-                    }
-                }
-            };
 
-
-            // ---- K steps; EDGE=false is the mask-free body for chunks fully inside the matrix ----
+            // ---- K steps (every pass but the forward sweep, which runs fwd_blocks); EDGE=false is the mask-free body for chunks fully inside the matrix ----
             const unsigned pipe_off = pipe_now ? (unsigned)(f2_g * 4) : OOB;   // (PIPE) per-lane offset of the stores the steps carry (OOB: dummies)
-            auto steps = [&](auto edge_tag, auto kk0_tag, auto kk1_tag, auto pipe_tag) {   // steps kk in [KK0, KK1) of the chunk, in processing order
+            auto steps = [&](auto edge_tag, auto pipe_tag) {
                 constexpr bool EDGE = decltype(edge_tag)::value;
-                constexpr bool PIPED = decltype(pipe_tag)::value;   // the previous chunk's stores and this chunk's boundary values ride along
-                constexpr int KK0 = decltype(kk0_tag)::value, KK1 = decltype(kk1_tag)::value;
+                constexpr bool PIPED = decltype(pipe_tag)::value;   // the previous chunk's stores ride along
 #pragma unroll
-                for (int kk = KK0; kk < KK1; ++kk) {
+                for (int kk = 0; kk < K; ++kk) {
                     const int k = REV ? K - 1 - kk : kk;
                     const int t = t0 + k;
                     const int col = t - lane;
@@ -2637,38 +2260,14 @@ __device__ __forceinline__ void sweep(const Params &p)
                     const bool rowok = !EDGE || lane < rows;
 
                     float2 q0, q1;
-                    if constexpr (T::QIN == Q_EXACT) {
-                        q0 = rqx2[P][k];
-                        if constexpr (!ABL_NOLOAD && !TOPLOAD_X) rqx2[P][k] = load_f2(rs_qx, t0_next, k);
-                    }
+                    if constexpr (T::QIN == Q_EXACT) q0 = rqx2[P][k];
                     if constexpr (T::QIN == Q_PACKED) {
-                        if constexpr (QB == 18) {
-                            unsigned w9[9];
-                            q20_record(k >> 3, w9, cur_t{});
-                            q0 = q18_unpack(w9, k & 7);
-                        } else if constexpr (Q20) {
-                            unsigned w5[5];
-                            q20_record(k >> 2, w5, cur_t{});
-                            q0 = q20_unpack(w5, k & 3);
-                        } else {
-                            q0 = q_unpack(rq + 3 * (k >> 1), k & 1);
-                        }
-                        q0.x *= qf_unscale<QB>(), q0.y *= qf_unscale<QB>();
-                        if constexpr (!ABL_NOLOAD) {   // the record's last step in processing order has been consumed: refill it
-                            if (!Q20 && (k & (QREC_STEPS - 1)) == (REV ? 0 : QREC_STEPS - 1)) {
-                                // (the refill must stay BEHIND the last use of what it overwrites: hoisted above it by the
-                                //  scheduler, old and new record are alive together, get different registers, and the new
-                                //  ones are copied into place at the end of the iteration behind a vmcnt(0))
-                                if constexpr (SDP_REFILL_BARRIER) __builtin_amdgcn_sched_barrier(0);
-                                load_q(t0_next, k / QREC_STEPS, rq + QREC_DW * (k / QREC_STEPS));
-                                if constexpr (SDP_REFILL_BARRIER) __builtin_amdgcn_sched_barrier(0);
-                            }
-                        }
+                        unsigned w5[5];
+                        q20_record(k >> 2, w5, cur_t{});
+                        q0 = q20_unpack(w5, k & 3);
+                        q0.x *= QF_UNSCALE, q0.y *= QF_UNSCALE;
                     }
-                    if constexpr (T::DIN) {
-                        q1 = rdd2[P][k];
-                        if constexpr (!ABL_NOLOAD && !TOPLOAD_X) rdd2[P][k] = load_d(t0_next, k);
-                    }
+                    if constexpr (T::DIN) q1 = rdd2[P][k];
 
                     if constexpr (ABL_NOMATH) {
                         if constexpr (T::QOUT != Q_NONE || T::DOUT) {
@@ -2677,71 +2276,6 @@ __device__ __forceinline__ void sweep(const Params &p)
                         }
                         if constexpr (T::SOUT > 0) lo[k] = q0.x + q0.y + (T::DIN ? q1.x + q1.y : 0.f) + (T::SIN > 0 ? in0[k] : 0.f);
                         hist[k] = 0;
-                    } else if constexpr (PASS == PASS_FWD && KIND == CK_EXP) {
-                        // scaled exp-domain forward (see CK_EXP above)
-                        const float ua = __uint_as_float(dpp_i32<DPP_IN>((int)lo32(bcv[k]), __float_as_int(cy.xa)));
-                        const int ue = dpp_i32<DPP_IN>((int)hi32(bcv[k]), cy.xe);
-                        float ct, ca;
-                        int kai, kti;
-                        if constexpr (SDP_PREPASS) {
-                            ct = ctv[k], ca = cav[k], kai = kav[k], kti = ktv[k];
-                        } else {
-                            const float tt = __builtin_amdgcn_fmed3f(in0[k] * 1.44269504088896340736f, -1048576.f, 1048576.f);
-                            const float ta = __builtin_amdgcn_fmed3f(in1[k] * 1.44269504088896340736f, -1048576.f, 1048576.f);
-                            const float kt = __builtin_floorf(tt), ka = __builtin_floorf(ta);
-                            ct = __builtin_amdgcn_exp2f(tt - kt);
-                            ca = __builtin_amdgcn_exp2f(ta - ka);
-                            kti = (int)kt, kai = (int)ka;
-                        }
-                        const int ex = ue + kai, ey = cy.xe + kai, ed = cy.de;
-                        const int er = max(max(ex, ey), ed);
-                        const float u = __builtin_amdgcn_ldexpf(ua, ex - er);
-                        const float l = __builtin_amdgcn_ldexpf(cy.xa, ey - er);
-                        const float d = __builtin_amdgcn_ldexpf(cy.da, ed - er);
-                        const float ssum = __builtin_fmaf(ca, u + l, d);  // the operand with the largest exponent is unshifted
-                        const float rinv = ssum >= 1.1754944e-38f ? __builtin_amdgcn_rcpf(ssum) : 0.f;   // (see norm_block: a cell nothing reaches)
-                        const float tq = ca * rinv;
-                        {
-                            float2 qq = make_float2(tq * u, tq * l);
-                            if constexpr (QX) q_sharpen(qq.x, qq.y, d * rinv);
-                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
-                        }
-                        const float an = ct * ssum;
-                        float na = __builtin_amdgcn_frexp_mantf(an);
-                        int ne = er + kti + __builtin_amdgcn_frexp_expf(an);
-                        cy.da = ua;
-                        cy.de = ue;
-                        if constexpr (EDGE) {
-                            const bool live = col >= 0 && !dead;
-                            na = live ? na : EXP_ONE_A;
-                            ne = live ? ne : EXP_ONE_E;
-                        }
-                        cy.xa = na;
-                        cy.xe = ne;
-                        hist[k] = pack2(__float_as_uint(na), (unsigned)ne);
-                        if constexpr (EDGE) vt_keep = (t == t_final) ? hist[k] : vt_keep;
-                    } else if constexpr (PASS == PASS_FWD) {
-                        const float th = in0[k];
-                        const float ga = in1[k];
-                        const double up = dpp_f64<DPP_IN>(__longlong_as_double((long long)bcv[k]), cy.a);
-                        const double diag = cy.b, left = cy.a;
-                        const double ad = (double)ga;
-                        const double x = ad + up, y = ad + left;
-                        const double mx = fmax(fmax(x, diag), y);
-                        const float ex = fast_exp((float)(x - mx));
-                        const float em = fast_exp((float)(diag - mx));
-                        const float ey = fast_exp((float)(y - mx));
-                        const float ssum = (ex + em) + ey;
-                        const float inv = __builtin_amdgcn_rcpf(ssum);
-                        const double v = ((double)th + mx) + (double)fast_log(ssum);
-                        {
-                            float2 qq = make_float2(ex * inv, ey * inv);
-                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
-                        }
-                        cy.b = up;
-                        cy.a = (!EDGE || (col >= 0 && !dead)) ? v : 0.0;
-                        hist[k] = (u64)__double_as_longlong(cy.a);
-                        if constexpr (EDGE) vt_keep = (t == t_final) ? hist[k] : vt_keep;
                     } else if constexpr (PASS == PASS_AFWD) {
                         // Fused loss seed: Ztheta = dLoss/dE is formed here from the loss's own operands --
                         // ref (Ytrue or the path matrix), pred (= E, the alignment matrix the loss was evaluated on), the
@@ -2773,7 +2307,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         cy.a = inside ? vd : 0.0;
                         hist[k] = (u64)__double_as_longlong(cy.a);
                         if constexpr (EDGE) vt_keep = (t == t_final) ? hist[k] : vt_keep;
-                    } else if constexpr (PASS == PASS_BWD && KIND == CK_F32) {
+                    } else if constexpr (PASS == PASS_BWD) {
                         const float in = __uint_as_float(dpp_i32<DPP_IN>((int)lo32(bcv[k]), __float_as_int(cy.fa)));
                         float e = in + cy.fb;
                         if constexpr (EDGE) {
@@ -2797,60 +2331,9 @@ __device__ __forceinline__ void sweep(const Params &p)
                         lo[k] = e;
                         hist[k] = (u64)__float_as_uint(cy.fa);
                         if constexpr (PIPED) {
-                            // one of the previous chunk's 16 output stores per two steps ...
-                            if constexpr (SDP_PIPE_ST == 1) {
-                                if (kk < K / 2) flush_store1(pf_t0, kk, fv[kk], pipe_off);
-                            } else {
-                                if (kk & 1) flush_store1(pf_t0, kk >> 1, fv[kk >> 1], pipe_off);
-                            }
-                            // ... and the four boundary values of steps k .. k + 3 as soon as the lowest of them is done (an interior
-                            // chunk: t0 + K <= m, so the K four-byte slots from t0 on are K / 4 aligned 16-byte writes)
-                            if constexpr (SDP_PIPE_PUB == 1) {
-                                if ((k & 3) == 0 && has_succ && lane == PUB_LANE)
-                                    reinterpret_cast<uint4 *>(bnd_out + t0)[k >> 2] =
-                                        make_uint4((unsigned)hist[k], (unsigned)hist[k + 1], (unsigned)hist[k + 2], (unsigned)hist[k + 3]);
-                            } else if constexpr (SDP_PIPE_PUB == 2) {
-                                if ((k & 15) == 0 && has_succ && lane == PUB_LANE) {
-#pragma unroll
-                                    for (int g = 0; g < 4; ++g)
-                                        reinterpret_cast<uint4 *>(bnd_out + t0)[(k >> 2) + g] =
-                                            make_uint4((unsigned)hist[k + 4 * g], (unsigned)hist[k + 4 * g + 1], (unsigned)hist[k + 4 * g + 2], (unsigned)hist[k + 4 * g + 3]);
-                                }
-                            }
+                            // one of the previous chunk's 16 output stores per step of the chunk's first half
+                            if (kk < K / 2) flush_store1(pf_t0, kk, fv[kk], pipe_off);
                         }
-                    } else if constexpr (PASS == PASS_BWD) {
-                        const double in = dpp_f64<DPP_IN>(__longlong_as_double((long long)bcv[k]), cy.a);
-                        const bool live = inside && rowok && !dead;
-                        double e = in + cy.b;
-                        if constexpr (EDGE) {
-                            e = (t == t_final) ? (double)et : e;
-                            e = live ? e : 0.0;
-                        }
-                        const double qx = live ? (double)q0.x : 0.0, qy = live ? (double)q0.y : 0.0;
-                        const double qm = fmax((1.0 - qx) - qy, 0.0);  // the two stored weights are rounded independently
-                        cy.b = qy * e;
-                        cy.a = __builtin_fma(qx, e, cy.c);  // px + pm of the previous step
-                        cy.c = qm * e;
-                        lo[k] = (float)e;
-                        hist[k] = (u64)__double_as_longlong(cy.a);
-                    } else if constexpr (PASS == PASS_ABWD && KIND == CK_F32) {
-                        const float ef = in0[k];
-                        const float in = __uint_as_float(dpp_i32<DPP_IN>((int)lo32(bcv[k]), __float_as_int(cy.fa)));
-                        const bool cell = inside && rowok;
-                        const bool live = cell && !dead;
-                        const float ed = cell ? in + cy.fb : 0.f;
-                        const float e = live ? ef : 0.f;
-                        const float qx = live ? q0.x : 0.f, qy = live ? q0.y : 0.f;
-                        const float qm = live ? (1.f - qx) - qy : 0.f;
-                        const float dx = live ? q1.x : 0.f, dy = live ? q1.y : 0.f;
-                        const float dm = -(dx + dy);
-                        const float gx = dx * e + qx * ed;
-                        const float gm = dm * e + qm * ed;
-                        cy.fb = dy * e + qy * ed;
-                        cy.fa = gx + cy.fc;
-                        cy.fc = gm;
-                        lo[k] = ed;
-                        hist[k] = (u64)__float_as_uint(cy.fa);
                     } else {  // PASS_ABWD
                         const float ef = in0[k];
                         const double in = dpp_f64<DPP_IN>(__longlong_as_double((long long)bcv[k]), cy.a);
@@ -2870,133 +2353,6 @@ __device__ __forceinline__ void sweep(const Params &p)
                     }
                 }
             };
-            // ---- windowed exp-domain forward ----
-            // For the K steps of the chunk every lane keeps its values as plain floats relative to one exponent R
-            // (its "frame": the exponent of its own last value), the neighbour's values arrive scaled by the exact
-            // power of two 2^(R_neighbour - R), and the renormalisation happens once per chunk instead of once per
-            // step: a step is then one DPP move, five multiply/adds, one reciprocal and the range bookkeeping.
-            // All scalings are exact powers of two, so the results are those of the per-step-normalised form up to
-            // how 2^theta is split.  The strip above hands over its K values in one frame too (frame word); lane 0
-            // adopts that frame, so its boundary values need no conversion.
-            // EDGE chunks (the ramps of a strip, the Smith-Waterman border): a cell that is not live yet -- its
-            // column is still left of the matrix -- holds V = 0, i.e. 2^(1-R) * 0.5 in its lane's frame, and lanes
-            // that have not started take the frame of the last lane that has.  Cells right of the matrix or below
-            // it compute values nobody reads, exactly as in the normalised form.
-            // Returns 1 = done, 0 = not applicable here, -1 = a value left the safe range (nothing was committed).
-            auto steps_wf = [&](auto edge_tag, int *frames) -> int {
-                constexpr bool EDGE = decltype(edge_tag)::value;
-                const Carry saved = cy;  // a later block of the chunk may fail after earlier ones were committed
-                int thr = 0;             // EDGE: the lane's cell is live at step t iff t >= thr
-                if constexpr (EDGE) {
-                    thr = lane + (sw ? 1 : 0);
-                    if (sw && i0 + lane == 0) thr = 0x7fffffff;  // padded row 1 of Smith-Waterman never is
-                }
-#pragma unroll
-                for (int sb = 0; sb < K / WB; ++sb) {  // one frame per block of WB steps, whatever the chunk length
-                    const int tb = t0 + sb * WB;
-                    const bool use_pred = has_pred && tb < m;  // lane 0 meets real boundary values in this block
-                    int fa = 0, fb = 0;
-                    if (use_pred) {
-                        fa = __builtin_amdgcn_readfirstlane(frm_in[(tb + 63) / WB]);                   // block that produced column tb
-                        fb = tb + 1 < m ? __builtin_amdgcn_readfirstlane(frm_in[(tb + 64) / WB]) : fa;  // ... columns tb+1 .. tb+WB-1
-                        if (fa == FRAME_NONE || fb == FRAME_NONE) {
-                            cy = saved;
-                            return 0;
-                        }
-                    }
-                    int R = cy.xe + WF_BIAS;
-                    if (use_pred && lane == 0) R = fb;
-                    if constexpr (EDGE) {
-                        const int nstarted = tb - (sw ? 1 : 0);  // lanes below this were live at step tb - 1
-                        if (nstarted < 64) {  // the others take the frame of the last started lane (or of the boundary)
-                            const int rref = nstarted > 0 ? __builtin_amdgcn_readlane(R, nstarted - 1) : (use_pred ? fb : EXP_ONE_E + WF_BIAS);
-                            R = lane < nstarted ? R : rref;
-                        }
-                    }
-                    float x = __builtin_amdgcn_ldexpf(cy.xa, cy.xe - R);
-                    float d = __builtin_amdgcn_ldexpf(cy.da, cy.de - R);
-                    const float xz = __builtin_amdgcn_ldexpf(EXP_ONE_A, EXP_ONE_E - R);  // V = 0 in this frame
-                    const int Rn = dpp_i32<DPP_IN>(R, R);
-                    const int dR = Rn - R;   // (see fwd_blocks: the neighbour's value is rescaled with ldexp, the factor alone can underflow)
-                    unsigned mx = max(__float_as_uint(x), __float_as_uint(d)), mn = 0x3f800000u, mc = 0;
-                    if (!EDGE || tb > thr) mn = __float_as_uint(x);  // a value that is not live yet may be arbitrarily small
-                    float bf[WB];  // lane 0's `up` values in its frame
-                    if (use_pred) {
-                        bf[0] = __builtin_amdgcn_ldexpf(__uint_as_float(lo32(bcv[sb * WB])), fa - R);
-#pragma unroll
-                        for (int j = 1; j < WB; ++j) bf[j] = __uint_as_float(lo32(bcv[sb * WB + j]));
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < WB; ++j) bf[j] = xz;
-                    }
-#pragma unroll
-                    for (int j = 0; j < WB; ++j) {
-                        const int k = sb * WB + j;
-                        const float ct = __builtin_amdgcn_exp2f(in0[k] * 1.44269504088896340736f);
-                        const float ca = __builtin_amdgcn_exp2f(in1[k] * 1.44269504088896340736f);
-                        const float ua = __uint_as_float(dpp_i32<DPP_IN>(__float_as_int(bf[j]), __float_as_int(x)));
-                        const float u = __builtin_amdgcn_ldexpf(ua, dR);
-                        const float ssum = __builtin_fmaf(ca, u + x, d);
-                        const float rinv = __builtin_amdgcn_rcpf(ssum);
-                        const float tq = ca * rinv;
-                        {
-                            float2 qq = make_float2(tq * u, tq * x);
-                            if constexpr (QX) q_sharpen(qq.x, qq.y, d * rinv);
-                            if constexpr (ABL_NOSTORE) { keep(qq.x); keep(qq.y); } else store_state(t0, k, qq);
-                        }
-                        d = u;
-                        x = ct * ssum;
-                        if constexpr (EDGE) {
-                            const bool live = t0 + k >= thr;
-                            x = live ? x : xz;
-                            mn = min(mn, live ? __float_as_uint(x) : 0x3f800000u);
-                        } else {
-                            mn = min(mn, __float_as_uint(x));
-                        }
-                        mx = max(max(mx, __float_as_uint(u)), __float_as_uint(x));
-                        mc = max(max(mc, __float_as_uint(ct)), __float_as_uint(ca));
-                        hist[k] = pack2(__float_as_uint(x), (unsigned)R);
-                    }
-                    if (__builtin_amdgcn_ballot_w64(mx > WF_HI || mn < WF_LO || mc > WF_FMAX) != 0) {
-                        cy = saved;
-                        return -1;
-                    }
-                    cy.xa = __builtin_amdgcn_frexp_mantf(x);
-                    cy.xe = R + __builtin_amdgcn_frexp_expf(x);
-                    cy.da = __builtin_amdgcn_frexp_mantf(d);
-                    cy.de = R + __builtin_amdgcn_frexp_expf(d);
-                    if constexpr (EDGE) {
-                        if (tb + WB - 1 < thr) cy.xa = EXP_ONE_A, cy.xe = EXP_ONE_E;  // still waiting: exactly V = 0
-                    }
-                    frames[sb] = R;
-                }
-                if constexpr (EDGE) {
-                    const int tf = m - 1 + rows - 1;  // step at which the last strip meets the terminal cell
-                    if (s == nstrips - 1 && tf >= t0 && tf < t0 + K) {
-                        const int ktf = t_final - t0;  // only that lane has t_final >= 0
-#pragma unroll
-                        for (int k = 0; k < K; ++k) vt_keep = (k == ktf) ? hist[k] : vt_keep;
-                        // a terminal cell on the Smith-Waterman border is not live: V = 0 exactly (its value in the
-                        // frame may have underflowed to 0, which would read as -inf)
-                        if (t_final >= 0 && t_final < thr) vt_keep = edge_zero<KIND>();
-                    }
-                }
-                return 1;
-            };
-
-            bool wf_done = false;
-            int wf_frames[K / WB];
-#pragma unroll
-            for (int sb = 0; sb < K / WB; ++sb) wf_frames[sb] = FRAME_NONE;
-            if constexpr (PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_WF) {
-                if (wf_skip == 0) {
-                    const int rc = interior ? steps_wf(std::false_type{}, wf_frames) : steps_wf(std::true_type{}, wf_frames);
-                    wf_done = rc > 0;
-                    if (rc < 0) wf_skip = 1;  // values move too fast for one frame per block here: try again later
-                } else if (wf_skip > 0) {
-                    --wf_skip;
-                }
-            }
             // ---- exact zeros (fp32 backward sweep) ----
             // E is a sum of products of weights along paths: away from the alignment it underflows to exactly +0 (47 % of the
             // cells of the benchmark's soft scores, nearly all of a peaked alignment).  If every lane's three carries, the K
@@ -3009,60 +2365,18 @@ __device__ __forceinline__ void sweep(const Params &p)
                 if (zero_chunk) zero_fill_ring();
                 else zring &= ~(1 << par);
             }
-            if (!wf_done && !HALF && !zero_chunk) {
-#pragma unroll
-                for (int sb = 0; sb < K / WB; ++sb) wf_frames[sb] = FRAME_NONE;
-                prepass();
+            if (!zero_chunk) {
                 if constexpr (PIPE) {
-                    if (interior) steps(std::false_type{}, kc0{}, kc1{}, std::true_type{}), pub_vals_done = SDP_PIPE_PUB != 0;
-                    else if (mask_free) steps(std::false_type{}, kc0{}, kc1{}, std::false_type{});
-                    else steps(std::true_type{}, kc0{}, kc1{}, std::false_type{});
+                    if (interior) steps(std::false_type{}, std::true_type{});
+                    else if (mask_free) steps(std::false_type{}, std::false_type{});
+                    else steps(std::true_type{}, std::false_type{});
                 } else {
-                    if (mask_free) steps(std::false_type{}, kc0{}, kc1{}, std::false_type{});
-                    else steps(std::true_type{}, kc0{}, kc1{}, std::false_type{});
+                    if (mask_free) steps(std::false_type{}, std::false_type{});
+                    else steps(std::true_type{}, std::false_type{});
                 }
             }
-
-            // The normalised form publishes its values in one frame per block as well whenever they fit (exact
-            // rescaling to the exponent of the block's last value), so that the strip below can use the windowed
-            // form regardless of how this chunk was computed.  Only the publishing lane's values matter.
-            if constexpr (PASS == PASS_FWD && KIND == CK_EXP && !ABL_NOMATH && SDP_WF) {
-                if (!wf_done && has_succ) {
-#pragma unroll
-                    for (int sb = 0; sb < K / WB; ++sb) {
-                        const int R = (int)hi32(hist[sb * WB + WB - 1]);
-                        float av[WB];
-                        unsigned mx = 0, mn = ~0u;
-#pragma unroll
-                        for (int j = 0; j < WB; ++j) {
-                            const int k = sb * WB + j;
-                            av[j] = __builtin_amdgcn_ldexpf(__uint_as_float(lo32(hist[k])), (int)hi32(hist[k]) - R);
-                            mx = max(mx, __float_as_uint(av[j]));
-                            mn = min(mn, __float_as_uint(av[j]));
-                        }
-                        const bool fits = mx <= WF_HI && mn >= WF_LO;
-                        if ((__builtin_amdgcn_ballot_w64(fits) >> PUB_LANE) & 1ull) {
-#pragma unroll
-                            for (int j = 0; j < WB; ++j) hist[sb * WB + j] = pack2(__float_as_uint(av[j]), (unsigned)R);
-                            wf_frames[sb] = R;
-                        }
-                    }
-                }
-            }
-
-            if constexpr (HALF) {
-                // upper half of the chunk (steps t0 + 31 .. t0 + 16), hand it down, lower half, hand it down
-                if (interior) steps(std::false_type{}, kc0{}, kch{}, std::false_type{});
-                else steps(std::true_type{}, kc0{}, kch{}, std::false_type{});
-                publish_range(kch{}, kc1{}, nullptr);
-                acquire(kc0{}, kch{});
-                if (interior) steps(std::false_type{}, kch{}, kc1{}, std::false_type{});
-                else steps(std::true_type{}, kch{}, kc1{}, std::false_type{});
-                publish_range(kc0{}, kch{}, nullptr);
-            } else {
-                stamp_rev(3);
-                publish_range(kc0{}, kc1{}, wf_frames);
-            }
+            stamp_rev(3);
+            publish_range();
             if constexpr (FLUSH2) {
                 if (!zero_chunk) lo[-1 - par * K] = lo[K - 1];   // step 31's value once more, at position -1 of the row (see FLUSH2)
             }
@@ -3110,15 +2424,13 @@ __device__ __forceinline__ void sweep(const Params &p)
 
 // (-DSDP_ONLY=<n>: compile ONE kernel, for ISA inspection with `hipcc -S --cuda-device-only` -- tools/isa.sh; never linked)
 #if defined(SDP_ONLY) && SDP_ONLY == 1
-SDP_KERNEL(sdp_bwd_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q, false, false, false, false, 20, true)
+SDP_KERNEL(sdp_bwd_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q, false, false, false, false, true)
 #elif defined(SDP_ONLY) && SDP_ONLY == 21
 SDP_KERNEL(sdp_bwd_pipe_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q)
 #elif defined(SDP_ONLY) && SDP_ONLY == 0
-SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LINES != 0)
-#elif defined(SDP_ONLY) && SDP_ONLY == 18
-SDP_KERNEL(sdp_fwd18_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LINES != 0, false, false, 18)
-#elif defined(SDP_ONLY) && SDP_ONLY == 19
-SDP_KERNEL(sdp_bwd18_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, false, false, false, false, 18)
+SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, true)
+#elif defined(SDP_ONLY) && SDP_ONLY == 9
+SDP_KERNEL(sdp_fwd_x_tp_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, true)
 #elif defined(SDP_ONLY) && SDP_ONLY == 7
 SDP_KERNEL(sdp_bwd_x_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, true)
 #elif defined(SDP_ONLY) && SDP_ONLY == 3
@@ -3126,52 +2438,67 @@ SDP_KERNEL(sdp_adj_bwd_kernel, sdp::PASS_ABWD, SDP_K_ABWD, SDP_MAXW_ABWD)
 #elif defined(SDP_ONLY) && SDP_ONLY == 2
 SDP_KERNEL(sdp_adj_fwd_kernel, sdp::PASS_AFWD, SDP_K_AFWD, SDP_MAXW_AFWD)
 #else
-SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LINES != 0)
+// (-DSDP_GROUP=<g>: compile one group of kernels -- deepblast_amd/build.py builds the groups of this file in parallel and links
+//  them; without it, everything.  Group 0 holds the small kernels at the end of the file.)
+#ifndef SDP_GROUP
+#define SDP_GROUP (-1)
+#endif
+#define SDP_IN_GROUP(g) (SDP_GROUP < 0 || SDP_GROUP == (g))
+// template arguments after MAXW: QX (exact state / fused loss seed), LINES (throughput forward builds: line-aligned input blocks),
+// GEN (general pitch), PARTS (a pair over several workgroups), NOPIPE (packed backward sweep without the pipelined chunk)
+#if SDP_IN_GROUP(1)
+SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, true)
 SDP_KERNEL(sdp_fwd_lat_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT)
 SDP_KERNEL(sdp_fwd_x_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, true)
-SDP_KERNEL(sdp_fwd_x_tp_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, SDP_LINES != 0)
+SDP_KERNEL(sdp_fwd_x_tp_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, true)
+#endif
+#if SDP_IN_GROUP(2)
 // The packed backward sweep twice: with the chunk as ONE software pipeline (PIPE: deferred flush, stores inside the steps) for
 // long pairs on one wave per SIMD, and without it for everything else -- steady-state A/B, fwd;bwd us, +- 0.3 (tools/steady.py,
 // profiles/r05_steady_pipe.txt; no pipeline -> pipeline): 256 x 1024^2 1064.5 -> 1036.2, 256 x 512 x 1024 665.5 -> 650.7, 256 x 768 x 640
 // 576.1 -> 569.3, 256 x 1024 x 512 602.6 -> 596.6; but 256 x 512^2 272.5 -> 279.0, 64 x 512^2 218.3 -> 224.2, 128 x 512^2 243.3 -> 249.1,
 // 512 x 256^2 163.4 -> 169.6, 128 x 1024^2 (8 waves) 816.3 -> 825.1.  sdp_api.hip plan() picks (bwd_pipe_pays).
-SDP_KERNEL(sdp_bwd_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q, false, false, false, false, 20, true)
+SDP_KERNEL(sdp_bwd_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q, false, false, false, false, true)
 SDP_KERNEL(sdp_bwd_pipe_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q)
 SDP_KERNEL(sdp_bwd_lat_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT)
 SDP_KERNEL(sdp_bwd_x_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, true)
 SDP_KERNEL(sdp_bwd_x_lat_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, true)
+#endif
+#if SDP_IN_GROUP(3)
+SDP_KERNEL(sdp_adj_bwd_g_kernel, sdp::PASS_ABWD, SDP_K_ABWD, SDP_MAXW_ABWD, false, false, true)
 SDP_KERNEL(sdp_adj_fwd_kernel, sdp::PASS_AFWD, SDP_K_AFWD, SDP_MAXW_AFWD)
 SDP_KERNEL(sdp_adj_fwd_loss_kernel, sdp::PASS_AFWD, SDP_K_AFWD, 4, true)
 SDP_KERNEL(sdp_adj_bwd_kernel, sdp::PASS_ABWD, SDP_K_ABWD, SDP_MAXW_ABWD)
+#endif
 // PARTS instantiations: the throughput builds with the bridge between workgroups (a pair spread over several CUs)
-SDP_KERNEL(sdp_fwd_p_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LINES != 0, false, true)
-SDP_KERNEL(sdp_fwd_x_tp_p_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, SDP_LINES != 0, false, true)
+#if SDP_IN_GROUP(4)
+SDP_KERNEL(sdp_fwd_p_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, true, false, true)
+SDP_KERNEL(sdp_fwd_x_tp_p_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, true, false, true)
+SDP_KERNEL(sdp_fwd_pg_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, true, true, true)
+SDP_KERNEL(sdp_fwd_x_tp_pg_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, true, true, true)
+#endif
+#if SDP_IN_GROUP(5)
 SDP_KERNEL(sdp_bwd_p_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, false, false, false, true)
 SDP_KERNEL(sdp_bwd_x_p_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, true, false, false, true)
-SDP_KERNEL(sdp_fwd_pg_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LINES != 0, true, true)
-SDP_KERNEL(sdp_fwd_x_tp_pg_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, SDP_LINES != 0, true, true)
 SDP_KERNEL(sdp_bwd_pg_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, false, false, true, true)
 SDP_KERNEL(sdp_bwd_x_pg_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, true, false, true, true)
+#endif
 // general-pitch instantiations (GEN = true) of the kernels that stage outputs, and of the line-aligned forward builds
-SDP_KERNEL(sdp_fwd_g_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LINES != 0, true)
-SDP_KERNEL(sdp_fwd_x_tp_g_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, SDP_LINES != 0, true)
+#if SDP_IN_GROUP(6)
+SDP_KERNEL(sdp_fwd_g_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, true, true)
+SDP_KERNEL(sdp_fwd_x_tp_g_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, true, true)
+#endif
+#if SDP_IN_GROUP(7)
 SDP_KERNEL(sdp_bwd_g_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, false, false, true)
 SDP_KERNEL(sdp_bwd_lat_g_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, false, false, true)
 SDP_KERNEL(sdp_bwd_x_g_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, true, false, true)
 SDP_KERNEL(sdp_bwd_x_lat_g_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, true, false, true)
-SDP_KERNEL(sdp_adj_bwd_g_kernel, sdp::PASS_ABWD, SDP_K_ABWD, SDP_MAXW_ABWD, false, false, true)
-#if SDP_Q18
-// 18-bit packed state (N + M <= 1024, no per-pair lengths: sdp_kernels.h packed_bits): the forward / backward builds that serve it
-SDP_KERNEL(sdp_fwd18_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LINES != 0, false, false, 18)
-SDP_KERNEL(sdp_fwd18_lat_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, false, false, false, false, 18)
-SDP_KERNEL(sdp_fwd18_g_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, SDP_LINES != 0, true, false, 18)
-SDP_KERNEL(sdp_bwd18_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, false, false, false, false, 18)
-SDP_KERNEL(sdp_bwd18_lat_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, false, false, false, false, 18)
-SDP_KERNEL(sdp_bwd18_g_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, false, false, true, false, 18)
-SDP_KERNEL(sdp_bwd18_lat_g_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, false, false, true, false, 18)
-
 #endif
 #endif
+#ifndef SDP_IN_GROUP
+#define SDP_IN_GROUP(g) 1
+#endif
+#if SDP_IN_GROUP(0)
 
 // ----------------------------------------------------------------------------------
 // launch order for variable-length batches: order[r] = the pair with the r-th largest n*m (ties: lower index first).
@@ -3605,3 +2932,4 @@ extern "C" __global__ void sdp_selftest_kernel(int *out)
     const unsigned via_s = __builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, 64 * 4, 0);
     out[192 + lane] = (int)via_s;
 }
+#endif  // SDP_IN_GROUP(0)

@@ -163,7 +163,10 @@ class ShardedAligner:
 
         -> dict(Vt_local, E_local, Vt (B,) or None, E (B,N,M) | PendingGather | None,
                 paths (gather="paths"): (states (B, N+M+2, 3) int32, counts (B,) int32) as Decoder.traceback_batch
-                reads them -- pair b's walk is states[b, :counts[b]]; counts < 0: the walk left the matrix)."""
+                reads them -- pair b's walk is states[b, :counts[b]]; counts < 0: the walk left the matrix).
+        With gather="paths" AND per-pair lengths, E_local is produced without its zero fill: outside each pair's
+        [n_b, m_b] block it holds uninitialised memory (possibly NaN), because the device walk -- the only consumer in
+        that mode -- masks by the same lengths.  Reduce / log / plot it only inside the blocks, or use another gather mode."""
         n_real = theta.shape[0]
         if plan is not None:
             if lengths is None:

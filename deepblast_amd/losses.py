@@ -116,9 +116,12 @@ class _DecodeLoss(torch.autograd.Function):
         B, N, M = th.shape
         Vt, Q = eng.forward(th, a, variant, lens_dp, exact_state=True)
         ones = torch.ones(B, dtype=torch.float32, device=th.device)
-        # E outside the pairs' blocks is read by nobody in this op (the loss masks by its lengths, both adjoint sweeps by the
-        # DP's): not filled unless the caller wants the returned E whole
-        E = eng.backward(ones, Q, (B, N, M), variant, lens_dp, exact_state=True, **({} if (fill or lens_dp is None) else {"no_fill": True}))
+        # E outside the pairs' blocks is read by nobody in this op WHEN THE LOSS MASKS BY THE DP'S OWN LENGTHS (one tensor for
+        # both: the loss slices by it, both adjoint sweeps mask by it): then it is not filled unless the caller wants the returned
+        # E whole.  If the loss's lengths are another tensor (x_len / y_len may exceed `lengths`: the API allows it) the loss kernel
+        # and the per-pair scale would read E between the two blocks, so E is zero-filled as decode() fills it.
+        lean = (not fill) and lens_dp is not None and lens_dp is lens_loss
+        E = eng.backward(ones, Q, (B, N, M), variant, lens_dp, exact_state=True, **({"no_fill": True} if lean else {}))
         acc = torch.empty(B, dtype=torch.float64, device=th.device)
         cnt = torch.empty(B, dtype=torch.int32, device=th.device)
         with torch.cuda.device(dev), eng._bracket("sdp_loss_fwd_kernel"):
@@ -165,10 +168,12 @@ def decode_loss(decoder, loss, theta, A, first, x_len, y_len, G, lengths=None, f
     lengths : optional (B,2) per-pair sizes for the DP itself (None = the reference's full padded DP)
     The scalar is differentiable w.r.t. theta (the gradient w.r.t. A is None, as in the reference's second-order
     path, nw.py:386); E is returned for inspection / traceback and is not differentiable through this op.
-    fill    : with `lengths`, False (default) leaves E OUTSIDE each pair's block unwritten -- nothing in this op reads it
-              (the loss slices by x_len / y_len as deepblast/losses.py:30-40 does, the sweeps mask by `lengths`), and
-              `decoder.traceback_batch(E, lengths)` does not either; True zero-fills it like decoder.decode() does.
-              The gradient w.r.t. theta is always zero outside the blocks."""
+    fill    : with `lengths` EQUAL to (x_len, y_len) -- the usual case -- False (default) leaves E OUTSIDE each pair's block
+              unwritten (uninitialised memory, possibly NaN): nothing in this op reads it (the loss slices by x_len / y_len as
+              deepblast/losses.py:30-40 does, the sweeps mask by `lengths`), and `decoder.traceback_batch(E, lengths)` does not
+              either; True zero-fills it like decoder.decode() does.  When `lengths` differs from (x_len, y_len) E is always
+              zero-filled: the loss then reads cells outside the DP's blocks.  The gradient w.r.t. theta is always zero
+              outside the blocks."""
     from ._engine import NW, SW
     from .sw import SmithWatermanDecoder
     variant = SW if isinstance(decoder, SmithWatermanDecoder) else NW
