@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 KERNELS = os.path.join(HERE, "csrc", "sdp_kernels.hip")
-KERNEL_GROUPS = 8   # SDP_GROUP = 0 .. 7 (sdp_kernels.hip, "SDP_IN_GROUP")
+KERNEL_GROUPS = 9   # SDP_GROUP = 0 .. 8 (sdp_kernels.hip, "SDP_IN_GROUP")
 SRC = [KERNELS, os.path.join(HERE, "csrc", "sdp_scores.hip"), os.path.join(HERE, "csrc", "sdp_ref.hip"),
        os.path.join(HERE, "csrc", "sdp_comm.hip"), os.path.join(HERE, "csrc", "sdp_api.hip")]
 HDR = [os.path.join(HERE, "csrc", "sdp_kernels.h"), os.path.join(ROOT, "include", "sdp.h")]

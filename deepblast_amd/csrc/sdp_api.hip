@@ -104,6 +104,9 @@ Variant variant(int id)
     case 27: return {(const void *)sdp_bwd_pg_kernel, SDP_K_BWD, SDP_MAXW_BWD, 27};
     case 28: return {(const void *)sdp_bwd_x_pg_kernel, SDP_K_BWD, SDP_MAXW_BWD, 28};
     case 36: return {(const void *)sdp_bwd_pipe_kernel, SDP_K_BWD, SDP_MAXW_BWD_Q, 36};   // [1] with the chunk as one software pipeline (long pairs)
+    // [0] / [9] with the cleaning of what lies beside the matrix (per-pair lengths, partial strips; sdp_kernels.hip "need_clean")
+    case 37: return {(const void *)sdp_fwd_c_kernel, SDP_K_FWD, SDP_MAXW_FWD, 37};
+    case 38: return {(const void *)sdp_fwd_x_tp_c_kernel, SDP_K_FWD, SDP_MAXW_FWD, 38};
     default: return {(const void *)sdp_bwd_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 4};
     }
 }
@@ -150,13 +153,13 @@ struct Plan {
 int general_id(int id)
 {
     switch (id) {
-    case 0: return 11;
+    case 0: case 37: return 11;
     case 1: return 12;
     case 3: return 14;
     case 4: return 15;
     case 7: return 18;
     case 8: return 19;
-    case 9: return 20;
+    case 9: case 38: return 20;
     default: return id;
     }
 }
@@ -203,6 +206,8 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
     if (pass == sdp::PASS_BWD && exact_state) v = variant(v.id == 1 ? 7 : 8);
     const int nin = (pass == sdp::PASS_AFWD && fused_seed) ? 3 : 0;   // three staged planes (ref, pred, G)
     if (nin) v = variant(10);
+    // the aligned throughput forward builds: without any edge cleaning where nothing foreign can be met (full strips, no lengths)
+    if (pass == sdp::PASS_FWD && (has_lens || (N & 63) != 0) && (v.id == 0 || v.id == 9)) v = variant(v.id == 0 ? 37 : 38);
     if (general_pitch) v = variant(general_id(v.id));
     // The packed backward sweep's pipelined twin (sdp_kernels.hip, sdp_bwd_pipe_kernel) trades instruction issue for memory
     // latency.  Steady-state A/B over 24 shapes (tools/steady.py, +- 0.3 us; profiles/r05_steady_pipe.txt): it pays 2.3 % where
@@ -345,10 +350,24 @@ constexpr int PACKED_MAX_PATH = 4096;
 // axis do not average out over many paths -- flat scores, max |dE| by shape, packed (exact), tools/thin_probe.py / profiles/
 // r05_thin.txt: 2 x 2048 1.0e-4 (4.5e-6), 4 x 2048 7.8e-5, 8 x 2048 6.1e-5, 16 x 1772 5.0e-5, 32 x 2048 3.6e-5, 64 x 2048 1.6e-5;
 // any N x 512 <= 3.0e-5.  The soak of round 5 met 1.17e-4 at 2 x 1772 (positive gap scores).  Such problems are tiny: the exact state.
+// Round 6: the same holds for a thin PAIR inside a fat padded batch with per-pair lengths (the reference's inference loop slices
+// every pair and calls the decoder on the slice, alignment.py:165-170: each pair gets what a call of its own shape would get).
+// The state format is a property of the kernel build, so such pairs are ROUTED: a launch with per-pair lengths whose padded shape
+// admits thin long pairs (sdp::thin_pair: min(n, m) < 32 and max(n, m) > 512) runs the packed-state build with those pairs
+// skipped (Params::route = 1) and, behind it, the exact-state build for those pairs only (route = 2; its workgroups of all other
+// pairs leave at once).  The thin pair's float2 state lives inside the pair's own packed record: strip s starts where the packed
+// strip s starts (st2_ps = st_ps) -- a wide thin pair has one strip and needs <= tpad x 512 B of the nstrips x tpad x 320 B, a tall
+// thin one <= 3 units x 16 KB per strip of the tpad x 320 B a packed strip owns -- which fits as soon as the padded shape has more
+// than 64 rows and more than 65 columns; padded shapes below that (and long) take the exact state as a whole, like thin problems.
 inline bool exact_for(bool flag, int N, int M)
 {
     const int lo = N < M ? N : M, hi = N < M ? M : N;
-    return flag || N + M > PACKED_MAX_PATH || (lo < 32 && hi > 512);
+    return flag || N + M > PACKED_MAX_PATH || (lo < sdp::THIN_FITS && hi > sdp::THIN_HI);
+}
+// does a launch of this padded shape with per-pair lengths have to route thin pairs to the exact-state build?
+inline bool routes_thin(bool exact, int N, int M, const int32_t *lens)
+{
+    return lens != nullptr && !exact && (N > sdp::THIN_HI || M > sdp::THIN_HI);
 }
 
 VariantBits split_variant(int variant)
@@ -367,7 +386,7 @@ VariantBits split_variant(int variant)
 // 160 KiB the hardware has, so concurrent callers cannot disagree
 int raise_lds_limit(const Variant &v, int device)
 {
-    static thread_local unsigned long long lds_raised[37] = {0};  // per kernel id: bit d = done on device d
+    static thread_local unsigned long long lds_raised[39] = {0};  // per kernel id: bit d = done on device d
     if (device >= 64 || !(lds_raised[v.id] >> device & 1ull)) {
         hipError_t e = hipFuncSetAttribute(v.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -377,7 +396,7 @@ int raise_lds_limit(const Variant &v, int device)
 }
 
 int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state = false, int forced_waves = 0, bool fused_seed = false,
-           const void *state = nullptr)
+           const void *state = nullptr, int route = 0)
 {
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
@@ -386,6 +405,12 @@ int launch(int pass, sdp::Params &p, int device, void *stream, bool exact_state 
     p.tpad = sdp::state_tpad(p.M);
     p.mcap = (p.M + 63) / 64 * 64;
     state_layout(p);
+    p.route = route;
+    if (route == 2) {   // thin pairs only, exact-state build, inside the packed records (see exact_for): one workgroup per pair, batch order
+        p.st2_ps = p.st_ps;
+        p.order = nullptr;
+        state = nullptr;
+    }
     p.status = status_words(device);
 #ifdef SDP_EXPERIMENTS
     p.dbg = g_dbg.load();
@@ -527,8 +552,9 @@ int sdp_max_cols(void) { return sdp::MAX_COLS; }
 size_t sdp_state_bytes(int B, int N, int M)
 {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
-    // 2 x 23 bits per cell, 3 dwords per 2 cells (a 768-byte record row per pair of steps); + the launch order of a
-    // variable-length batch.  Problems longer than PACKED_MAX_PATH, and thin long ones, keep the exact state (see exact_for).
+    // 2 x 20 bits per cell, five dwords per four cells (ten rows of 1024 B per 32 steps of a strip); + the launch order of a
+    // variable-length batch, the bridge rows and the dispatch map of a parts launch.  Problems longer than PACKED_MAX_PATH, and
+    // thin long ones, keep the exact state (see exact_for).
     if (exact_for(false, N, M)) return sdp_state_d_bytes(B, N, M);
     return packed_body_bytes(B, N, M) + sdp::state_order_bytes(B) + bridge_bytes(B, N, M) + parts_map_bytes(B, N);
 }
@@ -579,7 +605,7 @@ int sdp_init(int device)
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
     if (device >= 0 && device < MAX_DEV && !status_words(device)) return fail(SDP_E_SELFTEST, "sdp_init: could not create the host-pinned status words");
-    for (int id = 0; id <= 36; ++id) {   // (21-28: the parts instantiations, 29-35: the 18-bit packed state, 36: the pipelined backward twin)
+    for (int id = 0; id <= 38; ++id) {   // (21-28: the parts instantiations, 36: the pipelined backward twin, 37 / 38: the cleaning forward twins)
         const Variant v = variant(id);
         if (v.id != id) continue;   // ids without a build of their own map to the default
         if (int rc = raise_lds_limit(v, device)) return rc;
@@ -641,7 +667,9 @@ int sdp_forward_f32(const float *theta, const float *A, float *state, float *Vt,
         if (e != hipSuccess) return fail_hip(e, "sdp_order_kernel");
         if (B > num_cus(device)) p.order = order;   // (with parts the launch takes it from the state by itself)
     }
-    return launch(sdp::PASS_FWD, p, device, stream, exact, vb.waves, false, state);
+    if (!routes_thin(exact, N, M, lens)) return launch(sdp::PASS_FWD, p, device, stream, exact, vb.waves, false, state);
+    if (int rc = launch(sdp::PASS_FWD, p, device, stream, false, vb.waves, false, state, 1)) return rc;
+    return launch(sdp::PASS_FWD, p, device, stream, true, 0, false, nullptr, 2);
 }
 
 int sdp_backward_f32(const float *Et, const float *state, float *E, int B, int N, int M, const int32_t *lens,
@@ -665,7 +693,9 @@ int sdp_backward_f32(const float *Et, const float *state, float *E, int B, int N
     p.lens = lens;
     p.B = B, p.N = N, p.M = M, p.variant = variant, p.flags = vb.flags;
     if (lens != nullptr && B > num_cus(device)) p.order = order_in_state(state, B, N, M, exact);
-    return launch(sdp::PASS_BWD, p, device, stream, exact, vb.waves, false, state);
+    if (!routes_thin(exact, N, M, lens)) return launch(sdp::PASS_BWD, p, device, stream, exact, vb.waves, false, state);
+    if (int rc = launch(sdp::PASS_BWD, p, device, stream, false, vb.waves, false, state, 1)) return rc;
+    return launch(sdp::PASS_BWD, p, device, stream, true, 0, false, nullptr, 2);
 }
 
 size_t sdp_state_pair_stride(int N, int M, int exact_state)

@@ -72,6 +72,11 @@ constexpr int max_waves(int pass)
     return pass == PASS_FWD ? SDP_MAXW_FWD : (pass == PASS_BWD ? SDP_MAXW_BWD : (pass == PASS_AFWD ? SDP_MAXW_AFWD : SDP_MAXW_ABWD));
 }
 
+// Thin long pairs (fewer than THIN_LO rows or columns, more than THIN_HI of the other) take the exact state: the packed weights'
+// rounding does not average out over few paths (sdp_api.hip: exact_for).  thin_pair is evaluated per pair by the kernels of a routed
+// launch (Params::route); padded shapes with min(N, M) < THIN_FITS and max > THIN_HI take the exact state as a whole.
+constexpr int THIN_LO = 32, THIN_HI = 512, THIN_FITS = 66;
+__host__ __device__ constexpr bool thin_pair(int n, int m) { return (n < m ? n : m) < THIN_LO && (n < m ? m : n) > THIN_HI; }
 constexpr int MAX_COLS = 2048;     // boundary rows live in LDS (4 x MAX_COLS x 8 B = 64 KiB)
 // how a pass represents the values that flow from cell to cell (sdp_kernels.hip, "Carry kinds")
 enum { CK_F64 = 0, CK_F32 = 1, CK_EXP = 2 };
@@ -101,6 +106,7 @@ struct Params {
     int mcap;            // doubles per boundary row in LDS
     int stage_off;       // byte offset of the per-wave staging area in LDS
     int variant;
+    int route;           // 0: every pair; 1: thin long pairs (thin_pair) are skipped; 2: ONLY they are swept (sdp_api.hip: exact_for)
     int flags;           // bit 0: run every chunk (SDP_NO_ZERO_SKIP), bit 1: no zero fill outside the pairs' blocks (SDP_NO_FILL)
     int dbg;             // experiments build only (sdp_set_debug): bit0 inputs, bit1 outputs, bit2 state: all pairs alias
                          // pair 0; bit3: strips never publish their progress (exercises the hand-off time-out)
@@ -161,6 +167,8 @@ __global__ void sdp_fwd_kernel(const sdp::Params p);
 __global__ void sdp_fwd_lat_kernel(const sdp::Params p);
 __global__ void sdp_fwd_x_kernel(const sdp::Params p);
 __global__ void sdp_fwd_x_tp_kernel(const sdp::Params p);
+__global__ void sdp_fwd_c_kernel(const sdp::Params p);
+__global__ void sdp_fwd_x_tp_c_kernel(const sdp::Params p);
 __global__ void sdp_bwd_kernel(const sdp::Params p);
 __global__ void sdp_bwd_pipe_kernel(const sdp::Params p);
 __global__ void sdp_bwd_lat_kernel(const sdp::Params p);

@@ -44,7 +44,6 @@
 #include <stdint.h>
 
 #include <type_traits>
-#include <utility>
 
 #include "sdp_kernels.h"
 
@@ -103,14 +102,6 @@ constexpr unsigned OOB = 0x80000000u;  // voffset that is out of range for every
 #ifndef SDP_TB_WINDOW
 #define SDP_TB_WINDOW 32  // traceback: edge of the LDS window of E (32 or 64 cells)
 #endif
-// Round 6: the forward chunk as a software pipeline (see fwd_blocks).  bit0: the block's boundary reads are issued first, the 2^theta /
-// 2^A of the block are computed behind them, then the one wait; bit1: the inputs of the next block are read from the LDS ring
-// inside the steps of the current one (two register sets); bit2: the boundary values a block hands down leave four at a time
-// inside its steps, only the frame and progress words stay behind the range test; bit3: the LDS writes of the next block set are
-// spread through the steps of the chunk's second block.  (A build-time mask while the pieces are being measured.)
-#ifndef SDP_FWP
-#define SDP_FWP 0
-#endif
 // Everything below used to be a compile-time switch of its own (31 of them by round 5).  Each was measured, one setting won, and
 // the losing code paths were deleted in round 6 (their measurements: DESIGN_HISTORY.md, "Switches retired in round 6"; the code:
 // git history).  What is left are the constants the winning settings fold to.
@@ -155,18 +146,6 @@ template <class X>
 __device__ __forceinline__ void keep(X &x)
 {
     asm volatile("" : "+v"(x));
-}
-
-// f(integral_constant<int, 0>{}), ..., f(integral_constant<int, N - 1>{}): a loop whose index is a compile-time constant inside f
-template <int... I, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f)
-{
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
 // ----------------------------------------------------------------------------------
@@ -403,12 +382,14 @@ __device__ __forceinline__ float loss_dterm(float r, float y, float sc, int kind
 // start on K-float boundaries (M a multiple of 32, 128-byte aligned tensors): the same formulas with the offsets
 // folded to constants -- the host picks per launch (sdp_api.hip), and the headline shape pays nothing for generality
 // (with one instantiation for both, the forward kernel measured +5 % and the backward +3 % at M = 512).
-template <int PASS, int K, bool QX = false, bool LINES = false, bool GEN = false, bool PARTS = false, bool NOPIPE = false>
+template <int PASS, int K, bool QX = false, bool LINES = false, bool GEN = false, bool PARTS = false, bool NOPIPE = false, bool NOCLEAN = false>
 __device__ __forceinline__ void sweep(const Params &p)
 {
     using T = Traits<PASS, QX>;
     constexpr bool REV = T::REV;
     constexpr int KIND = Kind<PASS>::value;
+    constexpr bool CLEAN = PASS == PASS_FWD && !NOCLEAN;   // forward sweep: what lies beside the matrix takes no part in anything (see need_clean)
+    static_assert(!NOCLEAN || (LINES && !GEN && !PARTS), "only the aligned throughput builds have a twin without the cleaning");
     constexpr int RPI = 64 / K;    // tensor rows covered by one staged (dword) store instruction
     constexpr int PITCH = 2 * K;   // LDS pitch of a staged input plane: a ring of two K-column blocks per row
     constexpr int RING = 2 * K;
@@ -464,6 +445,9 @@ __device__ __forceinline__ void sweep(const Params &p)
     }
     n = __builtin_amdgcn_readfirstlane(n);
     m = __builtin_amdgcn_readfirstlane(m);
+    // routed launches (per-pair lengths; sdp_api.hip: exact_for): thin long pairs belong to the exact-state build's launch, all
+    // others to the packed-state build's -- the workgroups of the other kind leave before they touch anything
+    if (p.route != 0 && thin_pair(n, m) != (p.route == 2)) return;
     const int nstrips = (n + 63) >> 6;
     const int nchunks = (m + 63 + K - 1) / K;  // steps t in [0, m+63)
     const bool sw = p.variant == SDP_SW;
@@ -746,12 +730,6 @@ __device__ __forceinline__ void sweep(const Params &p)
         // ever surface as the SIGN of a zero in Ed, so Ed is stored as (float)ed + 0.0f in both paths: bit-identical results.
         constexpr bool ZSKIP_A = PASS == PASS_ABWD && !ABL_NOMATH && !ABL_NOLOAD;
         float rs[ZSKIP_A ? 2 : 1][NS][K];   // staged inputs of the NEXT chunk (registers); ZSKIP_A: of the next two chunks
-        // forward sweep, K = 32 builds: the 2 x 16 inputs (theta, A) of a block, one register set per block of the chunk; set 0 is
-        // filled at the end of the previous chunk (behind the staging writes), set 1 inside the steps of block 0 (FW_PRE)
-        constexpr bool FW_PIPE = PASS == PASS_FWD && !ABL_NOMATH && K == 2 * WB && LINES;
-        constexpr bool FW_LATE = FW_PIPE && (SDP_FWP & 1), FW_PRE = FW_PIPE && (SDP_FWP & 2), FW_PUBIN = FW_PIPE && (SDP_FWP & 4), FW_STAGEIN = FW_PIPE && (SDP_FWP & 8);
-        float fin0[2][WB], fin1[2][WB];
-        bool fw_staged = false;    // (FW_STAGEIN) the chunk's second block has written the next block set into the ring already
         // exact Q rows / Qd rows: slot k of a set holds step t0+k of a chunk; two sets whose roles (current chunk / next chunk)
         // swap every chunk (ROT)
         float2 rqx2[2][K];
@@ -959,7 +937,35 @@ __device__ __forceinline__ void sweep(const Params &p)
         // every address of block set bb in range: the uniform part may ride in the scalar offset (no VALU
         // add and no reliance on how the hardware range-checks the scalar offset)
         // (blocks moved left by up to K-1 columns: one block set later)
-        auto block_plain = [&](int bb) { return rows == 64 && bb >= QMAX + (li_unaligned ? 1 : 0) && (bb + 1) * K <= m; };
+        // (the latency builds' groups start at columns K j - (r mod 4): block set QMAX still holds groups that straddle column 0 of
+        //  the rows with q = QMAX -- up to three floats of the row above -- so there, too, plain begins one block set later)
+        auto block_plain = [&](int bb) { return rows == 64 && bb >= QMAX + ((li_unaligned || (CLEAN && !LINES)) ? 1 : 0) && (bb + 1) * K <= m; };
+        // Forward sweep: what lies BESIDE the matrix must not take part in anything (round 6).  A loaded group of four columns may
+        // straddle column 0 or column m -- up to three floats of the neighbouring row, of the neighbouring pair, of the padding of a
+        // batch with per-pair lengths, or of whatever follows the tensor in memory -- and the rows below a partial strip are rows of
+        // another problem altogether.  No RESULT ever depended on them (cells outside the matrix hand nothing to cells inside), but
+        // the windowed form's range test looks at every lane's inputs and values, so WHICH FORM a block ran in did -- and with it
+        // the timing, and in the packed state the last bits (the per-step form sharpens its weights): round 5's wrong-result bug
+        // needed a plane offset of 3 floats to show for exactly this reason.  Now: rows below the strip's last row are not fetched
+        // (out-of-range offset: zeros), and elements outside [0, m) are replaced by 0 on their way into the LDS ring, so that every
+        // cell outside the matrix computes from theta = A = 0.  Only block sets that touch an edge pay (the non-plain ones), and
+        // only where something foreign can be met at all: per-pair lengths, partial strips, unaligned pitch (GEN), the latency
+        // builds' shifted groups -- the aligned throughput build on full strips without lengths loads whole groups inside or
+        // outside a row and nothing else (tests/test_robustness_gpu.py::test_what_lies_beside_the_matrix_...).
+        // What it costs, and who pays (steady state, same box, main vs the same build without any of this: forward sweep of
+        // 256 x 512^2 169.6 vs 166.2 us although nothing was cleaned there -- the mere presence of the code costs registers in the
+        // ramp chunks, which are a pair's critical path; 64 x 512^2 on the latency build, cleaning every edge block set: 143.9 vs
+        // 135.2).  So: CLEAN is a property of the BUILD.  The aligned throughput builds exist twice -- without a trace of it
+        // (NOCLEAN: sdp_fwd_kernel, sdp_fwd_x_tp_kernel: full strips, no lengths, aligned pitch -- every loaded group lies wholly inside
+        // or wholly outside its row, and those outside are never fetched) and with it (sdp_fwd_c_kernel, sdp_fwd_x_tp_c_kernel: per-pair
+        // lengths or N not a multiple of 64; sdp_api.hip picks).  The general-pitch, latency and parts builds always carry it, and
+        // apply it where something foreign can be met: lengths, partial strips, and -- their groups straddle every row's ends --
+        // the strips that hold the plane's first and last row (the rows in between straddle into their own plane's neighbouring
+        // rows: data of the same problem, the same on every run).  Nothing of it is kept in registers across the chunk loop.
+        auto need_clean = [&]() {
+            if constexpr (!CLEAN) return false;
+            else return rows < 64 || p.lens != nullptr || ((GEN || !LINES) && (s == 0 || s == nstrips - 1));
+        };
         auto load_block_i = [&](int bb, auto plain_tag, int i, auto rset_tag) {  // instruction i of block set bb -> registers (set RS)
             constexpr bool plain = decltype(plain_tag)::value;
             constexpr int RS = decltype(rset_tag)::value;   // (a compile-time flag: with a run-time one every load sat behind its own branch)
@@ -974,7 +980,9 @@ __device__ __forceinline__ void sweep(const Params &p)
                 // floats for the first rows, so 3K floats travel from the scalar part to the per-lane part (plain block
                 // sets then have bb >= QMAX + 1 = 3, i.e. a scalar part of at least 3K floats).
                 const int bias = li_unaligned ? 3 * K * 4 : 0;
-                const unsigned off = plain ? li_voff[i] + (unsigned)bias : ((col > -4 && col < m) ? li_voff[i] + (unsigned)ubase : OOB);
+                // (forward sweep: rows below a partial strip are not fetched)
+                const bool rok = !CLEAN || (LINES ? ((i & 3) + 32 * (i >> 2) + 4 * r4_l) : (i * RPL + r4_l)) < rows;
+                const unsigned off = plain ? li_voff[i] + (unsigned)bias : ((col > -4 && col < m && rok) ? li_voff[i] + (unsigned)ubase : OOB);
 #pragma unroll
                 for (int q = 0; q < T::SIN; ++q) {
                     if constexpr (ABL_NOLOAD) {
@@ -1012,59 +1020,65 @@ __device__ __forceinline__ void sweep(const Params &p)
             for (int k = 0; k < K; ++k) any |= __float_as_uint(rs[RS][0][k]) << 1;   // (the sign does not matter: e = -0 multiplies like +0 here)
             return __builtin_amdgcn_ballot_w64(any != 0) == 0;
         };
-        // registers -> LDS ring: the four columns instruction i loaded of plane q (a "unit": 1-4 LDS writes), block set bb
-        // (i and q are constants wherever this is called -- fully unrolled loops -- so the tests on them fold)
-        auto write_unit = [&](int bb, int i, int q, auto rset_tag) {
+        auto write_block_c = [&](int bb, auto rset_tag, auto clean_tag) {  // registers -> LDS ring
             constexpr int RS = decltype(rset_tag)::value;
+            constexpr bool CLEAN = decltype(clean_tag)::value;   // elements outside the row's columns [0, m) become 0 (see need_clean)
             if constexpr (T::SIN > 0 && !ABL_NOLDS) {
                 const int flip = (bb & 1) * K;
-                if constexpr (LINES && !GEN) {
-                    // aligned planes and pitch: ring position of the group's first column = r mod 4 = i mod 4 (mod 4)
-                    float *dst = lds_in + q * PLANE;
-                    const float v0 = rs[RS][q][4 * i], v1 = rs[RS][q][4 * i + 1], v2 = rs[RS][q][4 * i + 2], v3 = rs[RS][q][4 * i + 3];
-                    if ((i & 3) == 0) {
-                        *reinterpret_cast<float4 *>(dst + (li_w[i][0] ^ flip)) = make_float4(v0, v1, v2, v3);
-                    } else if ((i & 3) == 2) {
-                        *reinterpret_cast<float2 *>(dst + (li_w[i][0] ^ flip)) = make_float2(v0, v1);
-                        *reinterpret_cast<float2 *>(dst + (li_w[i][2] ^ flip)) = make_float2(v2, v3);
-                    } else {
-                        // (the middle pair as ds_write2_b32 -- two data registers of its own -- not ds_write_b64: elements 1, 2 of a loaded
-                        //  dwordx4 are an ODD-aligned register pair, a 64-bit operand wants an even one, and the compiler made one by
-                        //  copying half of every such load into other registers: 16 moves per chunk, and -- once the writes moved away
-                        //  from the loads (FW_STAGEIN) -- placed right behind the loads with a ladder of waits for them)
-                        dst[li_w[i][0] ^ flip] = v0;
-                        asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" : : "v"((unsigned)(uintptr_t)(dst + (li_w[i][1] ^ flip))), "v"(v1), "v"(v2) : "memory");
-                        dst[li_w[i][3] ^ flip] = v3;
-                    }
-                } else if constexpr (LINES) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) lds_in[q * PLANE + (li_w[i][j] ^ flip)] = rs[RS][q][4 * i + j];
-                } else {
-                    *reinterpret_cast<float4 *>(lds_in + q * PLANE + (li_w[i][0] ^ flip)) =
-                        make_float4(rs[RS][q][4 * i], rs[RS][q][4 * i + 1], rs[RS][q][4 * i + 2], rs[RS][q][4 * i + 3]);
+                for (int i = 0; i < NLD; ++i) {
+                    if constexpr (CLEAN) {
+                        const int col = li_col[i] + bb * K;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool ok = (unsigned)(col + j) < (unsigned)m;
+#pragma unroll
+                            for (int q = 0; q < T::SIN; ++q) rs[RS][q][4 * i + j] = ok ? rs[RS][q][4 * i + j] : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < T::SIN; ++q) {
+                        if constexpr (LINES && !GEN) {
+                            // aligned planes and pitch: ring position of the group's first column = r mod 4 = i mod 4 (mod 4)
+                            float *dst = lds_in + q * PLANE;
+                            const float v0 = rs[RS][q][4 * i], v1 = rs[RS][q][4 * i + 1], v2 = rs[RS][q][4 * i + 2], v3 = rs[RS][q][4 * i + 3];
+                            if ((i & 3) == 0) {
+                                *reinterpret_cast<float4 *>(dst + (li_w[i][0] ^ flip)) = make_float4(v0, v1, v2, v3);
+                            } else if ((i & 3) == 2) {
+                                *reinterpret_cast<float2 *>(dst + (li_w[i][0] ^ flip)) = make_float2(v0, v1);
+                                *reinterpret_cast<float2 *>(dst + (li_w[i][2] ^ flip)) = make_float2(v2, v3);
+                            } else {
+                                // (the middle pair as ds_write2_b32 -- two data registers of its own -- not ds_write_b64: elements 1, 2 of a
+                                //  loaded dwordx4 are an ODD-aligned register pair, a 64-bit operand wants an even one, and the compiler makes
+                                //  one by copying -- 16 moves per chunk, and, whenever register pressure tips it that way (round 6 saw it with
+                                //  two unrelated changes), it places the copies right BEHIND the loads with a wait for them: the whole memory
+                                //  latency exposed at the top of every chunk, forward sweep 171 -> 194 us)
+                                dst[li_w[i][0] ^ flip] = v0;
+                                asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" : : "v"((unsigned)(uintptr_t)(dst + (li_w[i][1] ^ flip))), "v"(v1), "v"(v2) : "memory");
+                                dst[li_w[i][3] ^ flip] = v3;
+                            }
+                        } else if constexpr (LINES) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) lds_in[q * PLANE + (li_w[i][j] ^ flip)] = rs[RS][q][4 * i + j];
+                        } else {
+                            *reinterpret_cast<float4 *>(lds_in + q * PLANE + (li_w[i][0] ^ flip)) =
+                                make_float4(rs[RS][q][4 * i], rs[RS][q][4 * i + 1], rs[RS][q][4 * i + 2], rs[RS][q][4 * i + 3]);
+                        }
+                    }
                 }
             }
         };
-        auto write_block_s = [&](int bb, auto rset_tag) {  // the whole block set
-#pragma unroll
-            for (int i = 0; i < NLD; ++i)
-#pragma unroll
-                for (int q = 0; q < T::SIN; ++q) write_unit(bb, i, q, rset_tag);
+        auto write_block_s = [&](int bb, auto rset_tag) {
+            if constexpr (CLEAN) {
+                if (!block_plain(bb) && need_clean()) {
+                    write_block_c(bb, rset_tag, std::true_type{});
+                    return;
+                }
+            }
+            write_block_c(bb, rset_tag, std::false_type{});
         };
         auto write_block = [&](int bb) { write_block_s(bb, rs0_t{}); };
 
-        // (forward sweep) the 2 x 16 inputs of the block that starts at step tb: eight aligned 16-byte reads out of the ring
-        auto read_inputs = [&](int tb, float *d0, float *d1) {
-            const int pr = (tb & (RING - 1)) + 4 * ring_pi(lane & 7);
-#pragma unroll
-            for (int g = 0; g < WB / 4; ++g) {
-                const int idx = lane * PITCH + ((pr + 4 * g) & (RING - 1));
-                const float4 v0 = *reinterpret_cast<const float4 *>(lds_in + idx);
-                const float4 v1 = *reinterpret_cast<const float4 *>(lds_in + PLANE + idx);
-                d0[4 * g] = v0.x, d0[4 * g + 1] = v0.y, d0[4 * g + 2] = v0.z, d0[4 * g + 3] = v0.w;
-                d1[4 * g] = v1.x, d1[4 * g + 1] = v1.y, d1[4 * g + 2] = v1.z, d1[4 * g + 3] = v1.w;
-            }
-        };
         const int c_first = REV ? nchunks - 1 : 0;
         const int dir = REV ? -1 : 1;
 
@@ -1105,7 +1119,6 @@ __device__ __forceinline__ void sweep(const Params &p)
         if constexpr (ZSKIP_A) za_b1 = block_zero(rs0_t{});
         load_block(c_first + 1);
         write_block(c_first + 1);
-        if constexpr (FW_PRE) read_inputs(c_first * K, fin0[0], fin1[0]);
         if constexpr (ZSKIP_A) {
             za_b2 = block_zero(rs0_t{});
             known_zero = false;                     // (the first chunk's rows are fetched whatever it turns out to be)
@@ -1132,6 +1145,17 @@ __device__ __forceinline__ void sweep(const Params &p)
         // Both forms produce identical bits (same 2^theta, exact power-of-two rescaling), so results do not depend on
         // which form a block ran in, on K, or on the batch.
         constexpr bool FWD_SUB = PASS == PASS_FWD && !ABL_NOMATH;
+        auto read_inputs = [&](int tb, float *d0, float *d1) {
+            const int pr = (tb & (RING - 1)) + 4 * ring_pi(lane & 7);
+#pragma unroll
+            for (int g = 0; g < WB / 4; ++g) {
+                const int idx = lane * PITCH + ((pr + 4 * g) & (RING - 1));
+                const float4 v0 = *reinterpret_cast<const float4 *>(lds_in + idx);
+                const float4 v1 = *reinterpret_cast<const float4 *>(lds_in + PLANE + idx);
+                d0[4 * g] = v0.x, d0[4 * g + 1] = v0.y, d0[4 * g + 2] = v0.z, d0[4 * g + 3] = v0.w;
+                d1[4 * g] = v1.x, d1[4 * g + 1] = v1.y, d1[4 * g + 2] = v1.z, d1[4 * g + 3] = v1.w;
+            }
+        };
         // Boundary row of the block-wise forward sweep: the 8 bytes per column are kept as two PLANES -- mcap values (float)
         // followed by mcap exponents (int) -- instead of (value, exponent) pairs.  A block published in one frame (the
         // normal case) writes and reads its 16 values only: four 16-byte LDS accesses instead of sixteen 8-byte ones on
@@ -1278,11 +1302,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                     // block, the values read behind it are the published ones; otherwise (only while the pipeline fills)
                     // the wave spins as before and reads them again.
                     float bcf0[WB];
-                    // the block's inputs: read here, or (FW_PRE) already in this block's register set -- set 0 filled behind the
-                    // previous chunk's staging writes, set 1 inside the steps of block 0 when that ran the pipelined body
-                    float in_l[2][WB];
-                    float *const in0 = FW_PRE ? &fin0[sb][0] : &in_l[0][0], *const in1 = FW_PRE ? &fin1[sb][0] : &in_l[1][0];
-                    constexpr bool have_inputs = FW_PRE;
+                    float in0[WB], in1[WB];
                     int fa0 = 0, fb0 = 0, prog_seen = 0;
                     const int need = tb + WB < m ? tb + WB : m;
                     if (use_pred && imported) {
@@ -1311,40 +1331,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         if constexpr (!ABL_NOSYNC) prog_seen = lds_issue_i32(prog + 4 * pword);
                     }
                     read_boundary(tb, bcf0, fa0, fb0);
-                    if constexpr (!have_inputs) read_inputs(tb, in0, in1);
-                    // (FW_PRE) the SECOND block's inputs are requested by the first, behind its own boundary reads: the reads are in flight
-                    // under the first block's 2^theta / 2^A, and set 1 is defined on every path through the chunk (conditional reads
-                    // turned the set into a loop-carried value that the compiler parked in AGPRs: 64 moves per chunk)
-                    if constexpr (FW_PRE && sb == 0) read_inputs(tb + WB, fin0[1], fin1[1]);
-                    // 2^theta, 2^A of the block (windowed form): the log2(e) scalings as packed multiplies (two values per instruction).
-                    // Range of the factors, tested on the exponents: |theta log2e| <= 12 (two-sided) and A log2e <= 12.
-                    // With 2^-12 <= 2^theta <= 2^12 the per-step test on the lane's own value x is enough: the sum it
-                    // was made from is x / 2^theta, i.e. within [2^-112, 2^122] -- normal, with a normal reciprocal --
-                    // whatever the neighbour's scaled values were (an overflow or NaN anywhere ends up in x).
-                    // FW_LATE: computed HERE, between the issue of the block's LDS reads and the wait for them -- it needs nothing but
-                    // the inputs, and the hand-off's round trip (progress word, boundary values, frame words) passes underneath.
-                    float ctv[WB], cav[WB];
-                    float mcf = 0.f;
-                    auto exp_prep = [&]() {
-#pragma unroll
-                        for (int j = 0; j < WB; j += 2) {
-                            const f32x2 tt = (f32x2){in0[j], in0[j + 1]} * (f32x2){1.44269504088896340736f, 1.44269504088896340736f};
-                            const f32x2 ta = (f32x2){in1[j], in1[j + 1]} * (f32x2){1.44269504088896340736f, 1.44269504088896340736f};
-                            ctv[j] = __builtin_amdgcn_exp2f(tt[0]), ctv[j + 1] = __builtin_amdgcn_exp2f(tt[1]);
-                            cav[j] = __builtin_amdgcn_exp2f(ta[0]), cav[j + 1] = __builtin_amdgcn_exp2f(ta[1]);
-                            if constexpr (QX) {
-                                const f32x2 c = exp2_residual((f32x2){in0[j], in0[j + 1]}, tt);
-                                const f32x2 e = __builtin_elementwise_fma((f32x2){ctv[j], ctv[j + 1]}, c, (f32x2){ctv[j], ctv[j + 1]});
-                                ctv[j] = e[0], ctv[j + 1] = e[1];
-                            }
-                            mcf = __builtin_fmaxf(__builtin_fmaxf(mcf, __builtin_fabsf(tt[0])), __builtin_fabsf(tt[1]));
-                            mcf = __builtin_fmaxf(__builtin_fmaxf(mcf, ta[0]), ta[1]);
-                        }
-                    };
-                    if constexpr (FW_LATE) {
-                        if (wf_skip == 0) exp_prep();
-                        __builtin_amdgcn_sched_barrier(0);   // (the scheduler would move the wait below up, or the work above down)
-                    }
+                    read_inputs(tb, in0, in1);
                     if (use_pred) {
                         bool ready = ABL_NOSYNC;
                         if constexpr (!ABL_NOSYNC) {
@@ -1395,14 +1382,12 @@ __device__ __forceinline__ void sweep(const Params &p)
                     // whichever form computed the block -- NOT once behind both: with the 16 values (32 registers) flowing
                     // from two code paths into one publishing site the compiler shuffled them into common registers
                     // with 45-70 moves per block (a seventh of the block's instructions) ----
-                    auto publish = [&](bool vals_done = false) {   // vals_done: the pipelined steps have written the 16 values already
+                    auto publish = [&]() {
                         stamp(2);
                     // ---- publish the block: 16 boundary values, their frame word, then the progress word ----
                         if (has_succ) {
                             const int c_lo = tb - 63;  // lane 63 produced column tb+j-63 at step j
-                            if (lane == PUB_LANE && vals_done) {
-                                frm_out[tb / WB] = frame_pub;
-                            } else if (lane == PUB_LANE) {
+                            if (lane == PUB_LANE) {
                                 // values always; exponents only where the block is not in one frame (c_lo = tb - 63 is 1 mod 4:
                                 // the 16-byte stores are not aligned, which LDS accepts -- one lane, off the critical path)
                                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -1478,25 +1463,30 @@ __device__ __forceinline__ void sweep(const Params &p)
 #pragma unroll
                             for (int j = 0; j < WB; ++j) bf[j] = xz;
                         }
-                        if constexpr (!FW_LATE) exp_prep();
+                        // 2^theta, 2^A of the block: the log2(e) scalings as packed multiplies (two values per instruction)
+                        // Range of the factors, tested on the exponents: |theta log2e| <= 12 (two-sided) and A log2e <= 12.
+                        // With 2^-12 <= 2^theta <= 2^12 the per-step test on the lane's own value x is enough: the sum it
+                        // was made from is x / 2^theta, i.e. within [2^-112, 2^122] -- normal, with a normal reciprocal --
+                        // whatever the neighbour's scaled values were (an overflow or NaN anywhere ends up in x).
+                        float ctv[WB], cav[WB];
+                        float mcf = 0.f;
+#pragma unroll
+                        for (int j = 0; j < WB; j += 2) {
+                            const f32x2 tt = (f32x2){in0[j], in0[j + 1]} * (f32x2){1.44269504088896340736f, 1.44269504088896340736f};
+                            const f32x2 ta = (f32x2){in1[j], in1[j + 1]} * (f32x2){1.44269504088896340736f, 1.44269504088896340736f};
+                            ctv[j] = __builtin_amdgcn_exp2f(tt[0]), ctv[j + 1] = __builtin_amdgcn_exp2f(tt[1]);
+                            cav[j] = __builtin_amdgcn_exp2f(ta[0]), cav[j + 1] = __builtin_amdgcn_exp2f(ta[1]);
+                            if constexpr (QX) {
+                                const f32x2 c = exp2_residual((f32x2){in0[j], in0[j + 1]}, tt);
+                                const f32x2 e = __builtin_elementwise_fma((f32x2){ctv[j], ctv[j + 1]}, c, (f32x2){ctv[j], ctv[j + 1]});
+                                ctv[j] = e[0], ctv[j + 1] = e[1];
+                            }
+                            mcf = __builtin_fmaxf(__builtin_fmaxf(mcf, __builtin_fabsf(tt[0])), __builtin_fabsf(tt[1]));
+                            mcf = __builtin_fmaxf(__builtin_fmaxf(mcf, ta[0]), ta[1]);
+                        }
                         // (a NaN in theta or A is ignored by the maxima above but turns x into NaN, whose bit pattern
                         // fails the upper test below)
                         mc = mcf <= 12.0f ? 0u : 0xffffffffu;
-                        // The pipelined body (interior blocks of the K = 32 builds; round 6).  A wave that has its SIMD to itself hides
-                        // nothing: round 5's stamps had a 16-step block at ~750 cycles of waiting for LDS reads, ~2150 of recurrence and
-                        // ~700 of publishing, plus ~2400 per chunk for the staging writes and loads between two blocks.  An LDS instruction
-                        // costs ~17 cycles in a row of its kind and ~6 between VALU instructions, so everything that does not depend on
-                        // the hand-off rides inside the 16 steps:
-                        //   * FW_PRE, first block of a chunk: the 8 reads of the SECOND block's inputs (register set 1);
-                        //   * FW_STAGEIN, second block: the LDS writes of block set c + 2 (loaded at the top of the chunk; it replaces set
-                        //     c, whose last reader -- this block -- has its inputs in registers), one (instruction, plane) unit per step;
-                        //   * FW_PUBIN: the values handed down, four at a time as soon as their steps are done, by the publishing lane
-                        //     (EXEC narrowed to it around one ds_write_b128; no branch).  They are not visible before the progress word,
-                        //     which stays behind the range test; a block that fails the test is redone and publishes again.
-                        constexpr bool PIPED = !EDGE;
-                        const unsigned pub_addr = (unsigned)(uintptr_t)(bv_out + (tb - 63));
-                        const unsigned long long pub_exec = has_succ ? (1ull << PUB_LANE) : 0ull;
-                        float xs[WB];
 #pragma unroll
                         for (int j = 0; j < WB; ++j) {
                             const float ct = ctv[j], ca = cav[j];
@@ -1528,19 +1518,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                             }
                             mx = max(mx, __float_as_uint(x));
                             hist[j] = pack2(__float_as_uint(x), (unsigned)R);
-                            xs[j] = x;
-                            if constexpr (PIPED && FW_STAGEIN && sb == 1) write_unit(c + 2, j >> 1, j & 1, rs0_t{});
-                            if constexpr (PIPED && FW_PUBIN) {
-                                if ((j & 3) == 3) {
-                                    typedef float f32x4p __attribute__((ext_vector_type(4)));
-                                    const f32x4p pv = {xs[j - 3], xs[j - 2], xs[j - 1], xs[j]};
-                                    unsigned long long sv;
-                                    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b128 %2, %3 offset:%4\n\ts_mov_b64 exec, %0"
-                                                 : "=&s"(sv) : "s"(pub_exec), "v"(pub_addr), "v"(pv), "n"(4 * (j - 3)) : "memory");
-                                }
-                            }
                         }
-                        if constexpr (PIPED && FW_STAGEIN && sb == 1) fw_staged = true;
                         if (__builtin_amdgcn_ballot_w64(mx > WF_HI || mn < WF_LO || mc > WF_FMAX) != 0) return -1;  // carry untouched
                         cy.xa = __builtin_amdgcn_frexp_mantf(x);
                         cy.xe = R + __builtin_amdgcn_frexp_expf(x);
@@ -1559,7 +1537,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                             }
                         }
                         frame_pub = R;
-                        publish(PIPED && FW_PUBIN);
+                        publish();
                         return 1;
                     };
 
@@ -1688,6 +1666,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         if (blk_interior) norm_block(std::false_type{});
                         else norm_block(std::true_type{});
                     }
+
                     stamp(3);
                 };
                 one_block(std::integral_constant<int, 0>{});
@@ -2269,13 +2248,9 @@ __device__ __forceinline__ void sweep(const Params &p)
             stamp_chunk(t0 / WB, 5);
 
             if constexpr (FWD_SUB) {
-                fw_staged = false;
                 fwd_blocks(c, t0);
                 stamp_chunk(t0 / WB + 1, 4);
-                if (more && !fw_staged) write_block(bb_new);
-                // (FW_PRE) the first block of the next chunk finds its inputs in register set 0: read behind the staging writes -- its
-                // rows' ring positions take part of block set c + 2 -- and under the 16 loads at the top of the next chunk
-                if constexpr (FW_PRE) read_inputs(t0 + K, fin0[0], fin1[0]);
+                if (more) write_block(bb_new);
                 stamp_chunk(t0 / WB + 1, 5);
                 return;
             }
@@ -2513,9 +2488,13 @@ SDP_KERNEL(sdp_bwd_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q, false, fals
 #elif defined(SDP_ONLY) && SDP_ONLY == 21
 SDP_KERNEL(sdp_bwd_pipe_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q)
 #elif defined(SDP_ONLY) && SDP_ONLY == 0
-SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, true)
+SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, true, false, false, false, true)
+#elif defined(SDP_ONLY) && SDP_ONLY == 37
+SDP_KERNEL(sdp_fwd_c_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, true)
+#elif defined(SDP_ONLY) && SDP_ONLY == 6
+SDP_KERNEL(sdp_fwd_lat_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT)
 #elif defined(SDP_ONLY) && SDP_ONLY == 9
-SDP_KERNEL(sdp_fwd_x_tp_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, true)
+SDP_KERNEL(sdp_fwd_x_tp_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, true, false, false, false, true)
 #elif defined(SDP_ONLY) && SDP_ONLY == 7
 SDP_KERNEL(sdp_bwd_x_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, true)
 #elif defined(SDP_ONLY) && SDP_ONLY == 3
@@ -2531,11 +2510,16 @@ SDP_KERNEL(sdp_adj_fwd_kernel, sdp::PASS_AFWD, SDP_K_AFWD, SDP_MAXW_AFWD)
 #define SDP_IN_GROUP(g) (SDP_GROUP < 0 || SDP_GROUP == (g))
 // template arguments after MAXW: QX (exact state / fused loss seed), LINES (throughput forward builds: line-aligned input blocks),
 // GEN (general pitch), PARTS (a pair over several workgroups), NOPIPE (packed backward sweep without the pipelined chunk)
+// (... NOCLEAN: the aligned throughput forward builds without the edge cleaning -- full strips, no per-pair lengths; their _c twins carry it)
 #if SDP_IN_GROUP(1)
-SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, true)
+SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, true, false, false, false, true)
 SDP_KERNEL(sdp_fwd_lat_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT)
 SDP_KERNEL(sdp_fwd_x_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, true)
-SDP_KERNEL(sdp_fwd_x_tp_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, true)
+SDP_KERNEL(sdp_fwd_x_tp_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, true, false, false, false, true)
+#endif
+#if SDP_IN_GROUP(8)
+SDP_KERNEL(sdp_fwd_c_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, true)
+SDP_KERNEL(sdp_fwd_x_tp_c_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, true)
 #endif
 #if SDP_IN_GROUP(2)
 // The packed backward sweep twice: with the chunk as ONE software pipeline (PIPE: deferred flush, stores inside the steps) for

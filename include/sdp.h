@@ -39,10 +39,15 @@
  *     Problems with N + M > 4096 always use the float2 form (the packed format's
  *     rounding error is carried along an alignment path like a random walk: measured
  *     <= 4e-5 of E at N = M = 2048 on soft and on steep scores, bound 1e-4),
- *     and so do THIN long problems -- min(N, M) < 32 with max(N, M) > 512, where
- *     those errors do not average out over many paths (2 x 2048, flat scores:
- *     1.0e-4 packed, 4.5e-6 exact): sdp_state_bytes accounts for both, and forward
- *     and backward apply the same rule, so callers need not care.
+ *     and so do THIN long problems -- fewer than 32 rows or columns with more than
+ *     512 of the other, where those errors do not average out over many paths
+ *     (2 x 2048, flat scores: 1.0e-4 packed, 4.5e-6 exact).  Round 6: that holds PER
+ *     PAIR when `lens` is given -- a thin long pair inside a fat padded batch is
+ *     swept by the float2 build in a second launch over the same buffers (its state
+ *     lives inside the pair's own record), every other pair by the packed build; padded
+ *     shapes with min(N, M) < 66 and max(N, M) > 512 use the float2 form as a whole.
+ *     sdp_state_bytes accounts for all of it, and forward and backward apply the
+ *     same rule, so callers need not care.
  *   - `lens` is NULL (reference semantics: every pair uses the full padded N x M)
  *     or a DEVICE pointer to B x 2 int32 (n_b, m_b): pair b is aligned over its
  *     top-left n_b x m_b block, terminal cell (n_b, m_b); E/Ed outside the block
@@ -69,7 +74,7 @@
 extern "C" {
 #endif
 
-#define SDP_VERSION 105 /* 0.1.4: + SDP_NO_ZERO_SKIP, SDP_NO_FILL */
+#define SDP_VERSION 106 /* 0.1.5: per-pair state format under `lens` (thin long pairs routed to the float2 build); 0.1.4: + SDP_NO_ZERO_SKIP, SDP_NO_FILL */
 
 #define SDP_NW 0
 #define SDP_SW 1
@@ -298,10 +303,11 @@ int sdp_plan(int pass, int B, int N, int M, int has_lens, int exact_state, int c
              int *waves, size_t *lds);
 
 /* ... and whether that launch would spread every pair over several workgroups (CUs): the number of 64-row strips per
- * workgroup, or 0 for one workgroup per pair.  Forward and backward sweeps do it where it was measured to pay: padded
- * batches with per-pair lengths that do not outnumber the CUs (the batch takes as long as its longest pair; forward sweep:
- * pairs of more than eight strips, backward sweep: more than four), and the backward sweep of a few equal pairs of more
- * than twelve strips; the boundary between two parts of a pair then crosses
+ * workgroup, or 0 for one workgroup per pair.  It is done where it was measured to pay (round 5's table, profiles/
+ * r05_parts_table.txt): the FORWARD sweep of padded batches with per-pair lengths that do not outnumber the CUs (the batch
+ * takes as long as its longest pair) from pairs of more than eight strips on -- the backward sweep with per-pair lengths keeps
+ * one workgroup per pair since round 5 --, and the backward sweep of a few EQUAL pairs (<= CUs / 4) of more than twelve strips;
+ * never the adjoint pair.  The boundary between two parts of a pair then crosses
  * CUs through 8-byte granules in the tail of the state buffer.  Results do not depend on it (bit-identical).  Such
  * launches wait for the previous one of their kind on the same device, whatever its stream (two of them sharing the chip
  * could starve each other's producers); during stream capture that ordering is the graph's / the caller's. */

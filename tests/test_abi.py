@@ -42,7 +42,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_limits(lib):
-    assert lib.sdp_version() == 105
+    assert lib.sdp_version() == 106
     assert lib.sdp_max_cols() == 2048  # reference GPU path: max_cols = 2048 (nw_cuda.py:11)
 
 
@@ -110,8 +110,11 @@ def _plan(lib, pass_, B, N, M, lens=0, exact=0, cus=256):
 def test_thin_long_problems_take_the_exact_state(lib):
     """Round 5: fewer than 32 rows (or columns) with more than 512 on the other axis -- the packed weights' rounding does not
     average out over many paths there (2 x 2048: 1.0e-4) -- use the float2 state, like problems with N + M > 4096; the sizing
-    function follows (sdp_api.hip: exact_for)."""
-    for (N, M, exact) in [(2, 1772, True), (1772, 2, True), (31, 513, True), (32, 2048, False), (31, 512, False), (64, 960, False), (7, 1361, True),
+    function follows (sdp_api.hip: exact_for).  Round 6: thin long PAIRS of a batch with per-pair lengths are routed to the float2
+    build inside their own packed record, which needs more than 64 rows and more than 65 columns of padded shape to fit -- padded
+    shapes with min(N, M) < 66 (and max > 512) therefore take the float2 state as a whole."""
+    for (N, M, exact) in [(2, 1772, True), (1772, 2, True), (31, 513, True), (32, 2048, True), (65, 2048, True), (66, 2048, False), (2048, 65, True), (2048, 66, False),
+                          (31, 512, False), (64, 512, False), (64, 960, True), (7, 1361, True),
                           (2048, 2048, False), (2049, 2048, True), (512, 512, False)]:
         assert (lib.sdp_state_bytes(3, N, M) == lib.sdp_state_d_bytes(3, N, M)) == exact, (N, M)
 

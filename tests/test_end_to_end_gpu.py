@@ -131,14 +131,15 @@ def test_fused_decode_loss_when_the_loss_reads_beyond_the_dp_blocks(name):
     xl, yl = big[:, 0].tolist(), big[:, 1].tolist()
     dec = NeedlemanWunschDecoder("softmax")
     t1 = torch.from_numpy(theta).to(dev).requires_grad_()
-    l1 = loss_fn(first, dec.decode(t1, torch.from_numpy(A).to(dev), lens.tolist()), xl, yl, G)
+    a1 = torch.from_numpy(A).to(dev).requires_grad_()   # (decode differentiates w.r.t. both, like the reference)
+    l1 = loss_fn(first, dec.decode(t1, a1, lens.tolist()), xl, yl, G)
     l1.backward()
     # poison the allocator's free blocks: whatever the fused op leaves unwritten is then NaN, not a lucky zero
     for _ in range(3):
         junk = torch.full((B, N, M), float("nan"), device=dev)
         del junk
     t2 = torch.from_numpy(theta).to(dev).requires_grad_()
-    l2, E = decode_loss(dec, loss_fn, t2, torch.from_numpy(A).to(dev), first, xl, yl, G, lengths=lens.tolist())
+    l2, E = decode_loss(dec, loss_fn, t2, torch.from_numpy(A).to(dev).requires_grad_(), first, xl, yl, G, lengths=lens.tolist())
     l2.backward()
     torch.cuda.synchronize()
     assert torch.isfinite(l2) and torch.isfinite(E).all()

@@ -383,3 +383,85 @@ def test_the_two_builds_of_the_packed_backward_sweep_agree_bit_for_bit():
         assert torch.equal(vt1.view(torch.int32), vt2.view(torch.int32)), ci
         assert torch.equal(E1.view(torch.int32), E2.view(torch.int32)), (ci, int((E1.view(torch.int32) != E2.view(torch.int32)).sum()))
         assert bool(torch.isfinite(E1).all())
+
+
+@pytest.mark.parametrize("case", [(3, 150, 200, True, 0), (3, 150, 200, True, 0x100), (80, 192, 256, True, 0), (80, 130, 250, False, 0), (2, 100, 331, False, 0),
+                                  (80, 192, 256, True, 0x100)],
+                         ids=["lat-lens", "lat-lens-exact", "tp-lens", "tp-gen-partial", "lat-partial", "tp-lens-exact"])
+def test_what_lies_beside_the_matrix_takes_no_part_in_anything(case):
+    """VERDICT r5 2c.  The forward sweep's windowed form tests the range of EVERY lane's inputs and values, also of lanes whose
+    cell lies outside the matrix -- and until round 6 those lanes computed from whatever the loaded groups brought along: up to
+    three floats of the neighbouring row or pair, the padding of a batch with per-pair lengths, the rows below a partial strip,
+    the memory in front of and behind the tensor.  Results never depended on it, but WHICH FORM a block ran in did (timing, and
+    the last bits of the packed state), which is how round 5's wrong-result bug hid behind a plane offset of three floats.
+    Here everything beside the matrices is poisoned (NaN, +-inf, +-1e30) in one run and zero in the other, at every plane offset:
+    Vt and E must be equal as bit patterns AND every traced block must have run in the same form (experiments build: the form
+    codes of pair 0's first 40 blocks of every strip)."""
+    lib = _exp_lib()
+    lib.sdp_set_trace.restype, lib.sdp_set_trace.argtypes = ctypes.c_int, [ctypes.c_void_p]
+    B, N, M, use_lens, xflag = case
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(0).cuda_stream
+    rng = np.random.default_rng(6006 + N + M)
+    theta, A = datagen.theta_A(6100 + N, B, N, M)
+    theta = (theta * 3.0).astype(np.float32)   # (steeper than the benchmark's scores: some blocks near the window's edge)
+    lens = None
+    if use_lens:
+        lens = np.stack([rng.integers(1, N + 1, B), rng.integers(1, M + 1, B)], axis=1).astype(np.int32)
+        lens[0] = (N - 3, M - 5)            # the traced pair: ragged in both directions
+        lens[1 % B] = (N, M)
+    poison = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30], np.float32)
+    PAD = 4096
+    results = []
+    for variant in (0, 1):
+        per_variant = []
+        for offset in range(4):
+            runs = []
+            for dirty in (False, True):
+                bufs = []
+                for src in (theta, A):
+                    fill = poison[rng.integers(0, 5, src.size + 2 * PAD)] if dirty else np.zeros(src.size + 2 * PAD, np.float32)
+                    buf = torch.from_numpy(fill.astype(np.float32)).to(dev)
+                    view = buf[PAD + offset:PAD + offset + src.size].view(B, N, M)
+                    x = src.copy()
+                    if lens is not None:   # the padding of every pair as well
+                        for b in range(B):
+                            pad = poison[rng.integers(0, 5, (N, M))] if dirty else np.zeros((N, M), np.float32)
+                            x[b, lens[b, 0]:, :] = pad[lens[b, 0]:, :]
+                            x[b, :, lens[b, 1]:] = pad[:, lens[b, 1]:]
+                    view.copy_(torch.from_numpy(x))
+                    bufs.append((buf, view))
+                t, a = bufs[0][1], bufs[1][1]
+                ln = None if lens is None else torch.from_numpy(lens).to(dev)
+                lp = None if ln is None else ln.data_ptr()
+                nb = max(lib.sdp_state_bytes(B, N, M), lib.sdp_state_d_bytes(B, N, M))
+                st = torch.zeros(nb // 4 + 64, device=dev)
+                vt = torch.empty(B, device=dev)
+                E = torch.full((B, N, M), 7.0, device=dev)
+                et = torch.ones(B, device=dev)
+                trace = torch.zeros(4 * 4 * 4 * 40 * 8, dtype=torch.int64, device=dev)
+                lib.sdp_set_trace(trace.data_ptr())
+                try:
+                    assert lib.sdp_forward_f32(t.data_ptr(), a.data_ptr(), st.data_ptr(), vt.data_ptr(), B, N, M, lp, variant | xflag, 0, stream) == 0
+                    torch.cuda.synchronize()
+                finally:
+                    lib.sdp_set_trace(None)
+                assert lib.sdp_backward_f32(et.data_ptr(), st.data_ptr(), E.data_ptr(), B, N, M, lp, variant | xflag, 0, stream) == 0
+                torch.cuda.synchronize()
+                forms = trace.cpu().numpy().reshape(4, 4, 4, 40, 8)[0, :, :, :, 6].copy()   # pair 0: [wave][strip round][block]
+                runs.append((vt.cpu().numpy().view(np.uint32), E.cpu().numpy().view(np.uint32), forms))
+            clean, dirty_run = runs
+            assert np.array_equal(clean[0], dirty_run[0]), (variant, offset, "Vt")
+            assert np.array_equal(clean[1], dirty_run[1]), (variant, offset, "E", int((clean[1] != dirty_run[1]).sum()))
+            assert (clean[2] > 0).sum() >= 4, "no traced blocks: the trace did not see pair 0"
+            assert np.array_equal(clean[2], dirty_run[2]), (variant, offset, "forms", np.argwhere(clean[2] != dirty_run[2])[:5].tolist())
+            per_variant.append(clean)
+        # ... and the plane offset itself changes nothing either (the same problem at four alignments)
+        for k in range(1, 4):
+            assert np.array_equal(per_variant[0][0], per_variant[k][0]) and np.array_equal(per_variant[0][1], per_variant[k][1]), (variant, k)
+            assert np.array_equal(per_variant[0][2], per_variant[k][2]), (variant, k, "forms by offset")
+        results.append(per_variant[0])
+    # against the oracle once (NW), so that "equal" is not "equally wrong"
+    ref = (parity.oracle_lens(theta, A, None, None, 0, lens) if lens is not None else parity.oracle_all(theta, A, None, None, 0))
+    assert parity.rel_err(results[0][0].view(np.float32), ref["Vt"]) <= parity.TOL
+    assert parity.abs_err(results[0][1].view(np.float32), ref["E"]) <= parity.TOL

@@ -187,3 +187,36 @@ def test_no_time_slicing_of_strips_beats_run_to_completion():
     # (the simulator runs whole 16-step blocks: its run-to-completion figure is the formula's rounded up to blocks)
     assert min(res.values()) == res[("lowest strip first (= run to completion)", "w, w+W")] >= 1387
     assert min(res.values()) <= 1387 + 16
+
+
+def test_strip_roll_over_pays_the_ramp_once_per_wave():
+    """VERDICT r5 item 4.  The "ramp bound" T >= S L / W + (W - 1) lag takes a strip for a chain of L = M + 63 steps: every strip
+    pays its own 63-step ramp.  A wave whose lanes ROLL from strip w into strip w + W (lane l changes rows the step after it has
+    finished its row; lane l - 1 changed one step earlier, so the DPP chain stays valid) runs one chain of R M + 63 steps for
+    its R strips: 2 x 512 + 63 + 3 x 79 = 1324 steps against 1387 at the headline shape (-4.5 %), 1372 against 1435 in the
+    backward sweep, and the skew padding of the state falls from 1.123 to 1.0615.  tools/ramp_bound.py simulates the schedule
+    step by step (the hand-off between strips with its lag; a wave's own lanes need nothing from outside); it stalls only
+    when M < W lag -- wave 0's second strip then runs into wave W - 1's first."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import ramp_bound as rb
+    assert rb.roll_over(8, 512, 79, 4) == (1324, 1087)
+    assert rb.roll_over(8, 512, 95, 4) == (1372, 1087)
+    for S, M, W, lag in ((8, 512, 4, 79), (16, 1024, 4, 79), (16, 1024, 4, 95), (8, 512, 2, 79), (12, 400, 4, 95), (6, 512, 4, 79), (9, 640, 4, 79)):
+        R = -(-S // W)
+        steps, rows = rb.roll_over(S, M, lag, W)
+        assert M >= W * lag
+        # every wave with R strips ends at R M + 63 + w lag; the last strip belongs to wave (S - 1) % W
+        last = (S - 1) % W
+        assert steps == len(range(last, S, W)) * M + 63 + last * lag or steps == R * M + 63 + ((S - 1 - (R - 1) * W)) * lag, (S, M, W, lag, steps)
+        assert rows == R * M + 63
+        assert steps < rb.run_to_completion(S, M + 63, lag, W)
+    # short rows: M < W lag is not a stall but a DEADLOCK -- wave 0 cannot take the first step of its second strip before wave
+    # W - 1 has published column 0 of its first one (virtual step `lag` of a wave that runs (W - 1) lag behind), and a wave that
+    # waits waits with all its lanes, also those still inside the previous strip, whose last columns wave 1 is waiting for, and
+    # so on around the ring.  A build with roll-over therefore needs M >= W lag (the host would have to choose per launch).
+    import pytest
+    with pytest.raises(RuntimeError):
+        rb.roll_over(8, 256, 79, 4)
+    assert rb.roll_over(8, 316, 79, 4)[0] == 2 * 316 + 63 + 3 * 79

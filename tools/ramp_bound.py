@@ -103,6 +103,46 @@ def best_found(S, L, lag, W, blk=16):
     return out
 
 
+def roll_over(S, M, lag, W):
+    """Strip roll-over: the bound above assumes that every strip pays its own 63-step ramp -- a strip is a
+    chain of L = M + 63 steps.  It need not: the lanes of a wave can ROLL from strip w straight into strip w + W -- lane l moves to
+    row 64 (w + W) + l the step after it has finished row 64 w + l; the DPP chain stays valid because lane l - 1 moved one step
+    earlier -- so a wave runs ONE chain of R M + 63 "virtual" steps for its R strips, virtual step t of lane l being column
+    (t - l) mod M of its strip (t - l) div M.  Simulated here step by step: wave w may execute virtual step t only when the strip
+    above the one its lane 0 is in has executed its own step for that column plus `lag` (lane 63 meets a column 63 steps after lane
+    0, plus the publishing granule); everything else is inside the wave.  -> (steps until the pair is done, state rows per wave).
+
+    Closed form when nothing stalls: R M + 63 + (W - 1) lag.  Wave 0's second strip takes its boundary from wave W - 1's first,
+    which runs (W - 1) lag behind wave 0: fine iff M >= W lag (512 >= 316 forward, 380 backward).  Below that the schedule does
+    not merely stall, it DEADLOCKS (RuntimeError here): a wave that waits for its lane 0 waits with all its lanes, also those
+    still inside the previous strip, whose last columns the next wave is waiting for -- around the ring of W waves."""
+    R = [len(range(w, S, W)) for w in range(W)]            # strips per wave
+    total = [r * M + 63 if r else 0 for r in R]             # virtual steps per wave
+    done = [0] * W                                          # virtual steps executed
+    t = 0
+    while any(done[w] < total[w] for w in range(W)):
+        nxt = list(done)
+        for w in range(W):
+            v = done[w]
+            if v >= total[w]:
+                continue
+            k, c = divmod(v, M)                             # lane 0 is at column c of the wave's k-th strip (or past its last one)
+            ok = True
+            if k < R[w]:
+                s = w + k * W
+                if s > 0:
+                    pw, pk = (s - 1) % W, (s - 1) // W      # the strip above: wave pw, its pk-th strip
+                    need = min(pk * M + min(c + lag, M + 63), total[pw])  # virtual step of that wave by which column c is published (its last columns: when it is through)
+                    ok = done[pw] >= need
+            if ok:
+                nxt[w] = v + 1
+        done = nxt
+        t += 1
+        if t > 100 * (S * (M + 63)):
+            raise RuntimeError("schedule does not progress")
+    return t, max(total)
+
+
 def main():
     S, M, W = 8, 512, 4
     L = M + 63
@@ -114,6 +154,9 @@ def main():
         best = min(res.values())
         print(f"   block-granular time-slicing, {len(res)} policy x assignment combinations: best {best:.0f} steps "
               f"({min(res, key=res.get)}), worst {max(res.values()):.0f}")
+        ro, rows = roll_over(S, M, lag, W)
+        print(f"   strip roll-over (one ramp per WAVE, not per strip): {ro} steps ({100.0 * (ro - rtc) / rtc:+.1f} %), state rows per wave {rows} "
+              f"instead of {S // W * L} (skew padding {rows / (S // W * M):.4f} instead of {L / M:.4f})")
     return 0
 
 

@@ -1,3 +1,3 @@
-mkdir -p gpurun_out/v4
+mkdir -p gpurun_out/v10
 export TMPDIR=/tmp
-hipcc --offload-arch=gfx950 -O3 -o /tmp/vmemissue tools/ubench/vmemissue.hip 2> /dev/null && timeout 300 /tmp/vmemissue 2>&1 | tee gpurun_out/v4/vmemissue.txt
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -15 | tee gpurun_out/v10/pytest.txt
