@@ -107,6 +107,8 @@ Variant variant(int id)
     // [0] / [9] with the cleaning of what lies beside the matrix (per-pair lengths, partial strips; sdp_kernels.hip "need_clean")
     case 37: return {(const void *)sdp_fwd_c_kernel, SDP_K_FWD, SDP_MAXW_FWD, 37};
     case 38: return {(const void *)sdp_fwd_x_tp_c_kernel, SDP_K_FWD, SDP_MAXW_FWD, 38};
+    case 39: return {(const void *)sdp_fwd_lat_c_kernel, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, 39};   // [6] ...
+    case 40: return {(const void *)sdp_fwd_x_c_kernel, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, 40};     // [5] ...
     default: return {(const void *)sdp_bwd_lat_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 4};
     }
 }
@@ -206,8 +208,14 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
     if (pass == sdp::PASS_BWD && exact_state) v = variant(v.id == 1 ? 7 : 8);
     const int nin = (pass == sdp::PASS_AFWD && fused_seed) ? 3 : 0;   // three staged planes (ref, pred, G)
     if (nin) v = variant(10);
-    // the aligned throughput forward builds: without any edge cleaning where nothing foreign can be met (full strips, no lengths)
-    if (pass == sdp::PASS_FWD && (has_lens || (N & 63) != 0) && (v.id == 0 || v.id == 9)) v = variant(v.id == 0 ? 37 : 38);
+    // the aligned-pitch forward builds come without any edge cleaning (sdp_kernels.hip "need_clean"); per-pair lengths or partial
+    // strips take their twins that carry it
+    if (pass == sdp::PASS_FWD && (has_lens || (N & 63) != 0)) {
+        if (v.id == 0) v = variant(37);
+        else if (v.id == 9) v = variant(38);
+        else if (v.id == 6) v = variant(39);
+        else if (v.id == 5) v = variant(40);
+    }
     if (general_pitch) v = variant(general_id(v.id));
     // The packed backward sweep's pipelined twin (sdp_kernels.hip, sdp_bwd_pipe_kernel) trades instruction issue for memory
     // latency.  Steady-state A/B over 24 shapes (tools/steady.py, +- 0.3 us; profiles/r05_steady_pipe.txt): it pays 2.3 % where
@@ -386,7 +394,7 @@ VariantBits split_variant(int variant)
 // 160 KiB the hardware has, so concurrent callers cannot disagree
 int raise_lds_limit(const Variant &v, int device)
 {
-    static thread_local unsigned long long lds_raised[39] = {0};  // per kernel id: bit d = done on device d
+    static thread_local unsigned long long lds_raised[41] = {0};  // per kernel id: bit d = done on device d
     if (device >= 64 || !(lds_raised[v.id] >> device & 1ull)) {
         hipError_t e = hipFuncSetAttribute(v.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -605,7 +613,7 @@ int sdp_init(int device)
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
     if (device >= 0 && device < MAX_DEV && !status_words(device)) return fail(SDP_E_SELFTEST, "sdp_init: could not create the host-pinned status words");
-    for (int id = 0; id <= 38; ++id) {   // (21-28: the parts instantiations, 36: the pipelined backward twin, 37 / 38: the cleaning forward twins)
+    for (int id = 0; id <= 40; ++id) {   // (21-28: the parts instantiations, 36: the pipelined backward twin, 37-40: the cleaning forward twins)
         const Variant v = variant(id);
         if (v.id != id) continue;   // ids without a build of their own map to the default
         if (int rc = raise_lds_limit(v, device)) return rc;

@@ -169,6 +169,8 @@ __global__ void sdp_fwd_x_kernel(const sdp::Params p);
 __global__ void sdp_fwd_x_tp_kernel(const sdp::Params p);
 __global__ void sdp_fwd_c_kernel(const sdp::Params p);
 __global__ void sdp_fwd_x_tp_c_kernel(const sdp::Params p);
+__global__ void sdp_fwd_lat_c_kernel(const sdp::Params p);
+__global__ void sdp_fwd_x_c_kernel(const sdp::Params p);
 __global__ void sdp_bwd_kernel(const sdp::Params p);
 __global__ void sdp_bwd_pipe_kernel(const sdp::Params p);
 __global__ void sdp_bwd_lat_kernel(const sdp::Params p);

@@ -389,7 +389,7 @@ __device__ __forceinline__ void sweep(const Params &p)
     constexpr bool REV = T::REV;
     constexpr int KIND = Kind<PASS>::value;
     constexpr bool CLEAN = PASS == PASS_FWD && !NOCLEAN;   // forward sweep: what lies beside the matrix takes no part in anything (see need_clean)
-    static_assert(!NOCLEAN || (LINES && !GEN && !PARTS), "only the aligned throughput builds have a twin without the cleaning");
+    static_assert(!NOCLEAN || (!GEN && !PARTS), "only the aligned-pitch one-workgroup-per-pair builds have a twin without the cleaning");
     constexpr int RPI = 64 / K;    // tensor rows covered by one staged (dword) store instruction
     constexpr int PITCH = 2 * K;   // LDS pitch of a staged input plane: a ring of two K-column blocks per row
     constexpr int RING = 2 * K;
@@ -939,7 +939,7 @@ __device__ __forceinline__ void sweep(const Params &p)
         // (blocks moved left by up to K-1 columns: one block set later)
         // (the latency builds' groups start at columns K j - (r mod 4): block set QMAX still holds groups that straddle column 0 of
         //  the rows with q = QMAX -- up to three floats of the row above -- so there, too, plain begins one block set later)
-        auto block_plain = [&](int bb) { return rows == 64 && bb >= QMAX + ((li_unaligned || (CLEAN && !LINES)) ? 1 : 0) && (bb + 1) * K <= m; };
+        auto block_plain = [&](int bb) { return rows == 64 && bb >= QMAX + ((li_unaligned || (CLEAN && !LINES && p.lens != nullptr)) ? 1 : 0) && (bb + 1) * K <= m; };
         // Forward sweep: what lies BESIDE the matrix must not take part in anything (round 6).  A loaded group of four columns may
         // straddle column 0 or column m -- up to three floats of the neighbouring row, of the neighbouring pair, of the padding of a
         // batch with per-pair lengths, or of whatever follows the tensor in memory -- and the rows below a partial strip are rows of
@@ -955,16 +955,18 @@ __device__ __forceinline__ void sweep(const Params &p)
         // What it costs, and who pays (steady state, same box, main vs the same build without any of this: forward sweep of
         // 256 x 512^2 169.6 vs 166.2 us although nothing was cleaned there -- the mere presence of the code costs registers in the
         // ramp chunks, which are a pair's critical path; 64 x 512^2 on the latency build, cleaning every edge block set: 143.9 vs
-        // 135.2).  So: CLEAN is a property of the BUILD.  The aligned throughput builds exist twice -- without a trace of it
-        // (NOCLEAN: sdp_fwd_kernel, sdp_fwd_x_tp_kernel: full strips, no lengths, aligned pitch -- every loaded group lies wholly inside
-        // or wholly outside its row, and those outside are never fetched) and with it (sdp_fwd_c_kernel, sdp_fwd_x_tp_c_kernel: per-pair
-        // lengths or N not a multiple of 64; sdp_api.hip picks).  The general-pitch, latency and parts builds always carry it, and
-        // apply it where something foreign can be met: lengths, partial strips, and -- their groups straddle every row's ends --
-        // the strips that hold the plane's first and last row (the rows in between straddle into their own plane's neighbouring
-        // rows: data of the same problem, the same on every run).  Nothing of it is kept in registers across the chunk loop.
+        // 135.2, and still 140.0 with the code present but never executed).  So: CLEAN is a property of the BUILD.  The aligned-pitch
+        // builds exist twice -- without a trace of it (NOCLEAN: sdp_fwd_kernel, sdp_fwd_x_tp_kernel, sdp_fwd_lat_kernel, sdp_fwd_x_kernel:
+        // full strips, no lengths) and with it (their _c twins: per-pair lengths or N not a multiple of 64; sdp_api.hip picks).  The
+        // general-pitch and parts builds always carry it, and apply it where something foreign can be met: per-pair lengths and
+        // partial strips.  (The groups of the general-pitch and latency builds straddle the ends of
+        // every row, but into the pair's OWN plane -- the neighbouring rows of the same problem, the same on every run and in every
+        // batch: the plane's first row starts a group exactly, r mod 4 = 0, and what follows its last row is past the buffer
+        // descriptor's range and reads as zero.  Cleaning the first and last strip as well cost the latency build 3.8 % at
+        // 64 x 512^2 -- those strips' ramps are the pair's critical path -- for nothing.)  No flag of it lives across the chunk loop.
         auto need_clean = [&]() {
             if constexpr (!CLEAN) return false;
-            else return rows < 64 || p.lens != nullptr || ((GEN || !LINES) && (s == 0 || s == nstrips - 1));
+            else return rows < 64 || p.lens != nullptr;
         };
         auto load_block_i = [&](int bb, auto plain_tag, int i, auto rset_tag) {  // instruction i of block set bb -> registers (set RS)
             constexpr bool plain = decltype(plain_tag)::value;
@@ -2492,7 +2494,7 @@ SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, true, 
 #elif defined(SDP_ONLY) && SDP_ONLY == 37
 SDP_KERNEL(sdp_fwd_c_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, true)
 #elif defined(SDP_ONLY) && SDP_ONLY == 6
-SDP_KERNEL(sdp_fwd_lat_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT)
+SDP_KERNEL(sdp_fwd_lat_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, false, false, false, false, false, true)
 #elif defined(SDP_ONLY) && SDP_ONLY == 9
 SDP_KERNEL(sdp_fwd_x_tp_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, true, false, false, false, true)
 #elif defined(SDP_ONLY) && SDP_ONLY == 7
@@ -2513,13 +2515,15 @@ SDP_KERNEL(sdp_adj_fwd_kernel, sdp::PASS_AFWD, SDP_K_AFWD, SDP_MAXW_AFWD)
 // (... NOCLEAN: the aligned throughput forward builds without the edge cleaning -- full strips, no per-pair lengths; their _c twins carry it)
 #if SDP_IN_GROUP(1)
 SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, true, false, false, false, true)
-SDP_KERNEL(sdp_fwd_lat_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT)
-SDP_KERNEL(sdp_fwd_x_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, true)
+SDP_KERNEL(sdp_fwd_lat_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, false, false, false, false, false, true)
+SDP_KERNEL(sdp_fwd_x_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, true, false, false, false, false, true)
 SDP_KERNEL(sdp_fwd_x_tp_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, true, false, false, false, true)
 #endif
 #if SDP_IN_GROUP(8)
 SDP_KERNEL(sdp_fwd_c_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, true)
 SDP_KERNEL(sdp_fwd_x_tp_c_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, true)
+SDP_KERNEL(sdp_fwd_lat_c_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT)
+SDP_KERNEL(sdp_fwd_x_c_kernel, sdp::PASS_FWD, SDP_K_FWD_LAT, SDP_MAXW_FWD_LAT, true)
 #endif
 #if SDP_IN_GROUP(2)
 // The packed backward sweep twice: with the chunk as ONE software pipeline (PIPE: deferred flush, stores inside the steps) for
