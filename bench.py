@@ -466,7 +466,15 @@ def main():
                              # all sweeps of one step over the step's wall time: 12 + 12 B per cell for fwd + bwd, + 32 + 32 for the
                              # adjoint pair of the training modes
                              "whole_step_algorithmic_bytes": step_algo_bytes,
-                             "whole_step_frac": (step_algo_bytes * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9)},
+                             "whole_step_frac": (step_algo_bytes * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9),
+                             # ... and the same on the bytes the sweeps really moved (the counter passes' figures, when they belong to
+                             # these sources): the figure that says how close the step is to the memory system
+                             "whole_step_traffic": (sum(k_["traffic"] for k_ in per_kernel.values()) if per_kernel and all(k_["traffic"] for k_ in per_kernel.values()) else None),
+                             "whole_step_real_frac": ((sum(k_["traffic"] for k_ in per_kernel.values()) * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9)
+                                                      if per_kernel and all(k_["traffic"] for k_ in per_kernel.values()) else None),
+                             # the chip's own ceilings for bare streams of 1 KB per wave-instruction, one wave per SIMD (tools/ubench/
+                             # vmemissue.hip, profiles/r06_ubench_vmemissue.txt): what "memory-bound" means on this part
+                             "measured_stream_ceilings_GBs": {"loads": 7000.0, "stores": 5400.0, "fwd_mix": 5050.0}},
             }
             if no_skip is not None:
                 line["no_skip"] = no_skip

@@ -1072,7 +1072,14 @@ __device__ __forceinline__ void sweep(const Params &p)
         };
         auto write_block_s = [&](int bb, auto rset_tag) {
             if constexpr (CLEAN) {
-                if (!block_plain(bb) && need_clean()) {
+                // ... and only block sets that can hold a group STRADDLING an end of its row: groups wholly outside were not fetched
+                // (zeros), groups wholly inside need nothing.  A set's groups of row r start at columns bb K - K q_r - delta_r (+ 4 cg):
+                // within (bb - 3) K .. bb K for the aligned build (whose groups start on multiples of four: no straddle at column 0,
+                // and none at m unless m mod 4 != 0), within (bb - 4) K .. bb K for the general-pitch builds, (bb - 5) K .. for the latency builds.
+                constexpr int BACK = !LINES ? 5 : (GEN ? 4 : 3);   // (latency builds: q_r up to 4 at K = 16, and their groups start up to 3 columns further left)
+                const bool edge_r = m > (bb - BACK) * K && m < (bb + 1) * K && (GEN || !LINES || (m & 3) != 0);
+                const bool edge_l = (GEN || !LINES) && bb < BACK;
+                if (!block_plain(bb) && need_clean() && (edge_l || edge_r)) {
                     write_block_c(bb, rset_tag, std::true_type{});
                     return;
                 }

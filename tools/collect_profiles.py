@@ -43,7 +43,8 @@ for name, pattern in (("kernel_stats.csv", "prof/**/*kernel_stats.csv"), ("train
                       ("scores_bwd_kernel_stats.csv", "prof_scores_bwd/**/*kernel_stats.csv"), ("scores_bwd.txt", "scores_bwd.txt"),
                       ("bench_scores.json", "bench_scores.json"), ("bench_traceback.json", "bench_traceback.json"),
                       ("configs.txt", "configs.txt"), ("parts_configs2.txt", "parts_configs2.txt"),
-                      ("ubench_mix.txt", "ubench_mix.txt"), ("ubench_mix2.txt", "ubench_mix2.txt"),
+                      ("ubench_mix.txt", "ubench_mix.txt"), ("ubench_mix2.txt", "ubench_mix2.txt"), ("ubench_vmemissue.txt", "ubench_vmemissue.txt"),
+                      ("steady.txt", "steady.txt"), ("fwd_timeline.txt", "fwd_timeline.txt"),
                       ("bwd_trace.txt", "bwd_trace.txt"), ("bwd_trace_alias7.txt", "bwd_trace_alias7.txt"), ("fwd_trace.txt", "fwd_trace.txt"),
                       ("fwd_trace_alias7.txt", "fwd_trace_alias7.txt"), ("zero_probe.txt", "zero_probe.txt"), ("bigB.txt", "bigB.txt"),
                       ("shapes.txt", "shapes.txt"),

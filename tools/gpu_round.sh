@@ -5,7 +5,7 @@
 # modes, FETCH_SIZE and WRITE_SIZE counter passes (separate runs, kernel-trace only -- gpurun refuses pmc + other
 # traces), and the source hash the numbers belong to.  Afterwards, in the build container:
 #   python tools/collect_profiles.py <tag>    -> profiles/<tag>_*.csv|json + profiles/traffic.json (stamped)
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/round_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -50,7 +50,10 @@ timeout 600 python bench.py --mode align+traceback --no-cpu-baseline 2>> $OUT/be
 timeout 300 python tools/gpu_configs.py 2> /dev/null | tee $OUT/configs.txt
 timeout 300 python tools/parts_probe.py 256 1022 1020 lens cfg3 2> /dev/null | grep "^parts" | tee $OUT/parts_configs2.txt
 # bare read / write / mixed streams of the forward sweep's size: what this box's memory system gives
-for u in mix mix2; do hipcc --offload-arch=gfx950 -O3 -o /tmp/$u tools/ubench/$u.hip 2> /dev/null && timeout 120 /tmp/$u 2>&1 | tee $OUT/ubench_$u.txt; done
+for u in mix mix2 vmemissue; do hipcc --offload-arch=gfx950 -O3 -o /tmp/$u tools/ubench/$u.hip 2> /dev/null && timeout 300 /tmp/$u 2>&1 | tee $OUT/ubench_$u.txt; done
+# the steady state of the two sweeps against the previous round's library (build_variants/libsdp_r05.so travels with the snapshot)
+timeout 600 python tools/steady.py 256x512x512 64x512x512 256x1024x1024 512x512x512 2>&1 | grep "B=" | tee $OUT/steady.txt
+TRACE_BLOCKS=1 TRACE_TIMELINE=1 timeout 300 python tools/fwd_trace.py > $OUT/fwd_timeline.txt 2>&1
 # cycle stamps inside the two sweeps (real memory and everything cache-served), the exact-zero skip switched off and on,
 # larger batches, other shapes
 timeout 300 python tools/bwd_trace.py > $OUT/bwd_trace.txt 2>&1

@@ -30,8 +30,7 @@ def plan_ids(B=256, N=512, M=512, cus=256):
     lib = _lib.load()
     names = {0: "sdp_fwd_kernel", 1: "sdp_bwd_kernel", 2: "sdp_adj_fwd_kernel", 3: "sdp_adj_bwd_kernel", 4: "sdp_bwd_lat_kernel",
              5: "sdp_fwd_x_kernel", 6: "sdp_fwd_lat_kernel", 7: "sdp_bwd_x_kernel", 8: "sdp_bwd_x_lat_kernel", 9: "sdp_fwd_x_tp_kernel",
-             29: "sdp_fwd18_kernel", 30: "sdp_fwd18_lat_kernel", 31: "sdp_fwd18_g_kernel", 32: "sdp_bwd18_kernel", 33: "sdp_bwd18_lat_kernel",
-             34: "sdp_bwd18_g_kernel", 35: "sdp_bwd18_lat_g_kernel"}
+             36: "sdp_bwd_pipe_kernel", 37: "sdp_fwd_c_kernel", 38: "sdp_fwd_x_tp_c_kernel", 39: "sdp_fwd_lat_c_kernel", 40: "sdp_fwd_x_c_kernel"}
     out = {}
     for label, pass_, exact in (("fwd", 0, 0), ("bwd", 1, 0), ("fwd_exact", 0, 1), ("bwd_exact", 1, 1), ("adj_fwd", 2, 0), ("adj_bwd", 3, 0)):
         kid, chunk, waves, lds = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
