@@ -1855,9 +1855,10 @@ __device__ __forceinline__ void sweep(const Params &p)
             using nxt_t = std::integral_constant<int, ROT ? 1 - P : P>;
             // experiments build, sdp_set_trace, backward sweep: per chunk (slot = position in processing order) cycle stamps
             // 0 top, 1 previous chunk's outputs flushed, 2 boundary values there, 3 steps done, 4 published
+            // (debug bit 1024: the backward sweep's; 8192 / 16384: the adjoint backward / forward sweep's, tools/adj_trace.py)
             auto stamp_rev = [&](int k) {
-                if constexpr (SDP_EXP_BUILD != 0 && PASS == PASS_BWD) {
-                    if (p.trace && (p.dbg & 1024) && (b & 63) == 0 && b < 256 && lane == 0 && (parts ? part < 4 : sidx / W < 2) && ci < 40)
+                if constexpr (SDP_EXP_BUILD != 0 && (PASS == PASS_BWD || PASS == PASS_ABWD || PASS == PASS_AFWD)) {
+                    if (p.trace && (p.dbg & (PASS == PASS_BWD ? 1024 : (PASS == PASS_ABWD ? 8192 : 16384))) && (b & 63) == 0 && b < 256 && lane == 0 && (parts ? part < 4 : sidx / W < 2) && ci < 40)
                         p.trace[((((b >> 6) * 4 + wave) * 4 + (parts ? part : sidx / W)) * 40 + ci) * 8 + k] = __builtin_readcyclecounter();
                 }
             };
@@ -2194,7 +2195,9 @@ __device__ __forceinline__ void sweep(const Params &p)
 #pragma unroll
                     for (int k = 0; k < K; ++k) hist[k] = 0, lo[k] = 0.f;
                     cy.a = cy.b = cy.c = 0.0;
+                    stamp_rev(2), stamp_rev(3);
                     publish_range();
+                    stamp_rev(4);
                     pf_t0 = t0, pf_par = par;
                     if (more) write_block_s(bb_new, ecur_t{});
                     return;
