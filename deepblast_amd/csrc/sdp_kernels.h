@@ -126,13 +126,15 @@ __host__ __device__ inline int xb_frame_base(int M) { return (M + 63 + 63) / 64 
 __host__ __device__ inline int xb_row_granules(int M) { return xb_frame_base(M) + (M + 63 + 63) / 64 * 4 + 4; }   // + one frame granule per 16-step block
 constexpr unsigned XB_INVALID = 0x7f7f7f7fu;   // tag (high word) of a granule that has not been written: the memset pattern
 
-// per-wave LDS staging (floats): input planes are rings [64][2K], the output ring is [64][2K+1]
-__host__ __device__ constexpr int stage_out_pitch(int K) { return 2 * K + 1; }
+// per-wave LDS staging (floats): input planes are rings [64][2K], the output ring is [64][2K+1] -- [64][65] in the adjoint backward
+// sweep, whose K = 16 builds flush 32-column blocks (sdp_kernels.hip, FLUSH2 / KF), behind a pad of four floats (one is written)
+__host__ __device__ constexpr int stage_out_pitch(int pass, int K) { return pass == PASS_ABWD ? 65 : 2 * K + 1; }
+__host__ __device__ constexpr int stage_out_pad(int pass) { return pass == PASS_ABWD ? 4 : 0; }
 __host__ __device__ constexpr int stage_floats(int pass, int K, int nin_override = 0)
 {
     const int nin = nin_override > 0 ? nin_override : ((pass == PASS_FWD || pass == PASS_AFWD) ? 2 : (pass == PASS_ABWD ? 1 : 0));
     const int nout = (pass == PASS_BWD || pass == PASS_ABWD) ? 1 : 0;
-    return nin * 64 * (2 * K) + nout * 64 * stage_out_pitch(K);
+    return nin * 64 * (2 * K) + nout * (64 * stage_out_pitch(pass, K) + stage_out_pad(pass));
 }
 
 // tail of both state buffers: room for the launch order of a variable-length batch (B ints, 256-byte granules)

@@ -398,7 +398,7 @@ __device__ __forceinline__ void sweep(const Params &p)
     constexpr int RPL = 64 / LPR;  // rows per load instruction,
     constexpr int NLD = K / 4;     // load instructions per plane and chunk
     constexpr int QMAX = (63 + K - 1) / K;  // largest ceil(r/K) over the 64 rows of a strip
-    constexpr int PO = stage_out_pitch(K);  // LDS pitch of the staged output ring: two chunks per row + 1
+    constexpr int PO = stage_out_pitch(PASS, K);  // LDS pitch of the staged output ring: two chunks per row + 1 (adjoint backward sweep: 64 steps + 1, see FLUSH2)
     constexpr int NSTAGE = T::SIN + T::SOUT;
     constexpr int NS = T::SIN > 0 ? T::SIN : 1;
     constexpr int PUB_LANE = REV ? 0 : 63;    // lane that produces this strip's boundary row
@@ -476,7 +476,7 @@ __device__ __forceinline__ void sweep(const Params &p)
     int *frm = reinterpret_cast<int *>(bnd + (size_t)nslot * p.mcap) + 16;
     float *stage = reinterpret_cast<float *>(smem + p.stage_off) + (size_t)wave * stage_floats(PASS, K, T::SIN);
     float *lds_in = stage;
-    float *lds_out = stage + T::SIN * PLANE;
+    float *lds_out = stage + T::SIN * PLANE + stage_out_pad(PASS);   // (the pad: FLUSH2 writes one float in front of a row, and row 0's would be the input ring's last)
 
     if (threadIdx.x <= (unsigned)W) lds_store_i32(prog + 4 * threadIdx.x, 0);   // (word W: imported boundaries)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the store above is inline asm: the compiler's own counter tracking does not see it
@@ -883,7 +883,13 @@ __device__ __forceinline__ void sweep(const Params &p)
         // only, a row pitch that is not a multiple of 32 floats made every 128-byte store straddle two lines: the
         // backward sweep ran 2.1-2.4x slower at M = 516 than at M = 512.)  fo_off0 is the LDS index when the current
         // chunk has parity 0, fo_dk the change when it has parity 1, fo_voff the global byte offset (row i0, t0 = 0).
-        constexpr bool FLUSH2 = T::SOUT > 0 && !GEN && K == 32;   // (see below)
+        constexpr bool FLUSH2 = T::SOUT > 0 && !GEN && (K == 32 || PASS == PASS_ABWD);   // (see below)
+        // KF: columns of a row that leave together.  The adjoint backward sweep (K = 16: its float64 rows a chunk ahead are 128
+        // registers) flushes 32-column blocks all the same -- whole 128-byte lines, every second chunk, out of a ring of 64 steps
+        // per row: round 6's stamps (tools/adj_trace.py) showed its 16 dword reads + 16 masked dword stores of 64-byte half
+        // lines per chunk, with three 16-entry index arrays held across the loop, as 2700-3700 of a chunk's 10 600 cycles.
+        constexpr int KF = FLUSH2 ? 32 : K;
+        static_assert(KF % K == 0 && PO >= 2 * KF + 1, "the output ring holds two flush blocks per row");
         int fo_off0[FLUSH2 ? 1 : K], fo_dk[FLUSH2 ? 1 : K];
         unsigned fo_voff[FLUSH2 ? 1 : K];
         bool fo_need_tail = false;
@@ -923,7 +929,7 @@ __device__ __forceinline__ void sweep(const Params &p)
         //   global float offset  = r ld - D_r + e_l   = [c ld - 32 (k2 >> 3)] + f2_g, f2_g = rl ld + e_l
         const int f2_rl = 8 * ((lane >> 4) >> 1) + 16 * ((lane >> 4) & 1), f2_el = 2 * (lane & 15);
         const int f2_l = f2_rl * PO + f2_rl + f2_el, f2_g = f2_rl * ld + f2_el;
-        const int f2_rl_c = f2_rl, f2_el_c = f2_el, f2_l_c = f2_l, f2_g_c = f2_g, r_l_c = r_l, s_l_c = s_l;   // (for the opaque copies in flush_out's rare paths)
+        const int f2_rl_c = f2_rl, f2_el_c = f2_el, f2_l_c = f2_l, f2_g_c = f2_g, r_l_c = lane / KF, s_l_c = lane % KF;   // (for the opaque copies in flush_out's rare paths)
         // Plain flushes of the builds without the pipelined chunk: four columns per lane and store (the same 16 aligned 8-byte LDS reads, but 8 dwordx4 stores instead of 16 dwordx2).  Instruction k4 (0..7), lane -> row r = c + rl, c = 4 (k4 & 3) + 32 (k4 >> 2),
         //   rl = (a & 1) + 16 ((a >> 1) & 1) + 2 (a >> 2), a = lane >> 3 -- the four rows of a 32-lane LDS group are r, r + 1 (bank bases two
         //   floats apart: their 8-byte reads at columns 4 g interleave) and r + 16, r + 17 (32 banks further); columns e_l .. e_l + 3, e_l = 4 (lane & 7)
@@ -1705,7 +1711,8 @@ __device__ __forceinline__ void sweep(const Params &p)
         // The wait for the state rows (requested an iteration ago) sits at the top of the iteration and counts the stores a
         // pipelined chunk issued behind that request (tail_st).
         constexpr bool PIPE = FLUSH2 && LAZY && !NOPIPE;   // (NOPIPE: the twin build for short pairs, see sdp_bwd_kernel below)
-        static_assert(!FLUSH2 || T::SIN == 0 || K <= 16, "FLUSH2 writes one float in front of lds_out: there must be no staged input plane before it");
+        static_assert(!FLUSH2 || T::SIN == 0 || stage_out_pad(PASS) > 0, "FLUSH2 writes one float in front of lds_out: a staged input plane before it needs the pad");
+        static_assert(!PIPE || KF == K, "the pipelined flush moves a chunk's own block");
         // the plain flush in two halves: LDS -> registers, registers -> memory (all 64 x 32 elements are real cells)
         auto flush_read = [&](int par, bool zero, float2 *vals) {
             const int thr_l = K - 1 - f2_rl - f2_el;   // (k2 & 7) < thr_l  <=>  sfull < K - 1
@@ -1748,22 +1755,22 @@ __device__ __forceinline__ void sweep(const Params &p)
                     // all 64 x 32 elements are real cells (rows of a full strip, columns t0 - 32 .. t0 + 31 inside the matrix): no
                     // per-lane tests, the global offset is one per-lane base plus a scalar, the LDS index one per-lane base plus a
                     // constant -- no vector arithmetic at all when the chunk has parity 0, a compare-and-select per row class when 1
-                    const bool flush_plain = active && rows == 64 && t0 >= K && t0 + K <= m;
+                    const bool flush_plain = active && rows == 64 && t0 >= KF && t0 + KF <= m;
                     if (flush_plain && !PIPE) {   // (PIPE: plain flushes are deferred -- flush_read / flush_store1 -- and never get here)
                         if (zero) flush_zero8(t0);
                         else {
-                            float2 vals[K / 2];
+                            float2 vals[KF / 2];
 #pragma unroll
-                            for (int k4 = 0; k4 < K / 4; ++k4)
+                            for (int k4 = 0; k4 < KF / 4; ++k4)
 #pragma unroll
                                 for (int j = 0; j < 2; ++j) {
                                     const int cc = 4 * (k4 & 3) + 32 * (k4 >> 2);
                                     const int sfull = 4 * (k4 & 3) + f4_s + 2 * j;
-                                    const int idx = cc * PO + 4 * (k4 & 3) + f4_l + 2 * j + (par ? (sfull < K - 1 ? K : -K) : 0);
+                                    const int idx = cc * PO + 4 * (k4 & 3) + f4_l + 2 * j + (par ? (sfull < KF - 1 ? KF : -KF) : 0);
                                     vals[2 * k4 + j] = *reinterpret_cast<const float2 *>(__builtin_assume_aligned(lds_out + idx, 8));
                                 }
 #pragma unroll
-                            for (int k4 = 0; k4 < K / 4; ++k4) {
+                            for (int k4 = 0; k4 < KF / 4; ++k4) {
                                 typedef unsigned u32x4f __attribute__((ext_vector_type(4)));
                                 const int cc = 4 * (k4 & 3) + 32 * (k4 >> 2);
                                 const float2 v0 = vals[2 * k4], v1 = vals[2 * k4 + 1];
@@ -1774,21 +1781,21 @@ __device__ __forceinline__ void sweep(const Params &p)
                         }
                         if constexpr (LAZY && !PIPE) __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8): everything older than these K / 4 stores
                     } else if ((m & 1) == 0) {   // (uniform)
-                        float2 vals[K / 2];
+                        float2 vals[KF / 2];
                         // (the per-lane constants pass through an opaque copy: the compiler otherwise hoists the 16 + 32 index /
                         //  offset calculations of these two rare paths out of the chunk loop into the strip's set-up -- ~250
                         //  instructions per strip and ~100 registers held across the whole sweep, round 5 ISA)
                         int f2_rl = f2_rl_c, f2_el = f2_el_c, f2_l = f2_l_c, f2_g = f2_g_c;
                         asm volatile("" : "+v"(f2_rl), "+v"(f2_el), "+v"(f2_l), "+v"(f2_g));
 #pragma unroll
-                        for (int k2 = 0; k2 < K / 2; ++k2) {
+                        for (int k2 = 0; k2 < KF / 2; ++k2) {
                             const int sfull = (k2 & 7) + f2_rl + f2_el;
-                            const int d1 = sfull < K - 1 ? K : -K;   // parity 1: the other half of the ring (sfull = K - 1: position -1)
+                            const int d1 = sfull < KF - 1 ? KF : -KF;   // parity 1: the other half of the ring (sfull = K - 1: position -1)
                             const int idx = ((k2 & 7) + 32 * (k2 >> 3)) * PO + (k2 & 7) + f2_l + (par ? d1 : 0);
                             vals[k2] = *reinterpret_cast<const float2 *>(__builtin_assume_aligned(lds_out + idx, 8));
                         }
 #pragma unroll
-                        for (int k2 = 0; k2 < K / 2; ++k2) {
+                        for (int k2 = 0; k2 < KF / 2; ++k2) {
                             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                             const int c_r = (k2 & 7) + 32 * (k2 >> 3);
                             const int row = c_r + f2_rl;
@@ -1803,9 +1810,9 @@ __device__ __forceinline__ void sweep(const Params &p)
                         int r_l = r_l_c, s_l = s_l_c;
                         asm volatile("" : "+v"(r_l), "+v"(s_l));
 #pragma unroll
-                        for (int k = 0; k < K; ++k) {
-                            const int row = k * RPI + r_l, rho = row & (K - 1), sfull = rho + s_l;
-                            const int idx = row * PO + sfull + (par ? (sfull >= K ? -K : K) : 0);
+                        for (int k = 0; k < KF; ++k) {
+                            const int row = k * (64 / KF) + r_l, rho = row & (KF - 1), sfull = rho + s_l;
+                            const int idx = row * PO + sfull + (par ? (sfull >= KF ? -KF : KF) : 0);
                             const float v = lds_out[idx];
                             const int col = t0 - (row - rho) + s_l;
                             const bool ok = active && (unsigned)col < (unsigned)m && (i0 + row) < n;
@@ -1976,7 +1983,10 @@ __device__ __forceinline__ void sweep(const Params &p)
             };
             u64 hist[K];  // the edge-facing carry after each step (published below by one lane)
             const int par = c & 1;
-            float *lo = lds_out + lane * PO + par * K;  // this lane's row, this chunk's half of the ring
+            const int fpar = (t0 / KF) & 1;   // the half of the output ring this chunk's flush block lives in (KF = K: par)
+            float *lo = lds_out + lane * PO + (t0 & (2 * KF - 1));  // this lane's row, this chunk's part of the ring
+            float *lo_m1 = lds_out + lane * PO - 1;                  // position -1 of the row (FLUSH2)
+            const bool top_of_block = ((t0 + K) & (KF - 1)) == 0;    // the chunk holds the last step of a flush block (KF = K: always)
             // ---- publish boundary values for the next strip (one lane), then the progress word ----
             auto publish_range = [&]() {   // values of the chunk's steps t0 + k, k in [0, K)
                 constexpr int K0 = 0, K1 = K;
@@ -2057,7 +2067,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                     for (int k = 0; k < K; ++k) lo[k] = 0.f;
                     zring |= 1 << par;
                 }
-                if constexpr (FLUSH2) lo[-1 - par * K] = 0.f;   // (shared by both halves)
+                if constexpr (FLUSH2) { if (top_of_block) *lo_m1 = 0.f; }   // (shared by both halves)
             };
             if constexpr (PIPE) {
                 // the iteration's one wait for memory: this chunk's rows (requested an iteration ago) and whatever is older.  A
@@ -2110,7 +2120,8 @@ __device__ __forceinline__ void sweep(const Params &p)
                         for (int k2 = 0; k2 < K / 2; ++k2) fv[k2] = make_float2(0.f, 0.f);
                     }
                 } else {
-                    flush_out(pf_t0, pf_par, ci > 0, ZSKIP && zring == 3);
+                    // (KF > K: a flush block is complete after every second chunk)
+                    if (KF == K || (pf_t0 & (KF - 1)) == 0) flush_out(pf_t0, pf_par, ci > 0, ZSKIP && zring == 3);
                 }
                 stamp_rev(1);
                 if (ci >= nchunks) {
@@ -2194,11 +2205,12 @@ __device__ __forceinline__ void sweep(const Params &p)
                 if (zskip) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) hist[k] = 0, lo[k] = 0.f;
+                    if constexpr (FLUSH2) { if (top_of_block) *lo_m1 = 0.f; }
                     cy.a = cy.b = cy.c = 0.0;
                     stamp_rev(2), stamp_rev(3);
                     publish_range();
                     stamp_rev(4);
-                    pf_t0 = t0, pf_par = par;
+                    pf_t0 = t0, pf_par = fpar;
                     if (more) write_block_s(bb_new, ecur_t{});
                     return;
                 }
@@ -2244,7 +2256,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                     stamp_rev(3);
                     publish_range();
                     stamp_rev(4);
-                    pf_t0 = t0, pf_par = par;
+                    pf_t0 = t0, pf_par = fpar;
                     return;
                 }
             }
@@ -2450,12 +2462,12 @@ __device__ __forceinline__ void sweep(const Params &p)
             stamp_rev(3);
             publish_range();
             if constexpr (FLUSH2) {
-                if (!zero_chunk) lo[-1 - par * K] = lo[K - 1];   // step 31's value once more, at position -1 of the row (see FLUSH2)
+                if (!zero_chunk && top_of_block) *lo_m1 = lo[K - 1];   // step 31's value once more, at position -1 of the row (see FLUSH2)
             }
             stamp_rev(4);
 
             // ---- flush: one memory-aligned K-element block per row (see fo_* above) ----
-            pf_t0 = t0, pf_par = par;
+            pf_t0 = t0, pf_par = fpar;
 
             if constexpr (ZSKIP_A) { if (more) write_block_s(bb_new, std::integral_constant<int, P>{}); }
             else { if (more) write_block(bb_new); }

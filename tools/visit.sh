@@ -1,6 +1,5 @@
-mkdir -p gpurun_out/adj
+mkdir -p gpurun_out/adj2
 export TMPDIR=/tmp
-for a in 0 7 4 3; do
-(ALIAS=$a timeout 300 python tools/adj_trace.py b 2>&1 | grep -v amdgpu | head -11) | tee gpurun_out/adj/abwd_trace_alias$a.txt
-(ALIAS=$a timeout 300 python tools/adj_trace.py f 2>&1 | grep -v amdgpu | head -11) | tee gpurun_out/adj/afwd_trace_alias$a.txt
-done
+(timeout 300 python tools/adj_trace.py b 2>&1 | grep -v amdgpu | head -11) | tee gpurun_out/adj2/abwd_trace.txt
+(ALIAS=7 timeout 300 python tools/adj_trace.py b 2>&1 | grep -v amdgpu | head -11) | tee gpurun_out/adj2/abwd_trace_alias7.txt
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 | tee gpurun_out/adj2/tests.txt
