@@ -47,7 +47,8 @@ for name, pattern in (("kernel_stats.csv", "prof/**/*kernel_stats.csv"), ("train
                       ("steady.txt", "steady.txt"), ("fwd_timeline.txt", "fwd_timeline.txt"),
                       ("bwd_trace.txt", "bwd_trace.txt"), ("bwd_trace_alias7.txt", "bwd_trace_alias7.txt"), ("fwd_trace.txt", "fwd_trace.txt"),
                       ("fwd_trace_alias7.txt", "fwd_trace_alias7.txt"), ("zero_probe.txt", "zero_probe.txt"), ("bigB.txt", "bigB.txt"),
-                      ("shapes.txt", "shapes.txt"),
+                      ("shapes.txt", "shapes.txt"), ("bench_driver_protocol.json", "bench_driver_protocol.json"), ("ubench_f2mix.txt", "ubench_f2mix.txt"),
+                      ("adj_trace.txt", "adj_trace.txt"), ("lens_ab.txt", "lens_ab.txt"),
                       ("pytest_multigpu.txt", "pytest_multigpu.txt"), ("multigpu_skipped.txt", "multigpu_skipped.txt"),
                       ("pytest_gpu.txt", "pytest_gpu.txt"), ("smoke.txt", "smoke.txt"), ("fuzz2.txt", "fuzz2.txt"), ("parts_fuzz.txt", "parts_fuzz.txt")):
     f = first(pattern)

@@ -10,6 +10,8 @@ OUT=gpurun_out/round_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 python tools/source_stamp.py > $OUT/stamp.json
+# the driver's protocol FIRST, on the box as it comes (20 timed steps behind 5: not yet the steady state of the default run below)
+timeout 600 python bench.py --steps 20 --warmup 5 2> $OUT/bench_driver_protocol.err | tee $OUT/bench_driver_protocol.json
 if [ "$2" != "quick" ]; then
   timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $OUT/pytest_gpu.txt
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee $OUT/smoke.txt
@@ -50,7 +52,7 @@ timeout 600 python bench.py --mode align+traceback --no-cpu-baseline 2>> $OUT/be
 timeout 300 python tools/gpu_configs.py 2> /dev/null | tee $OUT/configs.txt
 timeout 300 python tools/parts_probe.py 256 1022 1020 lens cfg3 2> /dev/null | grep "^parts" | tee $OUT/parts_configs2.txt
 # bare read / write / mixed streams of the forward sweep's size: what this box's memory system gives
-for u in mix mix2 vmemissue; do hipcc --offload-arch=gfx950 -O3 -o /tmp/$u tools/ubench/$u.hip 2> /dev/null && timeout 300 /tmp/$u 2>&1 | tee $OUT/ubench_$u.txt; done
+for u in mix mix2 vmemissue f2mix; do hipcc --offload-arch=gfx950 -O3 -o /tmp/$u tools/ubench/$u.hip 2> /dev/null && timeout 300 /tmp/$u 2>&1 | tee $OUT/ubench_$u.txt; done
 # the steady state of the two sweeps against the previous round's library (build_variants/libsdp_r05.so travels with the snapshot)
 timeout 600 python tools/steady.py 256x512x512 64x512x512 256x1024x1024 512x512x512 2>&1 | grep "B=" | tee $OUT/steady.txt
 TRACE_BLOCKS=1 TRACE_TIMELINE=1 timeout 300 python tools/fwd_trace.py > $OUT/fwd_timeline.txt 2>&1
@@ -60,6 +62,9 @@ timeout 300 python tools/bwd_trace.py > $OUT/bwd_trace.txt 2>&1
 timeout 300 python tools/bwd_trace.py 7 > $OUT/bwd_trace_alias7.txt 2>&1
 timeout 300 python tools/fwd_trace.py > $OUT/fwd_trace.txt 2>&1
 timeout 300 python tools/fwd_trace.py 7 > $OUT/fwd_trace_alias7.txt 2>&1
+# the adjoint sweeps' chunks, real memory and cache-served; per-pair lengths against the previous round's library
+for a in 0 7; do for k in b f; do (ALIAS=$a timeout 300 python tools/adj_trace.py $k 2>&1 | grep -v amdgpu | cut -c1-220) >> $OUT/adj_trace.txt; done; done
+timeout 300 python tools/lens_ab.py 2>&1 | grep -v amdgpu > $OUT/lens_ab.txt
 timeout 300 python tools/zero_probe.py 2>&1 | grep -v amdgpu > $OUT/zero_probe.txt
 timeout 300 python tools/zero_probe.py 256 1024 1024 2>&1 | grep -v amdgpu >> $OUT/zero_probe.txt
 for B in 512 1024; do

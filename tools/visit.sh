@@ -1,5 +1,3 @@
 mkdir -p gpurun_out/adj2
 export TMPDIR=/tmp
-(timeout 300 python tools/adj_trace.py b 2>&1 | grep -v amdgpu | head -11) | tee gpurun_out/adj2/abwd_trace.txt
-(ALIAS=7 timeout 300 python tools/adj_trace.py b 2>&1 | grep -v amdgpu | head -11) | tee gpurun_out/adj2/abwd_trace_alias7.txt
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 | tee gpurun_out/adj2/tests.txt
+hipcc --offload-arch=gfx950 -O3 tools/ubench/f2mix.hip -o /tmp/f2mix && (timeout 300 /tmp/f2mix 2>&1) | tee gpurun_out/adj2/f2mix.txt
