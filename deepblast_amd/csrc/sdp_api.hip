@@ -375,6 +375,9 @@ inline bool exact_for(bool flag, int N, int M)
 // does a launch of this padded shape with per-pair lengths have to route thin pairs to the exact-state build?
 inline bool routes_thin(bool exact, int N, int M, const int32_t *lens)
 {
+#ifdef SDP_EXPERIMENTS
+    if (g_dbg.load() & 32768) return false;   // sdp_set_debug(32768): no routing (A/B timing of the second launch; thin pairs then keep the packed state)
+#endif
     return lens != nullptr && !exact && (N > sdp::THIN_HI || M > sdp::THIN_HI);
 }
 

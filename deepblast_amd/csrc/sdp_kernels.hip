@@ -893,8 +893,9 @@ __device__ __forceinline__ void sweep(const Params &p)
         int fo_off0[FLUSH2 ? 1 : K], fo_dk[FLUSH2 ? 1 : K];
         unsigned fo_voff[FLUSH2 ? 1 : K];
         bool fo_need_tail = false;
+        const int fo_beta = (GEN && T::SOUT > 0) ? (int)(((uintptr_t)(p.sout + b_out * plane_elems) >> 2) & (uintptr_t)(K - 1)) : 0;
         if constexpr (T::SOUT > 0 && !FLUSH2) {
-            const int beta = GEN ? (int)(((uintptr_t)(p.sout + b_out * plane_elems) >> 2) & (uintptr_t)(K - 1)) : 0;
+            const int beta = fo_beta;
             fo_need_tail = GEN && (beta != 0 || (ld & (K - 1)) != 0);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -1823,6 +1824,42 @@ __device__ __forceinline__ void sweep(const Params &p)
                         if constexpr (LAZY && !PIPE) __builtin_amdgcn_s_waitcnt(0x8F70);   // vmcnt(32)
                     }
                 } else {
+                    if constexpr (GEN) {
+                        // General pitch, every element a real cell (a full strip, the rows' blocks -- which start up to 63 columns left of
+                        // t0 -- inside the matrix): the blocks are K-float pieces of MEMORY lines, so four columns per lane leave as one
+                        // aligned dwordx4 -- K / 4 stores per chunk instead of K masked dword stores, and none of the per-lane index
+                        // arrays (round 6: the dword flush was 2700-2900 of the 6100-7900 cycles of a chunk of the general-pitch
+                        // backward sweeps, with real memory and cache-served alike: tools/bwd_trace.py 0 64 1022 1020).  Row and block
+                        // offset are formed on the spot: rho_r as in the set-up above.
+                        // K = 32 only: at K = 16 (the 8-wave latency builds, BASELINE configs[2] with per-pair lengths) four dwordx4 stores of
+                        // sixteen 64-byte row pieces each were no gain over sixteen dword stores of four (interleaved A/B: 523 -> 542 us with the
+                        // zero fill, 300-330 either way without); K = 32, steady state: 64 x 1022 x 1020 backward 355.5 -> 328.3 us,
+                        // 256 x 500 x 516 147.6 -> 142.7, 256 x 1022 x 1020 (the memory system's) 404.5 -> 409.8
+                        if (K == 32 && active && rows == 64 && t0 >= 64 && t0 + K <= m) {
+                            constexpr int LPRF = K / 4, RPIF = 64 / LPRF;
+                            const int rlf = lane / LPRF, e4 = 4 * (lane % LPRF);
+                            typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
+                            u32x4g v[K / 4];
+                            unsigned voff[K / 4];
+#pragma unroll
+                            for (int j = 0; j < K / 4; ++j) {
+                                const int r = j * RPIF + rlf;
+                                const int rho = (r * (1 - ld) - fo_beta) & (K - 1);
+                                const int s0 = rho + e4 + par * K;
+                                const float *row = lds_out + r * PO;
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj) v[j][jj] = __float_as_uint(row[(s0 + jj) & (2 * K - 1)]);
+                                voff[j] = (unsigned)((r * ld - r + rho + e4) * 4 + ubase);
+                            }
+#pragma unroll
+                            for (int j = 0; j < K / 4; ++j) {
+                                if constexpr (ABL_NOSTORE) { unsigned vv = v[j][0] ^ v[j][3] ^ voff[j]; keep(vv); }
+                                else __builtin_amdgcn_raw_buffer_store_b128(v[j], rs_out, voff[j], 0, AUX_OUT_STORE);
+                            }
+                            if constexpr (LAZY) __builtin_amdgcn_s_waitcnt(0x0F70 | ((K / 4) & 15));   // vmcnt(K / 4)
+                            return;
+                        }
+                    }
                     float vals[K];
 #pragma unroll
                     for (int k = 0; k < K; ++k) vals[k] = lds_out[fo_off0[k] + par * fo_dk[k]];
@@ -2511,6 +2548,10 @@ __device__ __forceinline__ void sweep(const Params &p)
 SDP_KERNEL(sdp_bwd_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q, false, false, false, false, true)
 #elif defined(SDP_ONLY) && SDP_ONLY == 21
 SDP_KERNEL(sdp_bwd_pipe_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q)
+#elif defined(SDP_ONLY) && SDP_ONLY == 11
+SDP_KERNEL(sdp_bwd_g_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, false, false, true)
+#elif defined(SDP_ONLY) && SDP_ONLY == 15
+SDP_KERNEL(sdp_bwd_lat_g_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, false, false, true)
 #elif defined(SDP_ONLY) && SDP_ONLY == 0
 SDP_KERNEL(sdp_fwd_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, true, false, false, false, true)
 #elif defined(SDP_ONLY) && SDP_ONLY == 37

@@ -7,6 +7,8 @@ import gpu_tune
 sys.path.insert(0, os.path.join(gpu_tune.ROOT, "tests"))
 import datagen
 libs = {"main": os.path.join(gpu_tune.ROOT, "deepblast_amd", "libsdp_hip.so")}
+if "noroute" in sys.argv:
+    libs["exp"] = os.path.join(gpu_tune.ROOT, "deepblast_amd", "libsdp_hip_exp.so")   # the experiments build: has sdp_set_debug
 for p in sorted(glob.glob(os.path.join(gpu_tune.ROOT, "build_variants", "libsdp_*.so"))):
     libs[os.path.basename(p)[7:-3]] = p
 L = {k: gpu_tune.load(v) for k, v in libs.items()}
@@ -27,6 +29,12 @@ for k, l in L.items():
     g = (lambda l, st, E: lambda: l.sdp_backward_f32(et.data_ptr(), st.data_ptr(), E.data_ptr(), B, N, M, lens.data_ptr(), flag, 0, stream))(l, st, E)
     assert f() == 0 and g() == 0
     fn[k] = (f, g, vt, E)
+    if k == "exp" and "noroute" in sys.argv:   # the shipped library once more without the second (thin-pair) launch: sdp_set_debug(32768)
+        def wrap(h, l=l):
+            def run():
+                gpu_tune.set_debug(l, 32768); r = h(); gpu_tune.set_debug(l, 0); return r
+            return run
+        fn["exp-noroute"] = (wrap(f), wrap(g), vt, E)
 torch.cuda.synchronize()
 ref = fn["main"]
 for k in fn:

@@ -17,11 +17,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, un
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
 }
 template <int WIDE, int NV>
-__global__ void __launch_bounds__(256) kern(char *qd, const char *q, const char *z, float *out, int iters, unsigned wrap)
+__global__ void __launch_bounds__(256) kern(char *qd, const char *q, const char *z, float *out, int iters, unsigned wrap, unsigned skew)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), W = blockDim.x >> 6, b = blockIdx.x;
     const size_t w = (size_t)b * W + wave;
-    __amdgpu_buffer_rsrc_t rs = make_rsrc(qd + w * wrap, wrap), rq = make_rsrc(q + w * wrap, wrap), rz = make_rsrc(z + w * (wrap / 2), wrap / 2);
+    // (skew: every wave's streams start `skew` bytes further than a multiple of the 4 MB stride -- do power-of-two strides camp on channels?)
+    __amdgpu_buffer_rsrc_t rs = make_rsrc(qd + w * (wrap + skew), wrap), rq = make_rsrc(q + w * (wrap + skew), wrap), rz = make_rsrc(z + w * (wrap / 2 + skew), wrap / 2);
     float acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 1.0f + lane * 1e-3f + i;
@@ -77,6 +78,7 @@ __global__ void __launch_bounds__(256) kern(char *qd, const char *q, const char 
     for (int i = 0; i < 8; ++i) s += acc[i];
     out[w * 64 + lane] = s;
 }
+static unsigned g_skew = 0;
 template <int WIDE, int NV>
 void run(const char *what, int B, char *qd, char *q, char *z, float *out, unsigned wrap)
 {
@@ -86,7 +88,7 @@ void run(const char *what, int B, char *qd, char *q, char *z, float *out, unsign
     float best = 1e9f;
     for (int rep = 0; rep < 4; ++rep) {
         CHECK(hipEventRecord(e0));
-        kern<WIDE, NV><<<B, W * 64>>>(qd, q, z, out, iters, wrap);
+        kern<WIDE, NV><<<B, W * 64>>>(qd, q, z, out, iters, wrap, g_skew);
         CHECK(hipEventRecord(e1));
         CHECK(hipDeviceSynchronize());
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -95,11 +97,13 @@ void run(const char *what, int B, char *qd, char *q, char *z, float *out, unsign
     const double gb = (double)B * W * (8192.0 * 2 + 4096.0) * iters / (best * 1e-3) / 1e12;
     printf("%-60s B=%3d NV=%4d  %7.1f us  %5.2f TB/s\n", what, B, NV, best * 1e3, gb);
 }
-int main()
+int main(int argc, char **argv)
 {
     const unsigned wrap = 4u << 20;
+    g_skew = argc > 1 ? (unsigned)atoi(argv[1]) : 0u;   // bytes; the allocations leave room for 64 KB per wave
+    printf("skew %u bytes per wave\n", g_skew);
     char *qd, *q, *z; float *out;
-    CHECK(hipMalloc(&qd, (size_t)1024 * wrap)); CHECK(hipMalloc(&q, (size_t)1024 * wrap)); CHECK(hipMalloc(&z, (size_t)1024 * wrap / 2));
+    CHECK(hipMalloc(&qd, (size_t)1024 * (wrap + 65536))); CHECK(hipMalloc(&q, (size_t)1024 * (wrap + 65536))); CHECK(hipMalloc(&z, (size_t)1024 * (wrap / 2 + 65536)));
     CHECK(hipMalloc(&out, 1024 * 64 * 4));
     CHECK(hipMemset(q, 0, (size_t)1024 * wrap)); CHECK(hipMemset(z, 0, (size_t)1024 * wrap / 2));
     for (int B : {256, 64}) {
