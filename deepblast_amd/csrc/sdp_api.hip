@@ -88,7 +88,7 @@ Variant variant(int id)
     case 10: return {(const void *)sdp_adj_fwd_loss_kernel, SDP_K_AFWD, 4, 10};  // adj-fwd with the loss seed formed in the kernel
     // general-pitch instantiations (staged blocks aligned to lines of memory through run-time per-row offsets): id + 11
     case 11: return {(const void *)sdp_fwd_g_kernel, SDP_K_FWD, SDP_MAXW_FWD, 11};
-    case 12: return {(const void *)sdp_bwd_g_kernel, SDP_K_BWD, SDP_MAXW_BWD, 12};   // (general pitch: 87 spills under an 8-wave bound, stays at 4)
+    case 12: return {(const void *)sdp_bwd_g_kernel, SDP_K_BWD, SDP_MAXW_BWD_Q, 12};   // (general pitch: 210 registers since round 6 -- the flush's index arrays are gone -- so eight waves fit, like the aligned build's)
     case 14: return {(const void *)sdp_adj_bwd_g_kernel, SDP_K_ABWD, SDP_MAXW_ABWD, 14};
     case 15: return {(const void *)sdp_bwd_lat_g_kernel, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, 15};
     case 18: return {(const void *)sdp_bwd_x_g_kernel, SDP_K_BWD, SDP_MAXW_BWD, 18};
@@ -199,9 +199,9 @@ Plan plan(int pass, int B, int N, int M, bool has_lens, bool exact_state, int cu
         // the throughput builds need 4 waves' worth of LDS for their longer chunks; fall back to the latency
         // builds when that does not fit (long M) or when more waves are wanted
         const int w4 = nstrips < 4 ? nstrips : 4;
-        // (the packed backward build runs up to 8 waves since round 5 -- its general-pitch and exact-state twins only 4: a launch
-        //  that will end up in one of those is judged by their limit)
-        const int maxw = (pass == sdp::PASS_BWD && (general_pitch || exact_state)) ? SDP_MAXW_BWD : v.maxw;
+        // (the packed backward build runs up to 8 waves since round 5, its general-pitch twin since round 6 -- the exact-state twins
+        //  only 4: a launch that will end up in one of those is judged by their limit)
+        const int maxw = (pass == sdp::PASS_BWD && exact_state) ? SDP_MAXW_BWD : v.maxw;
         if (W > maxw || lds_bytes(pass, v.K, w4, mcap, nullptr) > 160 * 1024) v = variant(pass == sdp::PASS_FWD ? 6 : 4);
     }
     if (pass == sdp::PASS_FWD && exact_state) v = variant(v.id == 0 ? 9 : 5);

@@ -890,13 +890,17 @@ __device__ __forceinline__ void sweep(const Params &p)
         // lines per chunk, with three 16-entry index arrays held across the loop, as 2700-3700 of a chunk's 10 600 cycles.
         constexpr int KF = FLUSH2 ? 32 : K;
         static_assert(KF % K == 0 && PO >= 2 * KF + 1, "the output ring holds two flush blocks per row");
-        int fo_off0[FLUSH2 ? 1 : K], fo_dk[FLUSH2 ? 1 : K];
-        unsigned fo_voff[FLUSH2 ? 1 : K];
+        // (GENFAST: the general-pitch K = 32 builds, whose plain chunks leave through a path of their own -- see flush_out -- and whose
+        //  rare masked flushes form these indices on the spot: three 32-entry arrays held across the chunk loop are 96 registers)
+        constexpr bool GENFAST = GEN && K == 32 && T::SOUT > 0;
+        constexpr bool FO_ARRAYS = T::SOUT > 0 && !FLUSH2 && !GENFAST;
+        int fo_off0[FO_ARRAYS ? K : 1], fo_dk[FO_ARRAYS ? K : 1];
+        unsigned fo_voff[FO_ARRAYS ? K : 1];
         bool fo_need_tail = false;
         const int fo_beta = (GEN && T::SOUT > 0) ? (int)(((uintptr_t)(p.sout + b_out * plane_elems) >> 2) & (uintptr_t)(K - 1)) : 0;
-        if constexpr (T::SOUT > 0 && !FLUSH2) {
+        if constexpr (T::SOUT > 0 && !FLUSH2) fo_need_tail = GEN && (fo_beta != 0 || (ld & (K - 1)) != 0);
+        if constexpr (FO_ARRAYS) {
             const int beta = fo_beta;
-            fo_need_tail = GEN && (beta != 0 || (ld & (K - 1)) != 0);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int r = k * RPI + r_l;
@@ -1835,7 +1839,7 @@ __device__ __forceinline__ void sweep(const Params &p)
                         // sixteen 64-byte row pieces each were no gain over sixteen dword stores of four (interleaved A/B: 523 -> 542 us with the
                         // zero fill, 300-330 either way without); K = 32, steady state: 64 x 1022 x 1020 backward 355.5 -> 328.3 us,
                         // 256 x 500 x 516 147.6 -> 142.7, 256 x 1022 x 1020 (the memory system's) 404.5 -> 409.8
-                        if (K == 32 && active && rows == 64 && t0 >= 64 && t0 + K <= m) {
+                        if (GENFAST && active && rows == 64 && t0 >= 64 && t0 + K <= m) {
                             constexpr int LPRF = K / 4, RPIF = 64 / LPRF;
                             const int rlf = lane / LPRF, e4 = 4 * (lane % LPRF);
                             typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
@@ -1861,14 +1865,27 @@ __device__ __forceinline__ void sweep(const Params &p)
                         }
                     }
                     float vals[K];
-#pragma unroll
-                    for (int k = 0; k < K; ++k) vals[k] = lds_out[fo_off0[k] + par * fo_dk[k]];
+                    int g_rl = r_l, g_sl = s_l;   // (GENFAST: opaque copies, or the compiler hoists the index arithmetic out of the chunk loop again)
+                    if constexpr (GENFAST) asm volatile("" : "+v"(g_rl), "+v"(g_sl));
+                    auto g_rho = [&](int row) { return (row * (1 - ld) - fo_beta) & (K - 1); };
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        const int row = k * RPI + r_l;
-                        const int col = t0 + (int)(fo_voff[k] >> 2) - row * ld;   // t0 - D_row + s_l (fo_voff >= 0: D_r <= r)
+                        if constexpr (GENFAST) {
+                            const int row = k * RPI + g_rl;
+                            vals[k] = lds_out[row * PO + ((g_rho(row) + g_sl + par * K) & (2 * K - 1))];
+                        } else {
+                            vals[k] = lds_out[fo_off0[k] + par * fo_dk[k]];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const int row = k * RPI + (GENFAST ? g_rl : r_l);
+                        unsigned voff_k;
+                        if constexpr (GENFAST) voff_k = (unsigned)((row * ld - (row - g_rho(row)) + g_sl) * 4);
+                        else voff_k = fo_voff[k];
+                        const int col = t0 + (int)(voff_k >> 2) - row * ld;   // t0 - D_row + s_l (voff >= 0: D_r <= r)
                         const bool ok = active && (unsigned)col < (unsigned)m && (i0 + row) < n;
-                        const unsigned off = ok ? fo_voff[k] + (unsigned)ubase : OOB;
+                        const unsigned off = ok ? voff_k + (unsigned)ubase : OOB;
                         if constexpr (ABL_NOSTORE) {
                             unsigned vv = __float_as_uint(vals[k]) ^ off;
                             keep(vv);
@@ -2549,7 +2566,7 @@ SDP_KERNEL(sdp_bwd_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q, false, fals
 #elif defined(SDP_ONLY) && SDP_ONLY == 21
 SDP_KERNEL(sdp_bwd_pipe_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q)
 #elif defined(SDP_ONLY) && SDP_ONLY == 11
-SDP_KERNEL(sdp_bwd_g_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, false, false, true)
+SDP_KERNEL(sdp_bwd_g_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q, false, false, true)
 #elif defined(SDP_ONLY) && SDP_ONLY == 15
 SDP_KERNEL(sdp_bwd_lat_g_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, false, false, true)
 #elif defined(SDP_ONLY) && SDP_ONLY == 0
@@ -2625,7 +2642,7 @@ SDP_KERNEL(sdp_fwd_g_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, true
 SDP_KERNEL(sdp_fwd_x_tp_g_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, true, true, true)
 #endif
 #if SDP_IN_GROUP(7)
-SDP_KERNEL(sdp_bwd_g_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, false, false, true)
+SDP_KERNEL(sdp_bwd_g_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q, false, false, true)
 SDP_KERNEL(sdp_bwd_lat_g_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, false, false, true)
 SDP_KERNEL(sdp_bwd_x_g_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, true, false, true)
 SDP_KERNEL(sdp_bwd_x_lat_g_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, true, false, true)
