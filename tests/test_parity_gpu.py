@@ -353,7 +353,9 @@ def test_variable_length_batch_larger_than_the_gpu_runs_longest_first(variant):
 
 @pytest.mark.parametrize("case", [(300, 70, 150, 0, False), (300, 69, 131, 1, False), (300, 130, 150, 0, True), (160, 200, 516, 0, False),
                                   (217, 9, 6, 0, False), (142, 63, 25, 0, False), (188, 57, 59, 1, False), (237, 15, 10, 0, True),
-                                  (279, 21, 35, 0, False), (130, 3, 1, 0, False), (131, 70, 2, 1, False)],
+                                  (279, 21, 35, 0, False), (130, 3, 1, 0, False), (131, 70, 2, 1, False),
+                                  # fewer pairs than CUs, nine strips: the general-pitch K = 32 backward build on EIGHT waves (round 6)
+                                  (40, 520, 516, 0, False), (40, 520, 516, 1, True)],
                          ids=lambda c: "x".join(str(int(v)) for v in c))
 def test_row_pitch_and_planes_not_aligned_to_cache_lines(case):
     """Full batches (throughput builds) whose rows and per-pair planes do not start on 128-byte lines: the input
