@@ -2569,8 +2569,6 @@ SDP_KERNEL(sdp_bwd_pipe_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q)
 SDP_KERNEL(sdp_bwd_g_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD_Q, false, false, true)
 #elif defined(SDP_ONLY) && SDP_ONLY == 18
 SDP_KERNEL(sdp_bwd_x_g_kernel, sdp::PASS_BWD, SDP_K_BWD, SDP_MAXW_BWD, true, false, true)
-#elif defined(SDP_ONLY) && SDP_ONLY == 25
-SDP_KERNEL(sdp_fwd_pg_kernel, sdp::PASS_FWD, SDP_K_FWD, SDP_MAXW_FWD, false, true, true, true)
 #elif defined(SDP_ONLY) && SDP_ONLY == 15
 SDP_KERNEL(sdp_bwd_lat_g_kernel, sdp::PASS_BWD, SDP_K_BWD_LAT, SDP_MAXW_BWD_LAT, false, false, true)
 #elif defined(SDP_ONLY) && SDP_ONLY == 0
