@@ -161,10 +161,54 @@ def test_aligned_flush_covers_every_cell_once(N, M, K, beta):
                 off0 = (s - K if prev else s) + (K if prev else 0)   # fo_off0 without the row term
                 dk = -K if prev else K
                 idx = off0 + par * dk
+                assert idx == (s + par * K) % (2 * K)                   # (round 6: the form the general-pitch K = 32 builds compute on the spot)
                 col = blk0 + e
                 if 0 <= col < M and r < rows:
                     assert ring[r, idx] == col, (c, r, e)
                     seen[r, col] += 1
+    assert (seen == 1).all()
+
+
+@pytest.mark.parametrize("N,M", [(64, 64), (64, 96), (64, 100), (40, 7), (64, 512), (64, 513), (64, 500), (33, 129), (64, 33)])
+def test_wide_flush_of_a_short_chunk_sweep(N, M):
+    """Round 6, adjoint backward sweep (sdp_kernels.hip: FLUSH2 with KF = 32 at K = 16): the sweep runs 16-step chunks, but a
+    row's outputs leave as 32-column blocks -- whole 128-byte lines -- out of a ring of 64 steps per row, after every SECOND
+    chunk (the one whose t0 is a multiple of 32), at the top of the next iteration.  Element e of row r's block comes from step
+    offset s = (r mod 32) + e of the ring, counted from the block's own half (this super-chunk) into the other half (the one
+    processed before); the pair that would straddle ring positions 63 | 0 is read from position -1 of the row, where the chunk
+    that holds a block's last step leaves a copy of it.  Model ring, cadence and position -1 literally; check values and that
+    every cell leaves exactly once."""
+    K, KF, PO = 16, 32, 65
+    nchunks = ceil_div(M + 63, K)
+    rows = min(N, 64)
+    ring = np.full((64, PO + 1), -10**6, dtype=np.int64)     # column 0 of this array is "position -1" of the row
+    pos = lambda p_: p_ + 1
+    seen = np.zeros((rows, M), dtype=np.int64)
+    pf_t0 = 0
+    for ci in range(nchunks + 1):                              # one extra iteration for the last chunk's flush
+        if (pf_t0 & (KF - 1)) == 0 and ci > 0:                 # (ci = 0: the kernel's flush runs with every store masked)
+            t0, par = pf_t0, (pf_t0 // KF) & 1
+            for r in range(64):
+                rho = r & (KF - 1)
+                d = r - rho
+                for e in range(0, KF, 2):                      # the kernel reads pairs (8-byte LDS reads)
+                    sb = rho + e
+                    base = sb + ((KF if sb < KF - 1 else -KF) if par else 0)
+                    for j in range(2):
+                        col = t0 - d + e + j
+                        if 0 <= col < M and r < rows:
+                            assert ring[r, pos(base + j)] == col, (ci, r, e, j, par)
+                            seen[r, col] += 1
+        if ci < nchunks:
+            c = nchunks - 1 - ci
+            t0 = c * K
+            q = t0 & (2 * KF - 1)
+            for k in range(K - 1, -1, -1):
+                for lane in range(64):
+                    ring[lane, pos(q + k)] = t0 + k - lane     # the value Ed[lane, t0 + k - lane] (any int stands in)
+            if ((t0 + K) & (KF - 1)) == 0:                     # the chunk holds the last step of a flush block
+                ring[:, pos(-1)] = ring[:, pos(q + K - 1)]
+            pf_t0 = t0
     assert (seen == 1).all()
 
 
