@@ -1,5 +1,3 @@
-mkdir -p gpurun_out/soak3
+mkdir -p gpurun_out/alias
 export TMPDIR=/tmp
-(timeout 1500 python tools/fuzz2.py 2500 621 2>&1 | grep -v amdgpu | tail -12) | tee gpurun_out/soak3/fuzz2_2500.txt
-(timeout 900 python tools/fuzz2.py 120 622 full 2>&1 | grep -v amdgpu | tail -6) | tee gpurun_out/soak3/fuzz2_full120.txt
-(timeout 600 python tools/parts_fuzz.py 400 2>&1 | grep -v amdgpu | tail -3) | tee gpurun_out/soak3/parts_fuzz_400.txt
+for d in 0 7 4 3; do echo "== DBG=$d (1 inputs, 2 outputs, 4 state of every pair aliased to pair 0's)"; timeout 300 python tools/steady.py 256x512x512 128x512x512 EXP=1 DBG=$d only=none ROUNDS=3 2>&1 | grep "B="; done | tee gpurun_out/alias/steady_alias.txt
