@@ -109,12 +109,13 @@ int main()
 {
     const unsigned wrap = 4u << 20;   // 4 MB per wave: streams, 4 GB in total
     char *stb, *ldb; float *out; long long *cyc;
-    CHECK(hipMalloc(&stb, (size_t)1024 * wrap)); CHECK(hipMalloc(&ldb, (size_t)1024 * wrap));
-    CHECK(hipMalloc(&out, 1024 * 64 * 4)); CHECK(hipMalloc(&cyc, 1024 * 8));
-    CHECK(hipMemset(ldb, 0, (size_t)1024 * wrap));
-  for (int pass = 0; pass < 3; ++pass) {
-    g_B = pass == 0 ? 256 : (pass == 1 ? 64 : 16);
-    printf("== %d workgroups x 4 waves (one per SIMD); per iteration NV v_fma (8 independent accumulators) + NM memory instructions (dwordx4, 1 KB each)\n", g_B);
+    CHECK(hipMalloc(&stb, (size_t)4096 * wrap)); CHECK(hipMalloc(&ldb, (size_t)4096 * wrap));
+    CHECK(hipMalloc(&out, 4096 * 64 * 4)); CHECK(hipMalloc(&cyc, 4096 * 8));
+    CHECK(hipMemset(ldb, 0, (size_t)4096 * wrap));
+  // (passes 3, 4: two and four workgroups per CU -- 8 and 16 waves per CU: does the memory system give more to more waves?)
+  for (int pass = 0; pass < 5; ++pass) {
+    g_B = pass == 0 ? 256 : (pass == 1 ? 64 : (pass == 2 ? 16 : (pass == 3 ? 512 : 1024)));
+    printf("== %d workgroups x 4 waves (one per SIMD and workgroup); per iteration NV v_fma (8 independent accumulators) + NM memory instructions (dwordx4, 1 KB each)\n", g_B);
     run<0, 320, 10>("no memory instruction (the bare chain)", stb, ldb, out, cyc, wrap);
     run<1, 320, 10>("10 stores, data registers OVERWRITTEN right behind each store", stb, ldb, out, cyc, wrap);
     run<2, 320, 10>("10 stores, data registers written right BEFORE each store, at rest behind it", stb, ldb, out, cyc, wrap);
