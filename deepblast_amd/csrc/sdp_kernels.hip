@@ -2824,8 +2824,66 @@ __device__ __forceinline__ void traceback_walk(const float *grad, int *states, i
         __syncthreads();
         int ti = TW - 1, tj = TW - 1;   // the current cell; the walk stays in the window while both are >= 1
         bool stop = false;
-        if (r0 >= 0 && c0 >= 0) {
-            // ---- the whole window is inside the matrix: no floor values, no wrap ----
+        if (TW == 32 && r0 >= 0 && c0 >= 0) {
+            // ---- the whole window is inside the matrix: no floor values, no wrap (round 6) ----
+            // Which way a cell sends the walk depends on the cell alone, so the choices of all 31 x 31 cells of the window are made at
+            // once -- the same three comparisons per cell as in the loop below, sixteen cells per lane -- and kept as two bits per cell
+            // (0 / 1 / 2: the step; 3: the sentinel rule says stop) in ONE register: lane c + 32 h holds column c, rows 16 h .. 16 h + 15.
+            // A step of the walk is then a v_readlane, a shift and a few scalar instructions -- no LDS round trip and no ballot in
+            // the chain of <= N + M dependent steps (it was three broadcast reads and three ballots per step: ~360 cycles).
+            const int cc = lane & 31, hh = lane >> 5;
+            float colv[17];   // rows 16 hh - 1 .. 16 hh + 15 of column cc (row -1 is never a current cell's: clamped)
+#pragma unroll
+            for (int k = 0; k < 17; ++k) colv[k] = tile[max(16 * hh - 1 + k, 0) * TW + cc];
+            unsigned code = 0;
+#pragma unroll
+            for (int k = 1; k < 17; ++k) {
+                // cell (r, cc), r = 16 hh + k - 1: left = (r - 1, cc), diag = (r - 1, cc - 1), upper = (r, cc - 1); column cc - 1 is the
+                // lane below's (column 0 has no current cells: the walk leaves the window at tj = 0)
+                const float left = colv[k - 1];
+                const float diag = __int_as_float(sdp::dpp_i32<sdp::DPP_WAVE_SHR1>(0, __float_as_int(colv[k - 1])));
+                const float upper = __int_as_float(sdp::dpp_i32<sdp::DPP_WAVE_SHR1>(0, __float_as_int(colv[k])));
+                const bool c1 = diag > left;
+                const float bv1 = c1 ? diag : left;
+                const bool c2 = upper > bv1;
+                const bool halt = RULE ? (left == floor_v || diag == floor_v || upper == floor_v)
+                                       : (left == floor_v && diag == floor_v && upper == floor_v);
+                code |= (halt ? 3u : (c2 ? 2u : (c1 ? 1u : 0u))) << (2 * (k - 1));
+            }
+            // The steps themselves run in segments of at most 32 that end where a group of 64 records is complete: inside a segment
+            // the states collect in a scalar (two bits per step) and nothing but the look-up, the move and the loop test is in the
+            // chain; the lanes take their records -- and a complete group leaves -- between segments.
+            while (true) {
+                const int cnt0 = cnt;
+                const int room = 64 - (cnt0 & 63), lim = room < 32 ? room : 32;
+                unsigned long long acc = 0;
+                int k = 0;
+                bool halted = false;
+                while (ti >= 1 && tj >= 1 && k < lim) {
+                    const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)code, tj + 32 * (ti >> 4));
+                    const int st = (int)((w >> (2 * (ti & 15))) & 3u);
+                    if (st == 3) {
+                        halted = true;
+                        break;
+                    }
+                    ti -= st == 2 ? 0 : 1;
+                    tj -= st == 0 ? 0 : 1;
+                    acc = (acc << 2) | (unsigned long long)st;
+                    ++k;
+                }
+                // step t of the segment (0 = first) sits in bits 2 (k - 1 - t) of acc; its record belongs to lane (cnt0 + t) mod 64
+                const int t = (lane - cnt0) & 63;
+                if (t < k) my_s = (int)((acc >> (2 * (k - 1 - t))) & 3ull);
+                cnt = cnt0 + k;
+                if (k > 0 && (cnt & 63) == 0) flush(cnt - 64, 64, r0 + ti, c0 + tj);
+                if (halted) {
+                    stop = true;
+                    break;
+                }
+                if (!(ti >= 1 && tj >= 1)) break;
+            }
+        } else if (r0 >= 0 && c0 >= 0) {
+            // ---- the same for the other window size: three LDS broadcasts and the comparisons per step ----
             while (ti >= 1 && tj >= 1) {
                 const float *p = tile + ti * TW + tj;
                 const float left = p[-TW], diag = p[-TW - 1], upper = p[-1];
