@@ -312,6 +312,8 @@ def main():
         Gm = torch.from_numpy((datagen.uniform(31, (B, N, M)) < 0.8).astype(np.float32)).to(dev)
         xl, yl = [N] * B, [M] * B
 
+    walk = {"stream": None}
+
     def step():
         if mce is not None:
             t = theta.detach().requires_grad_(True)
@@ -330,7 +332,18 @@ def main():
             return out["E_local"]
         if args.mode == "align+traceback":     # inference: the alignment matrix and its arg-max walk (alignment.py:165-170, batched)
             out = aligner.align(theta, A)
-            return out["paths"] if out.get("paths") is not None else eng.traceback(out["E_local"])
+            if out.get("paths") is not None:
+                return out["paths"]
+            E = out["E_local"]
+            ws = walk["stream"]
+            if ws is None:
+                return eng.traceback(E)
+            # (secondary figure `pipelined_walk`: the walk of this batch on a second stream, beside the sweeps of the next batch)
+            ws.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(ws):
+                paths = eng.traceback(E)
+            E.record_stream(ws)   # the allocator must not hand E's memory to the next step before the walk has read it
+            return paths
         t = theta.detach().requires_grad_(True)
         a = A.detach().requires_grad_(True)    # decode() differentiates w.r.t. (theta, A) like the reference
         aln = dec.decode(t, a)                 # forward + backward kernels (create_graph)
@@ -389,7 +402,7 @@ def main():
     value = world * per_step_updates * args.steps / elapsed
     ms = kernel_loop(timer)
 
-    no_skip = clocks = None
+    no_skip = clocks = pipelined = None
 
     def emit(e_gather, e_gather_one, paths_gather, direct=None):
         """rank 0: the ONE JSON line (called once: after the secondary measurements, or by the watchdog below)."""
@@ -476,6 +489,8 @@ def main():
                              # vmemissue.hip, profiles/r06_ubench_vmemissue.txt): what "memory-bound" means on this part
                              "measured_stream_ceilings_GBs": {"loads": 7000.0, "stores": 5400.0, "fwd_mix": 5050.0}},
             }
+            if pipelined is not None:
+                line["pipelined_walk"] = pipelined
             if no_skip is not None:
                 line["no_skip"] = no_skip
             if clocks is not None:
@@ -606,6 +621,20 @@ def main():
         finally:
             eng.zero_skip = True
             eng.launch_hook = None
+    # inference as a pipeline: a walk is one wavefront per pair, bound by memory latency, and needs 4 KB of LDS -- it fits beside the
+    # next batch's sweeps on every CU.  Same step count, same fences; every walk is inside the timed region (the closing fence
+    # synchronises the device, i.e. both streams)
+    if rank == 0 and not multi and args.mode == "align+traceback" and not os.environ.get("BENCH_NO_SECONDARY"):
+        try:
+            walk["stream"] = torch.cuda.Stream()
+            step()
+            dt_pw, _ = timed(args.steps)
+            pipelined = {"ms_per_step": dt_pw / args.steps * 1e3, "value": per_step_updates * args.steps / dt_pw, "steps": args.steps,
+                         "what": "the same step with the batched walk of batch k on a second HIP stream, beside the forward sweep of batch k + 1"}
+        except Exception as ex:   # noqa: BLE001
+            print(f"[bench] pipelined_walk failed: {ex}", file=sys.stderr, flush=True)
+        finally:
+            walk["stream"] = None
     if not os.environ.get("BENCH_NO_CLOCKS") and not os.environ.get("BENCH_NO_SECONDARY"):
         # every rank loops the same number of steps (~1.5 s by the timed region's own figure, the max over ranks); rank 0 samples
         rounds = max(1, min(400, int(1.5 / max(50 * elapsed / args.steps, 1e-4))))

@@ -105,6 +105,49 @@ def test_two_threads_two_streams_overlap():
     assert eng.check_device()[0] == 0
 
 
+def test_walks_on_a_second_stream_beside_the_next_batch_s_sweeps():
+    """Inference as a pipeline (bench.py --mode align+traceback, `pipelined_walk`): the batched walk of batch k runs on a second
+    stream while the first stream already sweeps batch k + 1.  Every batch's walks equal the ones of the serial order."""
+    from deepblast_amd._engine import get_engine
+    eng = get_engine()
+    B, N, M = 96, 200, 260
+    batches = []
+    for k in range(3):
+        theta, A = datagen.theta_A(1300 + k, B, N, M)
+        batches.append((torch.from_numpy(theta).cuda(), torch.from_numpy(A).cuda()))
+    ones = torch.ones(B, device="cuda")
+
+    def sweeps(t, a):
+        Vt, Q = eng.forward(t, a, 0)
+        return eng.backward(ones, Q, tuple(t.shape), 0)
+
+    serial = []
+    for t, a in batches:
+        st, cn = eng.traceback(sweeps(t, a))
+        serial.append((st.cpu().numpy(), cn.cpu().numpy()))
+    torch.cuda.synchronize()
+    ws = torch.cuda.Stream()
+    piped = []
+    for rnd in range(4):                       # several rounds: the allocator gets to reuse E's memory
+        for t, a in batches:
+            E = sweeps(t, a)
+            ws.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(ws):
+                st, cn = eng.traceback(E)
+            E.record_stream(ws)
+            del E
+            piped.append((st, cn))
+    torch.cuda.synchronize()
+    for i, (st, cn) in enumerate(piped):
+        want_st, want_cn = serial[i % len(batches)]
+        got_cn = cn.cpu().numpy()
+        assert np.array_equal(got_cn, want_cn), i
+        got_st = st.cpu().numpy()
+        for b in range(B):
+            assert np.array_equal(got_st[b, :got_cn[b]], want_st[b, :want_cn[b]]), (i, b)
+    assert eng.check_device()[0] == 0
+
+
 def test_pairs_over_several_workgroups_repeat_and_overlap():
     """Parts of a pair hand their boundary over through global memory with no fence and no flag (8-byte granules that
     are either the memset pattern or written, sdp_kernels.hip "bridge"), in an order that must never leave a consumer on
