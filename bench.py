@@ -635,6 +635,8 @@ def main():
             print(f"[bench] pipelined_walk failed: {ex}", file=sys.stderr, flush=True)
         finally:
             walk["stream"] = None
+    # (The same with the scores GEMM of batch k + 1 on a second stream beside the sweeps of batch k was measured in round 6 and is
+    #  no gain: 0.984 -> 0.972 ms per step -- the GEMM's workgroups fill the chip and the power budget; not kept.)
     if not os.environ.get("BENCH_NO_CLOCKS") and not os.environ.get("BENCH_NO_SECONDARY"):
         # every rank loops the same number of steps (~1.5 s by the timed region's own figure, the max over ranks); rank 0 samples
         rounds = max(1, min(400, int(1.5 / max(50 * elapsed / args.steps, 1e-4))))

@@ -1,2 +1,4 @@
+mkdir -p gpurun_out/tb
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_robustness_gpu.py -q -m gpu -k "second_stream" 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" | tail -4
+timeout 600 python bench.py --mode scores+dp --no-cpu-baseline 2> gpurun_out/tb/bench_sc.err | tee gpurun_out/tb/bench_scores.json
+tail -3 gpurun_out/tb/bench_sc.err
