@@ -1,4 +1,3 @@
-mkdir -p gpurun_out/tb
+mkdir -p gpurun_out/final
 export TMPDIR=/tmp
-timeout 600 python bench.py --mode scores+dp --no-cpu-baseline 2> gpurun_out/tb/bench_sc.err | tee gpurun_out/tb/bench_scores.json
-tail -3 gpurun_out/tb/bench_sc.err
+(timeout 1200 python tools/tb_fuzz.py 120 2026 2>&1 | grep -v amdgpu | tail -5) | tee gpurun_out/final/tb_fuzz.txt
